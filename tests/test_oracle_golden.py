@@ -1,0 +1,135 @@
+"""The oracle against the committed golden vectors (made by tools/make_goldens.py from the real
+reference).  CPU only; sized to finish in a couple of minutes."""
+import numpy as np
+import pytest
+import torch
+
+from localdiffusion_hallucination_amd import rng, schedule, weights
+from oracle import diffusion_ref, unet_ref
+
+CFG_MNIST = weights.UnetConfig(dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist")
+CFG_MRI = weights.UnetConfig(mode="mri")
+CFG_MVTEC = weights.UnetConfig(channels=3, out_dim=3, mode="mvtec")
+
+
+def sd_of(cfg):
+    return {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(cfg, 0).items()}
+
+
+class Noise:
+    def __init__(self, seed=10):
+        self.s = rng.NoiseStream(seed)
+
+    def __call__(self, shape):
+        return torch.from_numpy(self.s.next(tuple(shape)))
+
+
+def test_inventory_counts():
+    txt = open(__import__("os").path.join(__import__("conftest").GOLDEN, "g0_inventory.txt")).read().split("\n")
+    want = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in txt if l}
+    for tag, cfg in [("mnist", CFG_MNIST), ("mri", CFG_MRI), ("mvtec", CFG_MVTEC)]:
+        sh = weights.unet_param_shapes(cfg)
+        assert (len(sh), weights.num_params(cfg)) == want[tag]
+
+
+@pytest.mark.parametrize("sched", ["sigmoid", "linear", "cosine"])
+@pytest.mark.parametrize("T", [50, 100, 1000])
+def test_schedule_buffers(golden, sched, T):
+    g = golden("g1_schedules")
+    ours = schedule.make_buffers(T, sched, "pred_x0")
+    orc = diffusion_ref.schedule_buffers(sched, T, "pred_x0")
+    for name in schedule.BUFFER_NAMES:
+        ref = g[f"{sched}_{T}_{name}"]
+        assert np.array_equal(ours[name].numpy(), ref), name           # product: bit-exact
+        np.testing.assert_allclose(orc[name].numpy(), ref, rtol=3e-7, atol=1e-37)
+
+
+def test_schedule_known_answers():
+    """SURVEY.md 8a-11 KATs (sigmoid T=1000 / T=100, linear T=1000)."""
+    b = schedule.make_buffers(1000, "sigmoid")
+    assert abs(float(b["betas"][0]) - 3.0027919741e-4) < 1e-10
+    assert abs(float(b["betas"][-1]) - 0.999) < 1e-7
+    assert abs(float(b["alphas_cumprod"][-1]) - 3.0028698680e-7) < 1e-12
+    assert abs(float(b["posterior_log_variance_clipped"][0]) - (-46.051702)) < 1e-4
+    assert abs(float(b["posterior_log_variance_clipped"][1]) - (-8.800935)) < 1e-4
+    assert float(b["posterior_mean_coef1"][0]) == 1.0 and float(b["posterior_mean_coef2"][0]) == 0.0
+    assert abs(float(b["posterior_mean_coef1"][-1]) - 1.73114671e-2) < 1e-8
+    b = schedule.make_buffers(100, "sigmoid")
+    assert abs(float(b["betas"][0]) - 3.0772859361e-3) < 1e-9
+    b = schedule.make_buffers(1000, "linear")
+    assert abs(float(b["betas"][0]) - 1e-4) < 1e-10 and abs(float(b["betas"][-1]) - 2e-2) < 1e-8
+    assert abs(float(b["alphas_cumprod"][-1]) - 4.0358297654e-5) < 1e-10
+
+
+@pytest.mark.parametrize("tag,cfg,ts", [("mnist28", CFG_MNIST, (0, 5, 99)),
+                                        ("mri64", CFG_MRI, (0, 999)),
+                                        ("mvtec32", CFG_MVTEC, (3, 777))])
+def test_unet_forward(golden, tag, cfg, ts):
+    g = golden("g2_unet_forward")
+    B, C, H, cin = [int(v) for v in g[f"{tag}_shape"]]
+    sd = sd_of(cfg)
+    x = torch.from_numpy(rng.randn((B, C, H, H), 1, 100))
+    cond = torch.from_numpy(rng.uniform((B, cin, H, H), 1, 101, 0.0, 2.0))
+    for t in ts:
+        taps = {}
+        with torch.no_grad():
+            y = unet_ref.unet_forward(sd, cfg, x, cond, torch.full((B,), t, dtype=torch.long), taps)
+        np.testing.assert_allclose(y.numpy(), g[f"{tag}_t{t}_out"], atol=2e-5, rtol=0)
+        for key in g.files:
+            pre = f"{tag}_t{t}_tap_"
+            if key.startswith(pre):
+                tt = taps[key[len(pre):]].float()
+                assert abs(float(tt.mean()) - g[key][0]) < 1e-4
+                assert abs(float(tt.norm()) - g[key][1]) < 1e-3 * max(1.0, g[key][1])
+
+
+def _run(cfg, H, B, T, S, cond, mask, **kw):
+    o = diffusion_ref.SamplerOptions(timesteps=T, sampling_timesteps=S, **kw)
+    smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(cfg), cfg), o, cfg.channels, H)
+    with torch.no_grad():
+        out = smp.sample(cond, mask, (0.0, 2.0), B, Noise(10))
+    return np.stack([t.numpy() for t in out]) if isinstance(out, list) else out.numpy()
+
+
+def test_three_step_runs(golden):
+    g = golden("g3_three_step")
+    cond, mask = torch.from_numpy(g["cond"]), torch.from_numpy(g["mask"])
+    cases = {
+        "nonbranch": dict(data="mnist"),
+        "branch_fuse_mnist": dict(data="mnist", branch_out=True, start_intermediate=True, start_timestep=1, mask_x=True),
+        "branch_fuse_mri": dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=1, mask_x=True),
+        "branch_nofuse": dict(data="mri", branch_out=True, start_intermediate=False, mask_x=True),
+    }
+    for tag, kw in cases.items():
+        out = _run(CFG_MNIST, 28, 2, 3, None, cond, mask, **kw)
+        assert out.shape == g[tag].shape
+        np.testing.assert_allclose(out, g[tag], atol=1e-5, rtol=0)
+
+
+def test_cfg1_mnist_full(golden):
+    """BASELINE.json configs[0]: MNIST 28x28, T=100, 4 patches, branch + fusion."""
+    g = golden("g4_cfg1_mnist")
+    out = _run(CFG_MNIST, 28, 4, 100, None, torch.from_numpy(g["cond"]), torch.from_numpy(g["mask"]),
+               data="mnist", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True, ood_AD=True)
+    np.testing.assert_allclose(out, g["final"], atol=5e-5, rtol=0)
+
+
+def test_ddim(golden):
+    g = golden("g7_ddim")
+    cond = torch.from_numpy(rng.uniform((1, 1, 64, 64), 7, 1, 0.0, 2.0))
+    mask = torch.from_numpy(g["mask"])
+    out = _run(CFG_MRI, 64, 1, 50, 10, cond, mask, data="mri", branch_out=True, start_intermediate=False, mask_x=True)
+    np.testing.assert_allclose(out, g["nofuse_final"], atol=5e-5, rtol=0)
+    out = _run(CFG_MRI, 64, 1, 50, 10, cond, None, data="mri")
+    np.testing.assert_allclose(out, g["single_final"], atol=5e-5, rtol=0)
+
+
+def test_fallback_and_objectives(golden):
+    g = golden("g8_fallback_objectives")
+    cond = torch.from_numpy(rng.uniform((2, 1, 28, 28), 8, 1, 0.0, 2.0))
+    out = _run(CFG_MNIST, 28, 2, 20, None, cond, torch.ones(2, 1, 28, 28), data="mnist", branch_out=True,
+               start_intermediate=True, start_timestep=2, mask_x=True)
+    np.testing.assert_allclose(out, g["allones_final"], atol=1e-5, rtol=0)
+    for obj in ("pred_noise", "pred_v"):
+        out = _run(CFG_MNIST, 28, 2, 20, None, cond, None, data="mnist", objective=obj)
+        np.testing.assert_allclose(out, g[obj + "_final"], atol=1e-4, rtol=0)

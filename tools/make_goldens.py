@@ -1,0 +1,467 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  Runs ONLY in the build container (needs /root/reference).
+
+It imports the *real* reference modules (``ddpm.py``, ``attend.py``, ``unet_model.py``) through
+stub modules for the packages/files the reference imports but this image lacks,
+loads this repo's procedural weights into the reference ``Unet`` by parameter name, replaces
+``torch.randn`` / ``torch.randn_like`` with the portable counter-based generator
+(localdiffusion_hallucination_amd.rng), runs the reference's own code on CPU and
+
+  1. checks the oracle (oracle/unet_ref.py, oracle/diffusion_ref.py) against it, and
+  2. writes small input/output fixtures to tests/golden/*.npz.
+
+The fixtures are data (inputs + expected outputs); no reference source travels.
+Usage:  python tools/make_goldens.py [--only G1,G2,...] [--skip-long]
+"""
+import argparse
+import contextlib
+import gzip
+import io
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+import localdiffusion_hallucination_amd as ldh           # noqa: E402
+from localdiffusion_hallucination_amd import rng, weights, schedule   # noqa: E402
+from oracle import unet_ref, diffusion_ref                # noqa: E402
+
+
+# ----------------------------------------------------------------------------- reference import
+def import_reference():
+    sys.dont_write_bytecode = True
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return self
+
+    def mk(name):
+        m = types.ModuleType(name)
+
+        def ga(attr):
+            if attr.startswith("__"):
+                raise AttributeError(attr)
+            return _Dummy
+        m.__getattr__ = ga
+        m.__path__ = []
+        sys.modules[name] = m
+    for n in ["torchvision", "torchvision.transforms", "torchvision.utils",
+              "torchvision.transforms.functional", "ema_pytorch", "idx2numpy", "timm", "nibabel",
+              "medpy", "medpy.io", "anomalib", "anomalib.models", "anomalib.models.components",
+              "anomalib.models.patchcore", "anomalib.models.patchcore.anomaly_map",
+              "anomalib.pre_processing", "anomalib.config", "train_fusion", "data", "models"]:
+        mk(n)
+    sys.path.insert(0, REF)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import ddpm
+    torch.Tensor.cuda = lambda self, *a, **k: self          # ddpm.py:743,748,754 on a CPU box
+    return ddpm
+
+
+class PortableNoise:
+    """Monkeypatch target: every randn/randn_like call is draw #k of the portable stream."""
+
+    def __init__(self, seed=10):
+        self.seed, self.k = seed, 0
+
+    def randn(self, *shape, **kw):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        out = torch.from_numpy(rng.randn(tuple(shape), self.seed, self.k))
+        self.k += 1
+        return out
+
+    def randn_like(self, x, **kw):
+        return self.randn(tuple(x.shape))
+
+    def __call__(self, shape):
+        return self.randn(tuple(shape))
+
+
+@contextlib.contextmanager
+def reference_run(noise):
+    """temp CWD with ./fusion_test, silenced stdout, portable noise patched into torch."""
+    old = (torch.randn, torch.randn_like, os.getcwd())
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "fusion_test"))
+        os.chdir(d)
+        torch.randn, torch.randn_like = noise.randn, noise.randn_like
+        try:
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                yield
+        finally:
+            torch.randn, torch.randn_like = old[0], old[1]
+            os.chdir(old[2])
+
+
+def sd_torch(cfg, seed=0):
+    return {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(cfg, seed).items()}
+
+
+def build_reference_unet(ddpm, cfg, sd):
+    m = ddpm.Unet(dim=cfg.dim, init_dim=cfg.init_dim, out_dim=cfg.out_dim, dim_mults=cfg.dim_mults,
+                  channels=cfg.channels, full_attn=cfg.full_attn, mode=cfg.mode)
+    ref_sd = m.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), "parameter inventory differs from the reference"
+    for k in ref_sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd)
+    return m.eval()
+
+
+def base_config(**kw):
+    c = dict(branch_out=False, start_intermediate=False, start_timestep=2, data="mri", mask_x=False,
+             mask_cond=False, ood_AD=False, ood_confidence=False, classifier=False,
+             classifier_obj="tile", use_gt=False, use_gt_timestep=100, continue_fusion_timestep=0)
+    c.update(kw)
+    return c
+
+
+def opts_from(config, T, S=None, objective="pred_x0", sched="sigmoid"):
+    return diffusion_ref.SamplerOptions(
+        timesteps=T, sampling_timesteps=S, objective=objective, beta_schedule=sched,
+        branch_out=config["branch_out"], start_intermediate=config["start_intermediate"],
+        start_timestep=config["start_timestep"], data=config["data"], mask_x=config["mask_x"],
+        ood_AD=config["ood_AD"], ood_confidence=config["ood_confidence"])
+
+
+def maxdiff(a, b):
+    return float((a - b).abs().max())
+
+
+def save(name, **arrs):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+CFG_MNIST = weights.UnetConfig(dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist")
+CFG_MRI = weights.UnetConfig(mode="mri")
+CFG_MVTEC = weights.UnetConfig(channels=3, out_dim=3, mode="mvtec")
+
+
+def mnist_digits(n=4, label=3):
+    """First n test digits with the given label (config.yaml:14 anomaly_name: 3)."""
+    with gzip.open(os.path.join(REF, "MNIST/raw/t10k-images-idx3-ubyte.gz"), "rb") as f:
+        raw = f.read()
+    imgs = np.frombuffer(raw, dtype=np.uint8, offset=16).reshape(-1, 28, 28)
+    with gzip.open(os.path.join(REF, "MNIST/raw/t10k-labels-idx1-ubyte.gz"), "rb") as f:
+        lab = np.frombuffer(f.read(), dtype=np.uint8, offset=8)
+    idx = np.nonzero(lab == label)[0][:n]
+    return imgs[idx].copy()
+
+
+def mnist_lr_hr(digits):
+    """data.py:808-829 (MNIST.__getitem__): HR = 2x/255; LR = 2x-subsampled then bilinear x2."""
+    x = torch.from_numpy(digits.astype(np.float32))[:, None]
+    hr = 2.0 * x / 255.0
+    lr = torch.nn.functional.interpolate(x[:, :, ::2, ::2], scale_factor=2, mode="bilinear",
+                                         align_corners=False)
+    return 2.0 * lr / 255.0, hr
+
+
+# ----------------------------------------------------------------------------- G1 schedules
+def g1(ddpm):
+    print("G1 schedule buffers")
+    out = {}
+    for sched in ("sigmoid", "linear", "cosine"):
+        for T in (50, 100, 1000):
+            gd = _ref_diffusion(ddpm, base_config(), _DummyModel(), 28, T, sched, "pred_x0", None)
+            ours = schedule.make_buffers(T, sched, "pred_x0")
+            orc = diffusion_ref.schedule_buffers(sched, T, "pred_x0")
+            for name in schedule.BUFFER_NAMES:
+                ref = getattr(gd, name)
+                assert torch.equal(ref, ours[name]), (sched, T, name, "product schedule != reference")
+                d = maxdiff(ref, orc[name]) / max(1e-30, float(ref.abs().max()))
+                assert d < 2e-7, (sched, T, name, d)
+                out[f"{sched}_{T}_{name}"] = ref.numpy()
+    save("g1_schedules", **out)
+
+
+class _DummyModel(torch.nn.Module):
+    channels = 1
+    out_dim = 1
+    self_condition = False
+    random_or_learned_sinusoidal_cond = False
+
+
+def _ref_diffusion(ddpm, config, model, image_size, T, sched, objective, S):
+    return ddpm.GaussianDiffusion(config, model, image_size=image_size, timesteps=T,
+                                  beta_schedule=sched, objective=objective, auto_normalize=False,
+                                  sampling_timesteps=S)
+
+
+# ----------------------------------------------------------------------------- G2 forward
+def tap_stats(t):
+    t = t.detach().float()
+    flat = t.flatten()
+    idx = torch.linspace(0, flat.numel() - 1, 16).long()
+    return np.concatenate([[float(t.mean()), float(t.norm())], flat[idx].numpy()]).astype(np.float32)
+
+
+def g2(ddpm):
+    print("G2 Unet.forward")
+    out = {}
+    cases = [("mnist28", CFG_MNIST, 4, 28, (0, 5, 99)),
+             ("mri64", CFG_MRI, 1, 64, (0, 500, 999)),
+             ("mvtec32", CFG_MVTEC, 2, 32, (3, 777))]
+    for tag, cfg, B, H, ts in cases:
+        sd = sd_torch(cfg)
+        ref = build_reference_unet(ddpm, cfg, sd)
+        cin = cfg.cond_in_channels
+        x = torch.from_numpy(rng.randn((B, cfg.channels, H, H), 1, 100))
+        cond = torch.from_numpy(rng.uniform((B, cin, H, H), 1, 101, 0.0, 2.0))
+        for t in ts:
+            tv = torch.full((B,), t, dtype=torch.long)
+            hooks, caught = [], {}
+            names = dict(ref.named_modules())
+            want = [n for n in names if n in ("init_conv", "cond_model", "conv_fusion", "mid_block1",
+                                              "mid_block2", "final_res_block")
+                    or (n.count(".") == 2 and n.split(".")[0] in ("downs", "ups") and n[-1] in "01")]
+            for n in want:
+                hooks.append(names[n].register_forward_hook(
+                    lambda mod, inp, o, n=n: caught.__setitem__(n, o.detach())))
+            with torch.no_grad():
+                y_ref = ref(x, cond, tv)
+            for h in hooks:
+                h.remove()
+            taps = {}
+            with torch.no_grad():
+                y_orc = unet_ref.unet_forward(sd, cfg, x, cond, tv, taps)
+            d = maxdiff(y_ref, y_orc)
+            worst = max(maxdiff(caught[n], taps[n]) for n in want)
+            print(f"  {tag} t={t}: oracle-vs-reference out {d:.2e}, worst tap {worst:.2e}")
+            assert d <= 1e-5 and worst <= 1e-4, (tag, t, d, worst)
+            out[f"{tag}_t{t}_out"] = y_ref.numpy()
+            for n in want:
+                out[f"{tag}_t{t}_tap_{n}"] = tap_stats(caught[n])
+        out[f"{tag}_shape"] = np.array([B, cfg.channels, H, cin])
+    save("g2_unet_forward", **out)
+
+
+# ----------------------------------------------------------------------------- sampler runs
+def run_pair(ddpm, cfg, config, T, S, B, H, cond, mask, lohi, objective="pred_x0", sched="sigmoid",
+             record_ts=()):
+    """Run reference sample() and oracle sample() on identical inputs -> (ref_out, orc_out, recs)."""
+    sd = sd_torch(cfg)
+    ref_model = build_reference_unet(ddpm, cfg, sd)
+    config = dict(config)
+    gd = _ref_diffusion(ddpm, config, ref_model, H, T, sched, objective, S).eval()
+    noise = PortableNoise(10)
+    t0 = time.time()
+    with reference_run(noise):
+        with torch.inference_mode():
+            ref_out = gd.sample(cond.clone(), None, batch_size=B, mask=None if mask is None else mask.clone(),
+                                min_max_val=lohi)
+    t_ref = time.time() - t0
+    return ref_out, t_ref, sd
+
+
+def oracle_run(cfg, sd, config, T, S, B, H, cond, mask, lohi, objective="pred_x0", sched="sigmoid",
+               record=None):
+    o = opts_from(config, T, S, objective, sched)
+    smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd, cfg), o, cfg.channels, H)
+    noise = PortableNoise(10)
+    with torch.no_grad():
+        if record is None:
+            return smp.sample(cond, mask, lohi, B, noise)
+        branch, fuse = o.branch_out, o.start_intermediate
+        mask_x = o.mask_x or o.ood_AD or o.ood_confidence
+        return smp.p_sample_loop(cond, mask, lohi, (B, cfg.channels, H, H), noise, branch, fuse, mask_x,
+                                 record=record)
+
+
+def to_np(x):
+    if isinstance(x, (list, tuple)):
+        return np.stack([t.numpy() for t in x])
+    return x.numpy()
+
+
+def compare(tag, ref_out, orc_out, tol):
+    a, b = torch.from_numpy(to_np(ref_out)), torch.from_numpy(to_np(orc_out))
+    assert a.shape == b.shape, (tag, a.shape, b.shape)
+    d = maxdiff(a, b)
+    print(f"  {tag}: shape {tuple(a.shape)} oracle-vs-reference max-abs {d:.3e}")
+    assert d <= tol, (tag, d)
+    return d
+
+
+def band_mask(B, H, ncols):
+    m = torch.zeros(B, 1, H, H)
+    m[:, :, :, :ncols] = 1.0
+    return m
+
+
+def g3(ddpm):
+    """Single p_sample steps (non-branch, branch, fusion) are covered as T=3 runs with
+    start_timestep=1: step t=2 is a pure branch step, t=1 the fusion step, t=0 a joint step."""
+    print("G3 three-step runs (branch / fusion / joint)")
+    cfg, H, B = CFG_MNIST, 28, 2
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 3, 1, 0.0, 2.0))
+    mask = band_mask(B, H, 7)
+    out = {"cond": cond.numpy(), "mask": mask.numpy()}
+    for tag, kw in [("nonbranch", dict(data="mnist")),
+                    ("branch_fuse_mnist", dict(data="mnist", branch_out=True, start_intermediate=True,
+                                               start_timestep=1, mask_x=True)),
+                    ("branch_fuse_mri", dict(data="mri", branch_out=True, start_intermediate=True,
+                                             start_timestep=1, mask_x=True)),
+                    ("branch_nofuse", dict(data="mri", branch_out=True, start_intermediate=False,
+                                           mask_x=True))]:
+        config = base_config(**kw)
+        ref_out, _, sd = run_pair(ddpm, cfg, config, 3, None, B, H, cond, mask, (0.0, 2.0))
+        orc = oracle_run(cfg, sd, base_config(**kw), 3, None, B, H, cond, mask, (0.0, 2.0))
+        compare("G3 " + tag, ref_out, orc, 1e-5)
+        out[tag] = to_np(ref_out)
+    save("g3_three_step", **out)
+
+
+def g4(ddpm):
+    print("G4 cfg1: MNIST 28x28, T=100, 4 patches, branch + fusion (config.yaml defaults)")
+    cfg, H, B, T = CFG_MNIST, 28, 4, 100
+    digits = mnist_digits(B, 3)
+    lr, hr = mnist_lr_hr(digits)
+    mask = band_mask(B, H, 7)                                   # test.py:379-381
+    kw = dict(data="mnist", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True,
+              ood_AD=True)
+    ref_out, t_ref, sd = run_pair(ddpm, cfg, base_config(**kw), T, None, B, H, lr, mask, (0.0, 2.0))
+    recs = {}
+    keep = (99, 50, 10, 2, 1, 0)
+    orc = oracle_run(cfg, sd, base_config(**kw), T, None, B, H, lr, mask, (0.0, 2.0),
+                     record=lambda t, x: recs.__setitem__(t, to_np(x)) if t in keep else None)
+    compare("G4", ref_out, orc, 2e-5)
+    print(f"  reference sample() wall {t_ref:.1f}s")
+    save("g4_cfg1_mnist", digits=digits, cond=lr.numpy(), hr=hr.numpy(), mask=mask.numpy(),
+         final=to_np(ref_out), **{f"x_after_t{t}": v for t, v in recs.items()})
+
+
+def g5(ddpm):
+    print("G5 cfg2: 4-stage 1-ch 128x128, T=1000, fp32, non-branch  (several minutes)")
+    cfg, H, B, T = CFG_MRI, 128, 1, 1000
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 5, 1, 0.0, 2.0))
+    kw = dict(data="mri")
+    ref_out, t_ref, sd = run_pair(ddpm, cfg, base_config(**kw), T, None, B, H, cond, None, (0.0, 2.0))
+    print(f"  reference sample() wall {t_ref:.1f}s")
+    recs = {}
+    keep = (999, 750, 500, 250, 100, 10, 0)
+    t0 = time.time()
+    orc = oracle_run(cfg, sd, base_config(**kw), T, None, B, H, cond, None, (0.0, 2.0),
+                     record=lambda t, x: recs.__setitem__(t, to_np(x)) if t in keep else None)
+    print(f"  oracle sample() wall {time.time()-t0:.1f}s")
+    compare("G5", ref_out, orc, 1e-4)
+    save("g5_cfg2_mri128", final=to_np(ref_out), ref_seconds=np.array([t_ref]),
+         **{f"x_after_t{t}": v for t, v in recs.items()})
+
+
+def g6(ddpm):
+    print("G6 branch+fusion T=50: data='mri' 32x32 (UNet out kept) and data='mnist' 28x28")
+    out = {}
+    for tag, cfg, H, data in [("mri32", CFG_MRI, 32, "mri"), ("mnist28", CFG_MNIST, 28, "mnist")]:
+        B, T = 2, 50
+        cond = torch.from_numpy(rng.uniform((B, 1, H, H), 6, 1, 0.0, 2.0))
+        mask = band_mask(B, H, H // 4)
+        kw = dict(data=data, branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True)
+        ref_out, _, sd = run_pair(ddpm, cfg, base_config(**kw), T, None, B, H, cond, mask, (0.0, 2.0))
+        orc = oracle_run(cfg, sd, base_config(**kw), T, None, B, H, cond, mask, (0.0, 2.0))
+        compare("G6 " + tag, ref_out, orc, 2e-5)
+        out[tag + "_final"] = to_np(ref_out)
+    save("g6_branch_fusion", **out)
+
+
+def g7(ddpm):
+    print("G7 DDIM S=50 of T=1000, 64x64 1-ch, branch + fusion; and S=10 of T=50 no-fusion (list)")
+    cfg, H, B = CFG_MRI, 64, 1
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 7, 1, 0.0, 2.0))
+    mask = torch.zeros(B, 1, H, H)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(H), indexing="ij")
+    mask[:, :, ((yy - H // 2) ** 2 + (xx - H // 2) ** 2) <= (H // 8) ** 2] = 1.0
+    out = {"mask": mask.numpy()}
+    kw = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True)
+    ref_out, _, sd = run_pair(ddpm, cfg, base_config(**kw), 1000, 50, B, H, cond, mask, (0.0, 2.0))
+    orc = oracle_run(cfg, sd, base_config(**kw), 1000, 50, B, H, cond, mask, (0.0, 2.0))
+    compare("G7 fused", ref_out, orc, 2e-5)
+    out["fused_final"] = to_np(ref_out)
+    kw = dict(data="mri", branch_out=True, start_intermediate=False, mask_x=True)
+    ref_out, _, sd = run_pair(ddpm, cfg, base_config(**kw), 50, 10, B, H, cond, mask, (0.0, 2.0))
+    orc = oracle_run(cfg, sd, base_config(**kw), 50, 10, B, H, cond, mask, (0.0, 2.0))
+    compare("G7 nofuse", ref_out, orc, 2e-5)
+    out["nofuse_final"] = to_np(ref_out)
+    kw = dict(data="mri")
+    ref_out, _, sd = run_pair(ddpm, cfg, base_config(**kw), 50, 10, B, H, cond, None, (0.0, 2.0))
+    orc = oracle_run(cfg, sd, base_config(**kw), 50, 10, B, H, cond, None, (0.0, 2.0))
+    compare("G7 single", ref_out, orc, 2e-5)
+    out["single_final"] = to_np(ref_out)
+    save("g7_ddim", **out)
+
+
+def g8(ddpm):
+    print("G8 all-ones mask fallback + pred_noise / pred_v objectives (non-branch)")
+    cfg, H, B, T = CFG_MNIST, 28, 2, 20
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 8, 1, 0.0, 2.0))
+    out = {}
+    kw = dict(data="mnist", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True)
+    ones = torch.ones(B, 1, H, H)
+    ref_out, _, sd = run_pair(ddpm, cfg, base_config(**kw), T, None, B, H, cond, ones, (0.0, 2.0))
+    orc = oracle_run(cfg, sd, base_config(**kw), T, None, B, H, cond, ones, (0.0, 2.0))
+    compare("G8 all-ones", ref_out, orc, 1e-5)
+    out["allones_final"] = to_np(ref_out)
+    for obj in ("pred_noise", "pred_v"):
+        kw = dict(data="mnist")
+        ref_out, _, sd = run_pair(ddpm, cfg, base_config(**kw), T, None, B, H, cond, None, (0.0, 2.0),
+                                  objective=obj)
+        orc = oracle_run(cfg, sd, base_config(**kw), T, None, B, H, cond, None, (0.0, 2.0), objective=obj)
+        compare("G8 " + obj, ref_out, orc, 1e-4)
+        out[obj + "_final"] = to_np(ref_out)
+    save("g8_fallback_objectives", **out)
+
+
+def g0_inventory(ddpm):
+    print("G0 parameter inventory")
+    lines = []
+    for tag, cfg in [("mnist", CFG_MNIST), ("mri", CFG_MRI), ("mvtec", CFG_MVTEC)]:
+        sd = sd_torch(cfg)
+        build_reference_unet(ddpm, cfg, sd)
+        n = sum(v.numel() for v in sd.values())
+        lines.append(f"{tag} {len(sd)} {n}")
+        print("  ", lines[-1])
+    with open(os.path.join(GOLD, "g0_inventory.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--skip-long", action="store_true")
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    ddpm = import_reference()
+    os.makedirs(GOLD, exist_ok=True)
+    todo = [("G0", g0_inventory), ("G1", g1), ("G2", g2), ("G3", g3), ("G4", g4), ("G6", g6),
+            ("G7", g7), ("G8", g8), ("G5", g5)]
+    only = set(filter(None, a.only.split(",")))
+    for name, fn in todo:
+        if only and name not in only:
+            continue
+        if a.skip_long and name == "G5":
+            continue
+        t0 = time.time()
+        fn(ddpm)
+        print(f"  [{name} done in {time.time()-t0:.1f}s]")
+
+
+if __name__ == "__main__":
+    main()
