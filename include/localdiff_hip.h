@@ -1,0 +1,263 @@
+/*
+ * localdiff_hip.h -- C-ABI of the MI355X (gfx950) local-diffusion sampling hot path.
+ *
+ * The reference (edshkim98/LocalDiffusion-Hallucination) has no FFI boundary of its own: its hot
+ * path sits behind two Python nn.Module surfaces, Unet.forward (ddpm.py:404-451) and
+ * GaussianDiffusion.sample / p_sample_loop / ddim_sample / p_sample (ddpm.py:841-1125), whose
+ * bodies are stock ATen ops.  This library is what a ctypes binding on the reference side would
+ * call instead of those ATen ops; every entry point names the reference lines
+ * whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless marked "host".
+ *   - every launch function takes the HIP stream to enqueue on (void*, a hipStream_t) and returns
+ *     0 on success or a negative LD_E* code; ld_last_error() gives a thread-local message.
+ *   - no allocation, no synchronisation, no global mutable state inside launch functions, so they
+ *     may be captured into a HIP graph (ld_graph_*).
+ *   - internal activations are NHWC (channels-last) in the storage dtype (LD_F32 or LD_BF16),
+ *     accumulation is always fp32; tensors that cross the reference's API (x_t, cond, mask, model
+ *     output) are NCHW fp32 exactly as the reference holds them.
+ *   - "t_ptr" arguments are device pointers to the current timestep index (int32).  Kernels read
+ *     the step through them so that one captured graph can be replayed for every timestep; pass
+ *     NULL to mean row 0 of the table argument.
+ */
+#ifndef LOCALDIFF_HIP_H
+#define LOCALDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LD_OK 0
+#define LD_EINVAL (-1)   /* bad argument / unsupported shape */
+#define LD_EHIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
+
+#define LD_F32 0
+#define LD_BF16 1
+
+#define LD_ACT_NONE 0
+#define LD_ACT_SILU 1
+#define LD_ACT_RELU 2
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+const char* ld_last_error(void);
+int ld_version(void);
+/* host out-params: device name (buf, n), compute units, bytes of global memory */
+int ld_device_info(char* name, int name_len, int* compute_units, int64_t* global_mem_bytes);
+/* HIP-graph capture of everything enqueued on `stream` between begin and end (no tracing compiler:
+ * the host issues the step once, the graph replays it T times). */
+int ld_graph_begin(void* stream);
+int ld_graph_end(void* stream, void** graph_exec_out);
+int ld_graph_launch(void* graph_exec, void* stream);
+int ld_graph_destroy(void* graph_exec);
+/* hipMemsetAsync(ptr, 0, bytes) on the stream (statistics arenas are zeroed once per forward) */
+int ld_memset_zero(void* ptr, size_t bytes, void* stream);
+/* event timing on the stream the kernels run on (bench.py's roofline leg) */
+int ld_event_create(void** ev_out);
+int ld_event_record(void* ev, void* stream);
+int ld_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on stop */
+int ld_event_destroy(void* ev);
+
+/* ---- one input of a convolution, with an optional normalise-on-load prologue --------------- */
+/* Replaces the separate GroupNorm / FiLM / SiLU / ReLU / concat / nearest-upsample passes of
+ * Block.forward (ddpm.py:177-186), ResnetBlock.forward (:200-212), Upsample (:114-118),
+ * torch.cat (:435,439,442,448) and BasicBlock (unet_model.py:19-26): the consumer convolution
+ * applies  y = act(x * a[b,c] + s[b,c])  while staging its input tile, where a,s come from the
+ * producer's GroupNorm statistics (sum, sum of squares per (batch, group), fp64), gamma/beta and
+ * the FiLM (scale+1, shift) row of this timestep. */
+typedef struct ld_src {
+  const void* data;        /* NHWC [B, Hs, Ws, C], storage dtype */
+  int32_t C;               /* channels (multiple of 32) */
+  int32_t pix_stride;      /* elements between consecutive pixels; 0 = C (dense). Lets a conv read a
+                              channel slice, e.g. q = channels [0,hidden) of a qkv tensor */
+  int32_t upsample;        /* 1: source is [B, H/2, W/2, C], read with nearest x2 */
+  const double* gn_stats;  /* [B, groups, 2] or NULL = no prologue */
+  const float* gn_gamma;   /* [C] */
+  const float* gn_beta;    /* [C] */
+  int32_t gn_groups;
+  int32_t act;             /* LD_ACT_* applied after the affine */
+  const float* film;       /* [rows, 2*C] (scale | shift) or NULL */
+  int32_t film_tstride;    /* floats between timestep rows (0 if per-batch rows only) */
+  int32_t film_bstride;    /* floats between batch rows (0 if shared by the batch) */
+} ld_src;
+
+/* ---- 3x3 convolution, pad 1, implicit GEMM on MFMA ----------------------------------------- */
+/* nn.Conv2d(k=3,p=1): Block.proj (ddpm.py:173), Upsample conv (:117), stage convs (:372,:391),
+ * BasicBlock convs (unet_model.py:20,24,30).  Epilogue adds bias and (optionally) accumulates the
+ * GroupNorm statistics of the result for the next layer (ddpm.py:174 / unet_model.py:21,25,31). */
+typedef struct ld_conv3x3_args {
+  ld_src src[2];           /* channel-concatenated inputs (torch.cat order) */
+  int32_t nsrc;
+  const void* weight;      /* packed by ld_pack_conv_weight, storage dtype */
+  const float* bias;       /* [Cout] fp32 */
+  void* out;               /* NHWC [B,H,W,Cout] */
+  double* out_stats;       /* [B, out_groups, 2] accumulated (caller zeroes) or NULL */
+  int32_t out_groups;
+  int32_t B, H, W, Cout;   /* Cout multiple of 32 */
+  const int32_t* t_ptr;
+  int32_t dtype;
+} ld_conv3x3_args;
+int ld_conv3x3(const ld_conv3x3_args* args, void* stream);
+
+/* ---- 1x1 convolution (GEMM over channels) -------------------------------------------------- */
+#define LD_EPI_PLAIN 0      /* out = W x + b                                                    */
+#define LD_EPI_QKV_LINEAR 1 /* LinearAttention.to_qkv (ddpm.py:239-245): first `hidden` outputs   */
+                            /* (q) get softmax over each head's 32 channels times dim_head^-0.5  */
+#define LD_EPI_QKV_FULL 2   /* Attention.to_qkv (ddpm.py:276) with attend.py:98's scale folded   */
+                            /* into q                                                           */
+#define LD_EPI_RMS_RES 3    /* to_out conv + RMSNorm + residual (ddpm.py:229-232,251,425,444)    */
+#define LD_EPI_RES 4        /* to_out conv + residual (ddpm.py:269,282,425,431)                  */
+typedef struct ld_conv1x1_args {
+  ld_src src[2];
+  int32_t nsrc;
+  int32_t unshuffle;       /* 1: Downsample (ddpm.py:120-124): src[0] is [B,2H,2W,C], K = 4C in  */
+                           /*    (p1,p2,c) order (weights repacked accordingly)                  */
+  int32_t rms_in;          /* 1: RMSNorm on the input (ddpm.py:131-132): columns scaled by        */
+                           /*    1/max(||x_p||,1e-12); g*sqrt(C) is folded into `weight`          */
+  const void* weight;
+  int64_t weight_bstride;  /* bytes between per-batch weight sets (linear attention) or 0        */
+  const float* bias;       /* [Cout] or NULL */
+  int32_t epilogue;        /* LD_EPI_* */
+  int32_t hidden;          /* heads*dim_head for the QKV epilogues */
+  float q_scale;           /* dim_head^-0.5 */
+  const float* g2;         /* [Cout] g*sqrt(Cout) for LD_EPI_RMS_RES */
+  const void* residual;    /* NHWC [B,H,W,Cout] for *_RES */
+  void* out;
+  int32_t B, H, W, Cout;
+  int32_t dtype;
+} ld_conv1x1_args;
+int ld_conv1x1(const ld_conv1x1_args* args, void* stream);
+
+/* Repack an OIHW fp32 convolution weight (device) into the MFMA fragment order the kernels read.
+ * ksize 1 or 3.  `scale_in` (optional, [Cin]) multiplies input channel c (RMSNorm g*sqrt(C)).
+ * unshuffle=1 reorders K from (c,p1,p2) to (p1,p2,c).  out must hold Cout*Cin*k*k elements. */
+int ld_pack_conv_weight(const float* w_oihw, const float* scale_in, void* out, int cout, int cin,
+                        int ksize, int unshuffle, int dtype, void* stream);
+
+/* ---- small-Cin direct convolution from an NCHW fp32 image --------------------------------- */
+/* init_conv 7x7 (ddpm.py:319,413) and the first BasicBlock convs (unet_model.py:20,30) whose
+ * Cin is 1 or 3.  Cout must be 32.  Output NHWC storage dtype (+ optional GN statistics). */
+int ld_conv_image(const float* x_nchw, const float* w_oihw, const float* bias, void* out,
+                  double* out_stats, int out_groups, int B, int Cin, int H, int W, int ksize,
+                  int dtype, void* stream);
+
+/* ---- GroupNorm apply (+FiLM) + activation + residual, optional second normalised input ----- */
+/* ResnetBlock tail  h = SiLU(GN(conv2)) + res(x)  (ddpm.py:210-212) and BasicBlock tail
+ * ReLU(GN(conv2) + GN(conv_id)) followed by MaxPool2d(2) (unet_model.py:38-51,120,123,129). */
+typedef struct ld_gn_apply_args {
+  ld_src a;                /* first input, prologue required */
+  ld_src b;                /* optional second input (data NULL = none); gn_stats NULL = raw add */
+  int32_t final_act;       /* LD_ACT_* after the sum */
+  int32_t pool;            /* 1: 2x2 max-pool the result (out is [B,H/2,W/2,C]) */
+  void* out;
+  int32_t B, H, W;         /* input spatial size */
+  const int32_t* t_ptr;
+  int32_t dtype;
+} ld_gn_apply_args;
+int ld_gn_apply(const ld_gn_apply_args* args, void* stream);
+
+/* ---- attention ---------------------------------------------------------------------------- */
+/* Linear attention core (ddpm.py:243,247,249) on a qkv tensor [B, n, 3*hidden] whose q part was
+ * already soft-maxed by ld_conv1x1(LD_EPI_QKV_LINEAR):
+ *   1. ld_linattn_kmax:  per (b, k-channel) partial maxima over n             (softmax over n)
+ *   2. ld_linattn_ctx:   partial  ctx[d,e] = sum_n exp(k-max) v,  Z[d] = sum_n exp(k-max)
+ *   3. ld_linattn_fold:  M_b = W_out . (ctx/Z)^T  packed as a per-batch 1x1 weight, so that
+ *                        to_out(ctx^T q) becomes ONE 1x1 convolution over q (ld_conv1x1). */
+int ld_linattn_kmax(const void* qkv, float* kmax_part, int B, int n, int heads, int dim_head,
+                    int nparts, int dtype, void* stream);
+int ld_linattn_ctx(const void* qkv, const float* kmax_part, int nparts, float* ctx_part,
+                   int B, int n, int heads, int dim_head, int nchunks, int dtype, void* stream);
+int ld_linattn_fold(const float* ctx_part, int nchunks, const float* w_out /*[C,hidden] fp32*/,
+                    void* w_packed /*[B] packed C x hidden*/, int B, int C, int heads, int dim_head,
+                    int dtype, void* stream);
+size_t ld_linattn_ctx_part_floats(int B, int heads, int dim_head, int nchunks);
+
+/* Full softmax attention (attend.py:84-113) on qkv [B, n, 3*hidden] with q pre-scaled;
+ * out [B, n, hidden].  Flash-style (the n x n similarity matrix is never materialised). */
+int ld_attention(const void* qkv, void* out, int B, int n, int heads, int dim_head, int dtype,
+                 void* stream);
+
+/* ---- timestep embedding (ddpm.py:136-149, 339-344, 191-206) -------------------------------- */
+/* temb[i] = Linear(GELU(Linear(sincos(times[i]))))  for i < n;  freqs [dim/2] fp32 (host-made). */
+int ld_time_mlp(const int32_t* times, int n, const float* freqs, int dim, const float* w1,
+                const float* b1, const float* w2, const float* b2, int time_dim, float* temb,
+                void* stream);
+/* film[i] = Linear(SiLU(temb[i]))  -> [n, 2*C] */
+int ld_film(const float* temb, int n, int time_dim, const float* w, const float* b, int two_c,
+            float* film, void* stream);
+
+/* ---- final 1x1 conv to the image (ddpm.py:398,451): NHWC storage -> NCHW fp32 -------------- */
+int ld_final_conv(const void* x, const float* w /*[Cout,Cin]*/, const float* b, float* out_nchw,
+                  int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
+/* ---- reverse-process pointwise kernels (NCHW fp32) ---------------------------------------- */
+#define LD_OBJ_X0 0
+#define LD_OBJ_NOISE 1
+#define LD_OBJ_V 2
+/* schedule table row layout (floats): see LD_SCHED_* ; built by the host from the fp32 buffers */
+#define LD_SCHED_COLS 8
+#define LD_SCHED_COEF1 0      /* posterior_mean_coef1                (ddpm.py:592) */
+#define LD_SCHED_COEF2 1      /* posterior_mean_coef2                (ddpm.py:593) */
+#define LD_SCHED_SIGMA 2      /* exp(0.5*posterior_log_variance_clipped) (ddpm.py:591,853) */
+#define LD_SCHED_SQRT_RECIP 3 /* sqrt(1/abar)                        (ddpm.py:578) */
+#define LD_SCHED_SQRT_RECIPM1 4 /* sqrt(1/abar-1)                    (ddpm.py:579) */
+#define LD_SCHED_SQRT_AB 5    /* sqrt(abar)                          (ddpm.py:575) */
+#define LD_SCHED_SQRT_1MAB 6  /* sqrt(1-abar)                        (ddpm.py:576) */
+#define LD_SCHED_ABAR 7       /* abar                                (ddpm.py:570) */
+
+/* portable counter-based normals (rng.py): stream = stream_base + stream_tmul * (*t_ptr) */
+int ld_randn(float* out, int64_t n, uint64_t seed, int64_t stream_base, int64_t stream_tmul,
+             const int32_t* t_ptr, void* stream);
+/* *t_ptr += delta  (graph-replayable step counter) */
+int ld_step_add(int32_t* t_ptr, int delta, void* stream);
+
+/* p_sample, single branch (ddpm.py:631-666, 739-761, 817-838, 857-858):
+ *   x0 = clamp(to_x0(model_out)), x_prev = c1*x0 + c2*x_t + (t>0 ? sigma*z : 0).
+ * x0_out may be NULL.  noise may be NULL when t == 0 is guaranteed. */
+int ld_ddpm_step(const float* x_t, const float* model_out, const float* noise, float* x_prev,
+                 float* x0_out, const float* sched, const int32_t* t_ptr, float lo, float hi,
+                 int objective, int64_t n, void* stream);
+/* DDIM update (ddpm.py:1046-1068): x0 = clamp(to_x0(model_out)); eps re-derived from x0;
+ * x_next = x0*sqrt(abar_next) + c*eps + sigma*z.  Scalars are host-computed per pair.
+ * last=1 writes x0 (time_next < 0, :1053-1056). */
+int ld_ddim_step(const float* x_t, const float* model_out, const float* noise, float* x_next,
+                 float sqrt_recip, float sqrt_recipm1, float sqrt_ab, float sqrt_1mab,
+                 float sqrt_abar_next, float c, float sigma, float lo, float hi, int objective,
+                 int last, int64_t n, void* stream);
+/* branch conditioning (ddpm.py:672-690): binary=(mask>=1); cond_out=cond*binary;
+ * cond_in=cond*clip(1-binary, lo_clip, 1).  mask [B,1,H,W], cond [B,C,H,W]. */
+int ld_branch_conditions(const float* cond, const float* mask, float* cond_out, float* cond_in,
+                         float lo_clip, int B, int C, int HW, void* stream);
+/* mask_x on the OOD-branch prediction (ddpm.py:700-703): where(binary==0, min_val, out*binary) */
+int ld_mask_out(float* model_out, const float* mask, float min_val, int B, int C, int HW,
+                void* stream);
+/* DDPM fusion step recomposition (ddpm.py:775-776, 784-804) from per-branch x_t and per-branch
+ * x0 predictions (clamped here):  x0 = clamp(clamp(x0_in)*(1-m) + clamp(x0_out));
+ *   x = where(x_out*m == 0, x_in*(1-m), x_out*m) */
+int ld_fuse_ddpm(const float* x_out, const float* x_in, const float* x0_out, const float* x0_in,
+                 const float* mask, float* x, float* x0, float lo, float hi, int B, int C, int HW,
+                 void* stream);
+/* posterior step from an already-formed x0 (fusion step, ddpm.py:809 + :858) */
+int ld_posterior_step(const float* x_t, const float* x0, const float* noise, float* x_prev,
+                      const float* sched, const int32_t* t_ptr, int64_t n, void* stream);
+/* DDIM fusion (ddpm.py:1025-1041): x0 = clamp(where(x0o==0, x0i, x0o)); eps = where(eo*m==0,
+ * ei*(1-m), eo*m) with e* re-derived from the clamped per-branch x0;  x_next as ld_ddim_step. */
+int ld_fuse_ddim(const float* x_out, const float* x_in, const float* x0_out, const float* x0_in,
+                 const float* mask, const float* noise, float* x_next, float sqrt_recip,
+                 float sqrt_recipm1, float sqrt_abar_next, float c, float sigma, float lo,
+                 float hi, int B, int C, int HW, void* stream);
+/* q_sample (ddpm.py:1148-1154) for the use_gt start (:937-944) */
+int ld_q_sample(const float* x0, const float* noise, float* out, float sqrt_ab, float sqrt_1mab,
+                int64_t n, void* stream);
+/* recomposition of K gathered local patches by their masks (north-star multi-GPU path,
+ * SURVEY.md 8e): out[b] = sum_k patches[b,k]*m_k  with m_k = (masks[k] >= 1) */
+int ld_recompose(const float* patches /*[B,K,C,HW]*/, const float* masks /*[K,HW]*/, float* out,
+                 int B, int K, int C, int HW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCALDIFF_HIP_H */

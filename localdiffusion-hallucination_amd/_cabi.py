@@ -1,0 +1,129 @@
+"""ctypes binding of ``csrc/liblocaldiff_hip.so`` (declared in ``include/localdiff_hip.h``).
+
+This is the only way the package reaches the GPU: there is no CPU fallback.  ``lib()`` raises
+``RuntimeError`` when the shared library is missing or a symbol the header declares cannot be
+resolved, so a broken build can never silently run something else.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblocaldiff_hip.so")
+
+LD_F32, LD_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
+EPI_PLAIN, EPI_QKV_LINEAR, EPI_QKV_FULL, EPI_RMS_RES, EPI_RES = 0, 1, 2, 3, 4
+OBJ = {"pred_x0": 0, "pred_noise": 1, "pred_v": 2}
+SCHED_COLS = 8
+
+vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+
+
+class Src(C.Structure):
+    _fields_ = [("data", vp), ("C", i32), ("pix_stride", i32), ("upsample", i32), ("gn_stats", vp),
+                ("gn_gamma", vp), ("gn_beta", vp), ("gn_groups", i32), ("act", i32), ("film", vp),
+                ("film_tstride", i32), ("film_bstride", i32)]
+
+
+class Conv3x3Args(C.Structure):
+    _fields_ = [("src", Src * 2), ("nsrc", i32), ("weight", vp), ("bias", vp), ("out", vp),
+                ("out_stats", vp), ("out_groups", i32), ("B", i32), ("H", i32), ("W", i32),
+                ("Cout", i32), ("t_ptr", vp), ("dtype", i32)]
+
+
+class Conv1x1Args(C.Structure):
+    _fields_ = [("src", Src * 2), ("nsrc", i32), ("unshuffle", i32), ("rms_in", i32), ("weight", vp),
+                ("weight_bstride", i64), ("bias", vp), ("epilogue", i32), ("hidden", i32),
+                ("q_scale", f32), ("g2", vp), ("residual", vp), ("out", vp), ("B", i32), ("H", i32),
+                ("W", i32), ("Cout", i32), ("dtype", i32)]
+
+
+class GnApplyArgs(C.Structure):
+    _fields_ = [("a", Src), ("b", Src), ("final_act", i32), ("pool", i32), ("out", vp), ("B", i32),
+                ("H", i32), ("W", i32), ("t_ptr", vp), ("dtype", i32)]
+
+
+# name -> (restype, argtypes); must list every function include/localdiff_hip.h declares
+_SIGS = {
+    "ld_last_error": (C.c_char_p, []),
+    "ld_version": (C.c_int, []),
+    "ld_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64)]),
+    "ld_graph_begin": (C.c_int, [vp]),
+    "ld_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "ld_graph_launch": (C.c_int, [vp, vp]),
+    "ld_graph_destroy": (C.c_int, [vp]),
+    "ld_memset_zero": (C.c_int, [vp, C.c_size_t, vp]),
+    "ld_event_create": (C.c_int, [C.POINTER(vp)]),
+    "ld_event_record": (C.c_int, [vp, vp]),
+    "ld_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
+    "ld_event_destroy": (C.c_int, [vp]),
+    "ld_conv3x3": (C.c_int, [C.POINTER(Conv3x3Args), vp]),
+    "ld_conv1x1": (C.c_int, [C.POINTER(Conv1x1Args), vp]),
+    "ld_pack_conv_weight": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_conv_image": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, vp]),
+    "ld_gn_apply": (C.c_int, [C.POINTER(GnApplyArgs), vp]),
+    "ld_linattn_kmax": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_linattn_ctx": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, vp]),
+    "ld_linattn_fold": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_linattn_ctx_part_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ld_attention": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_time_mlp": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),
+    "ld_film": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]),
+    "ld_final_conv": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_randn": (C.c_int, [vp, i64, u64, i64, i64, vp, vp]),
+    "ld_step_add": (C.c_int, [vp, C.c_int, vp]),
+    "ld_ddpm_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, i64, vp]),
+    "ld_posterior_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp]),
+    "ld_ddim_step": (C.c_int, [vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, C.c_int,
+                               C.c_int, i64, vp]),
+    "ld_branch_conditions": (C.c_int, [vp, vp, vp, vp, f32, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_mask_out": (C.c_int, [vp, vp, f32, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_fuse_ddpm": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_fuse_ddim": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, C.c_int,
+                               C.c_int, C.c_int, vp]),
+    "ld_q_sample": (C.c_int, [vp, vp, vp, f32, f32, i64, vp]),
+    "ld_recompose": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first call).  Raises RuntimeError if it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or csrc/build.sh).  There is no CPU fallback for the HIP hot path.")
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = l
+    return l
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ld_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"localdiff_hip {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(name):
+    return {"fp32": LD_F32, "float32": LD_F32, "bf16": LD_BF16, "bfloat16": LD_BF16}[name]

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build liblocaldiff_hip.so for gfx950 (cross-compiles without a GPU).  Usage: ./build.sh [-j N]
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off"
+mkdir -p build
+pids=()
+for f in runtime pack conv3x3 conv1x1 conv_image gn_apply linattn attention time_embed pointwise; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.cuh -nt build/$f.o ] || [ ../../include/localdiff_hip.h -nt build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/*.o -o liblocaldiff_hip.so
+echo "built $(pwd)/liblocaldiff_hip.so"

@@ -1,0 +1,184 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, MFMA 16x16 tiles, 64-byte K-chunks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <type_traits>
+
+#include "../../include/localdiff_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __bf16 bf16;
+
+// ---------------------------------------------------------------- host-side error plumbing
+int ld_fail(int code, const char* fmt, ...);   // runtime.hip
+#define LD_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) return ld_fail(LD_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+#define LD_LAUNCH_CHECK(name)                                                          \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess) return ld_fail(LD_EHIP, "%s launch: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+#define LD_REQUIRE(cond, ...)                                                          \
+  do {                                                                                 \
+    if (!(cond)) return ld_fail(LD_EINVAL, __VA_ARGS__);                               \
+  } while (0)
+
+// Opt a kernel into > 64 KiB of dynamic LDS once per process.
+template <typename K>
+static inline hipError_t ld_allow_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// ---------------------------------------------------------------- dtype traits
+// One "fragment" is 16 bytes per lane for both storage types: 8 bf16 or 4 fp32 consecutive
+// channels.  A K-chunk is 4 fragments = 64 bytes of channels per pixel (32 bf16 / 16 fp32).
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int E = 4;       // elements per fragment
+  static constexpr int CK = 16;     // channels per K-chunk
+  static constexpr bool precise = true;
+};
+template <> struct DT<bf16> {
+  static constexpr int E = 8;
+  static constexpr int CK = 32;
+  static constexpr bool precise = false;
+};
+
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* v);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* v) {
+  v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y);
+  v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16>(const uint4& r, float* v) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+  v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved)
+  bf16 a = (bf16)lo, b = (bf16)hi;
+  unsigned short ua = __builtin_bit_cast(unsigned short, a), ub = __builtin_bit_cast(unsigned short, b);
+  return (unsigned)ua | ((unsigned)ub << 16);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* v);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* v) {
+  return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16>(const float* v) {
+  return make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                    pack_bf16x2(v[6], v[7]));
+}
+
+// 4 consecutive output channels (one accumulator fragment) -> 8 or 16 bytes
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
+  float4 r = *reinterpret_cast<const float4*>(p);
+  v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+}
+template <> __device__ __forceinline__ void load4<bf16>(const bf16* p, float* v) {
+  uint2 r = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+
+// ---------------------------------------------------------------- MFMA, D[cout 16][pixel 16]
+// A = weights fragment (row = output channel, lane&15), B = activation fragment (col = pixel,
+// lane&15); both hold the K-slice (lane>>4).  D: col = lane&15, row = 4*(lane>>4) + reg.
+// fp32 uses v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain, exact f32) four times per fragment:
+// step e consumes element e of both fragments, i.e. K index 4*(lane>>4)+e of the chunk.
+template <typename T> __device__ __forceinline__ void mma16(f32x4& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<bf16>(f32x4& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------- activations
+template <bool PRECISE> __device__ __forceinline__ float silu_f(float v) {
+  if constexpr (PRECISE) return v / (1.0f + expf(-v));
+  else return v * __frcp_rn(1.0f + __expf(-v));
+}
+template <bool PRECISE> __device__ __forceinline__ float act_f(float v, int act) {
+  if (act == LD_ACT_SILU) return silu_f<PRECISE>(v);
+  if (act == LD_ACT_RELU) return fmaxf(v, 0.0f);
+  return v;
+}
+
+// ---------------------------------------------------------------- normalise-on-load coefficients
+// Device mirror of ld_src (kernel-argument POD).
+struct SrcDev {
+  const void* data;
+  const double* stats;
+  const float* gamma;
+  const float* beta;
+  const float* film;
+  int C, ld, ups, groups, act, film_tstride, film_bstride;   // ld = elements between pixels
+};
+static inline SrcDev to_dev(const ld_src& s) {
+  SrcDev d;
+  d.data = s.data; d.stats = s.gn_stats; d.gamma = s.gn_gamma; d.beta = s.gn_beta; d.film = s.film;
+  d.C = s.C; d.ld = s.pix_stride > 0 ? s.pix_stride : s.C; d.ups = s.upsample; d.groups = s.gn_groups; d.act = s.act;
+  d.film_tstride = s.film_tstride; d.film_bstride = s.film_bstride;
+  return d;
+}
+
+// Build y = x*a + s coefficients for batch element b into LDS: coef[0..C) = a, coef[C..2C) = s.
+//   a = rstd*gamma*(scale+1),  s = (beta - mean*rstd*gamma)*(scale+1) + shift
+// (GroupNorm eps 1e-5, biased variance: ddpm.py:174 / unet_model.py:21; FiLM: ddpm.py:181-183).
+// npix = pixels the statistics were accumulated over (the producer's H*W).
+__device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, long npix, float* coef,
+                                              int tid, int nthreads) {
+  const int C = S.C, gs = C / S.groups;
+  const double inv_n = 1.0 / ((double)npix * gs);
+  const float* film = S.film ? S.film + (long)trow * S.film_tstride + (long)b * S.film_bstride : nullptr;
+  for (int c = tid; c < C; c += nthreads) {
+    const int g = c / gs;
+    const double sum = S.stats[((long)b * S.groups + g) * 2 + 0];
+    const double sq = S.stats[((long)b * S.groups + g) * 2 + 1];
+    const double mean = sum * inv_n;
+    double var = sq * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    float a = rstd * S.gamma[c];
+    float s = S.beta[c] - (float)mean * a;
+    if (film) {
+      const float sc = film[c] + 1.0f, sh = film[C + c];
+      a *= sc;
+      s = s * sc + sh;
+    }
+    coef[c] = a;
+    coef[C + c] = s;
+  }
+}
+
+__device__ __forceinline__ float wave16_sum(float v) {
+  // sum over the 16 lanes that share (lane >> 4); xor masks < 16 stay inside the group
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}

@@ -1,0 +1,268 @@
+// 1x1 convolution = GEMM over channels on MFMA, NHWC, gfx950, with the attention plumbing of the
+// reference fused in as prologues / epilogues:
+//   - input: channel concat of two tensors (res_conv over torch.cat, ddpm.py:198,439-443),
+//            pixel-unshuffle gather (Downsample, ddpm.py:120-124),
+//            RMSNorm on the input (ddpm.py:131-132,237,274): the per-pixel 1/max(||x||,1e-12) is
+//            accumulated while the tile is staged and applied to the output column; g*sqrt(C) is
+//            folded into the packed weight;
+//   - output: bias; q-softmax over each head's 32 channels * dim_head^-0.5 (ddpm.py:242,245);
+//            RMSNorm over the output channels + residual (ddpm.py:229-232,425,444);
+//            residual add (ddpm.py:425,431,444);
+//   - per-batch weights (weight_bstride) so that linear attention's  to_out(ctx^T q)  is one GEMM
+//     with M_b = W_out (ctx_b/Z_b)^T  (see linattn.hip).
+//
+// Tiling: 256 threads = 4 waves; tile = 64*NW consecutive pixels of one image x 16*MT output
+// channels; wave w owns pixel tiles [w*NW,(w+1)*NW) and all MT channel tiles.
+#include "common.cuh"
+
+namespace {
+
+struct Conv1Dev {
+  SrcDev s[2];
+  int nsrc, unshuffle, rms_in;
+  const void* w;
+  long w_bstride;
+  const float* bias;
+  int epi, hidden;
+  float q_scale;
+  const float* g2;
+  const void* res;
+  void* out;
+  int B, H, W, Cout;
+};
+
+template <typename T, int MT, int NW>
+__global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
+  constexpr int E = DT<T>::E, CK = DT<T>::CK;
+  constexpr int NPT = 64 * NW, PLANE = NPT * 16;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_x = smem;
+  char* s_w = smem + 4 * PLANE;
+  float* s_rinv = reinterpret_cast<float*>(s_w + MT * 1024);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.z, m0 = blockIdx.y * MT;
+  const int HW = a.H * a.W, p0 = blockIdx.x * NPT;
+  const int mt_total = a.Cout / 16;
+
+  f32x4 acc[MT][NW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float rs[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) rs[i] = 0.f;
+
+  // K-chunk bookkeeping: plain = chunks of src0 then src1; unshuffle = 4 sub-pixels x chunks of src0
+  const int nc0 = a.s[0].C / CK;
+  const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
+  const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)b * a.w_bstride);
+
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();
+    int si = 0, c0, p1 = 0, p2 = 0;
+    if (a.unshuffle) {
+      const int pp = ch / nc0;
+      c0 = (ch - pp * nc0) * CK;
+      p1 = pp >> 1; p2 = pp & 1;
+    } else {
+      si = ch >= nc0 ? 1 : 0;
+      c0 = (ch - si * nc0) * CK;
+    }
+    const T* sdata = reinterpret_cast<const T*>(si ? a.s[1].data : a.s[0].data);
+    const int Cs = si ? a.s[1].ld : a.s[0].ld;   // pixel stride in elements
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int qq = (it * 4 + wv) * 16 + px;
+      const int p = p0 + qq;
+      uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+      if (p < HW) {
+        size_t pix;
+        if (a.unshuffle) {
+          const int y = p / a.W, x = p - y * a.W;
+          pix = ((size_t)b * (2 * a.H) + 2 * y + p1) * (2 * a.W) + 2 * x + p2;
+        } else {
+          pix = (size_t)b * HW + p;
+        }
+        raw = *reinterpret_cast<const uint4*>(sdata + pix * Cs + c0 + kq * E);
+        if (a.rms_in) {
+          float v[E];
+          unpack16<T>(raw, v);
+#pragma unroll
+          for (int e = 0; e < E; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
+        }
+      }
+      *reinterpret_cast<uint4*>(s_x + kq * PLANE + qq * 16) = raw;
+    }
+    if (tid < MT * 64) {
+      *reinterpret_cast<uint4*>(s_w + tid * 16) = wg[((size_t)ch * mt_total + m0) * 64 + tid];
+    }
+    if (MT * 64 > 256) {
+#pragma unroll
+      for (int u = 256 + tid; u < MT * 64; u += 256)
+        *reinterpret_cast<uint4*>(s_w + u * 16) = wg[((size_t)ch * mt_total + m0) * 64 + u];
+    }
+    __syncthreads();
+    uint4 A[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) A[m] = *reinterpret_cast<const uint4*>(s_w + m * 1024 + lane * 16);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + kq * PLANE + ((wv * NW + j) * 16 + px) * 16);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[m], Bf);
+    }
+  }
+
+  if (a.rms_in) {
+    // the 4 kq lanes of a staged pixel sit 16 lanes apart in the same wave
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      float r = rs[it];
+      r += __shfl_xor(r, 16);
+      r += __shfl_xor(r, 32);
+      if (kq == 0) s_rinv[(it * 4 + wv) * 16 + px] = 1.0f / fmaxf(sqrtf(r), 1e-12f);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channels (m0+m)*16 + 4kq + r of pixel p0 + (wv*NW+j)*16 + px
+  T* out = reinterpret_cast<T*>(a.out);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  const bool q_part = (m0 * 16) < a.hidden;
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int qq = (wv * NW + j) * 16 + px;
+    const int p = p0 + qq;
+    const bool valid = p < HW;
+    const float rinv = a.rms_in ? s_rinv[qq] : 1.0f;
+    float v[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int co = (m0 + m) * 16 + kq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[m][r] = acc[m][j][r] * rinv + (a.bias ? a.bias[co + r] : 0.f);
+    }
+    if (a.epi == LD_EPI_QKV_LINEAR && q_part) {
+      // softmax over the 32 channels of each head = 2 channel tiles x 4 regs x 4 kq lanes
+#pragma unroll
+      for (int m = 0; m < MT; m += 2) {   // MT is even; (m, m+1) = one head
+        float mx = v[m][0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mx = fmaxf(mx, v[m][r]); mx = fmaxf(mx, v[m + 1][r]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[m][r] = expf(v[m][r] - mx); v[m + 1][r] = expf(v[m + 1][r] - mx);
+          sum += v[m][r] + v[m + 1][r];
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float sc = a.q_scale / sum;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[m][r] *= sc; v[m + 1][r] *= sc; }
+      }
+    } else if (a.epi == LD_EPI_QKV_FULL && q_part) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[m][r] *= a.q_scale;
+    } else if (a.epi == LD_EPI_RMS_RES) {
+      float ss = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss = fmaf(v[m][r], v[m][r], ss);
+      ss += __shfl_xor(ss, 16);
+      ss += __shfl_xor(ss, 32);
+      const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int co = (m0 + m) * 16 + kq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[m][r] = v[m][r] * inv * a.g2[co + r];
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int co = (m0 + m) * 16 + kq * 4;
+        const size_t o = ((size_t)b * HW + p) * a.Cout + co;
+        if (a.epi == LD_EPI_RMS_RES || a.epi == LD_EPI_RES) {
+          float rv[4];
+          load4<T>(res + o, rv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
+        }
+        store4<T>(out + o, v[m]);
+      }
+    }
+  }
+}
+
+template <typename T, int MT, int NW>
+int launch(const Conv1Dev& a, hipStream_t st) {
+  constexpr int NPT = 64 * NW;
+  const size_t lds = 4 * NPT * 16 + MT * 1024 + NPT * sizeof(float);
+  const int HW = a.H * a.W;
+  dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
+  hipLaunchKernelGGL((conv1x1_kernel<T, MT, NW>), grid, dim3(256), lds, st, a);
+  LD_LAUNCH_CHECK("conv1x1");
+  return LD_OK;
+}
+
+template <typename T>
+int dispatch(const Conv1Dev& a, hipStream_t st) {
+  const int HW = a.H * a.W;
+  if (a.epi == LD_EPI_RMS_RES) {
+    switch (a.Cout) {
+      case 32: return launch<T, 2, 2>(a, st);
+      case 64: return launch<T, 4, 2>(a, st);
+      case 128: return launch<T, 8, 2>(a, st);
+      default: return ld_fail(LD_EINVAL, "ld_conv1x1: RMS_RES epilogue supports Cout 32/64/128 (got %d)", a.Cout);
+    }
+  }
+  const bool mt4 = (a.Cout % 64) == 0;
+  const long blocks4 = (long)((HW + 255) / 256) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
+  const bool big = blocks4 >= 512;
+  if (mt4) return big ? launch<T, 4, 4>(a, st) : launch<T, 4, 2>(a, st);
+  return big ? launch<T, 2, 4>(a, st) : launch<T, 2, 2>(a, st);
+}
+
+}  // namespace
+
+extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
+  LD_REQUIRE(p != nullptr, "ld_conv1x1: null args");
+  LD_REQUIRE(p->nsrc == 1 || p->nsrc == 2, "ld_conv1x1: nsrc must be 1 or 2");
+  LD_REQUIRE(p->dtype == LD_F32 || p->dtype == LD_BF16, "ld_conv1x1: bad dtype %d", p->dtype);
+  LD_REQUIRE(p->Cout > 0 && p->Cout % 32 == 0, "ld_conv1x1: Cout %d must be a multiple of 32", p->Cout);
+  LD_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->weight && p->out, "ld_conv1x1: bad shape/null");
+  LD_REQUIRE(!(p->unshuffle && p->nsrc != 1), "ld_conv1x1: unshuffle takes one source");
+  LD_REQUIRE(p->epilogue >= LD_EPI_PLAIN && p->epilogue <= LD_EPI_RES, "ld_conv1x1: bad epilogue");
+  if (p->epilogue == LD_EPI_QKV_LINEAR || p->epilogue == LD_EPI_QKV_FULL)
+    LD_REQUIRE(p->hidden > 0 && p->hidden % 64 == 0 && p->Cout == 3 * p->hidden,
+               "ld_conv1x1: QKV epilogue needs Cout == 3*hidden, hidden %% 64 == 0");
+  if (p->epilogue == LD_EPI_RMS_RES) LD_REQUIRE(p->g2 && p->residual, "ld_conv1x1: RMS_RES needs g2/residual");
+  if (p->epilogue == LD_EPI_RES) LD_REQUIRE(p->residual, "ld_conv1x1: RES needs residual");
+  Conv1Dev a;
+  for (int s = 0; s < p->nsrc; ++s) {
+    LD_REQUIRE(p->src[s].data && p->src[s].C > 0 && p->src[s].C % 32 == 0,
+               "ld_conv1x1: src[%d] null or C %% 32 != 0", s);
+    LD_REQUIRE(p->src[s].gn_stats == nullptr && !p->src[s].upsample,
+               "ld_conv1x1: GroupNorm/upsample prologues are 3x3-only");
+    a.s[s] = to_dev(p->src[s]);
+  }
+  if (p->nsrc == 1) a.s[1] = a.s[0];
+  a.nsrc = p->nsrc; a.unshuffle = p->unshuffle; a.rms_in = p->rms_in;
+  a.w = p->weight; a.w_bstride = p->weight_bstride; a.bias = p->bias;
+  a.epi = p->epilogue;
+  a.hidden = (p->epilogue == LD_EPI_QKV_LINEAR || p->epilogue == LD_EPI_QKV_FULL) ? p->hidden : 0;
+  a.q_scale = p->q_scale; a.g2 = p->g2; a.res = p->residual; a.out = p->out;
+  a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return p->dtype == LD_F32 ? dispatch<float>(a, st) : dispatch<bf16>(a, st);
+}

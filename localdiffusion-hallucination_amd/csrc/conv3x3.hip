@@ -1,0 +1,272 @@
+// 3x3 convolution (pad 1) as an implicit GEMM on MFMA, NHWC, gfx950.
+//
+// Replaces nn.Conv2d(k=3,p=1) in Block.proj (ddpm.py:173), Upsample (:117), the last-stage
+// convs (:372,:391) and BasicBlock (unet_model.py:20,24,30), with
+//   - prologue fused into the input staging: channel concat of two sources (torch.cat,
+//     ddpm.py:435-448), nearest x2 upsample (:116), GroupNorm-apply + FiLM + SiLU/ReLU of the
+//     producer (:179-185, unet_model.py:21-22);
+//   - epilogue: bias, GroupNorm statistics of the result (sum, sum^2 per (batch, group), fp64
+//     atomics -- one per group per workgroup), NHWC store.
+//
+// Tiling.  Workgroup = 256 threads = 4 waves; output tile = (4*NW rows) x 16 cols of pixels x
+// (16*MT) output channels.  Wave w owns rows [w*NW, (w+1)*NW) (each row = one 16-pixel MFMA
+// column tile) and all MT channel tiles: acc[MT][NW] fragments of 16x16.
+// K loop over 64-byte channel chunks (32 bf16 / 16 fp32 channels):
+//   LDS input image  [kq 0..3][halo pixel q][16 B]   -- plane stride = multiple of 256 B, so the
+//       16 lanes of a ds_read_b128 group (consecutive q, same kq) hit 16 distinct 16-B slots for
+//       every tap offset: conflict-free without a swizzle;
+//   LDS weights      [tap][m][lane][16 B]            -- already in fragment order in HBM
+//       (ld_pack_conv_weight), read linearly.
+// Inner order: dx outer (3*MT weight fragments live), then halo rows rr: one activation fragment
+// feeds the (up to) 3 taps dy that touch it => 9*MT + 3*(NW+2) LDS reads per 9*MT*NW MFMAs.
+#include "common.cuh"
+
+namespace {
+
+struct Conv3Dev {
+  SrcDev s[2];
+  int nsrc;
+  const void* w;
+  const float* bias;
+  void* out;
+  double* ostats;
+  int ogroups;
+  int B, H, W, Cout;
+  const int* t_ptr;
+  int tiles_x;
+};
+
+template <typename T, int MT, int NW>
+__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
+  constexpr int E = DT<T>::E, CK = DT<T>::CK;
+  constexpr int TR = 4 * NW, TC = 16, HR = TR + 2, HC = TC + 2;
+  constexpr int NPIX = HR * HC, NPIXP = (NPIX + 15) / 16 * 16, PLANE = NPIXP * 16;
+  constexpr int ITER = (NPIXP + 63) / 64;
+  constexpr bool P = DT<T>::precise;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_x = smem;
+  char* s_w = smem + 4 * PLANE;
+  float* s_coef = reinterpret_cast<float*>(s_w + 9 * MT * 1024);
+  const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
+  float* s_stat = s_coef + 2 * ctot;          // [2][16*MT]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.z, m0 = blockIdx.y * MT;
+  const int ty0 = (blockIdx.x / a.tiles_x) * TR, tx0 = (blockIdx.x % a.tiles_x) * TC;
+  const int H = a.H, W = a.W;
+  const int trow = a.t_ptr ? *a.t_ptr : 0;
+
+  // ---- prologue coefficients
+  {
+    int off = 0;
+    for (int s = 0; s < a.nsrc; ++s) {
+      const SrcDev& S = a.s[s];
+      if (S.stats) {
+        const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
+        build_gn_coef(S, b, trow, npix, s_coef + off, tid, 256);
+      }
+      off += 2 * S.C;
+    }
+    if (tid < 32 * MT) s_stat[tid] = 0.0f;
+  }
+
+  f32x4 acc[MT][NW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nch0 = a.s[0].C / CK;
+  const int nch = nch0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
+  const int mt_total = a.Cout / 16;
+
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();   // previous chunk fully consumed (and, first time, coefficients visible)
+    const int si = ch >= nch0 ? 1 : 0;
+    const SrcDev S = si ? a.s[1] : a.s[0];   // uniform select (no dynamic kernarg indexing)
+    const int c0 = (ch - si * nch0) * CK;
+    const int coef_off = si ? 2 * a.s[0].C : 0;
+    const T* sdata = reinterpret_cast<const T*>(S.data);
+    const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
+    const bool has_coef = S.stats != nullptr;
+
+    // ---- stage the halo tile of this channel chunk: wave handles 16 halo pixels x 4 fragments
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int q = (it * 4 + wv) * 16 + px;
+      if (q < NPIXP) {
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (q < NPIX) {
+          const int hy = q / HC, hx = q - hy * HC;
+          const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+          if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const int sy = S.ups ? gy >> 1 : gy, sx = S.ups ? gx >> 1 : gx;
+            const size_t idx = (((size_t)b * Hs + sy) * Ws + sx) * S.ld + c0 + kq * E;
+            raw = *reinterpret_cast<const uint4*>(sdata + idx);
+            if (has_coef) {
+              float v[E];
+              unpack16<T>(raw, v);
+              const float* ca = s_coef + coef_off + c0 + kq * E;
+              const float* cs = ca + S.C;
+#pragma unroll
+              for (int e = 0; e < E; ++e) v[e] = act_f<P>(fmaf(v[e], ca[e], cs[e]), S.act);
+              raw = pack16<T>(v);
+            }
+          }
+        }
+        *reinterpret_cast<uint4*>(s_x + kq * PLANE + q * 16) = raw;
+      }
+    }
+    // ---- stage the weights of this chunk: 9 taps x MT tiles x 1 KiB, linear copy
+    {
+      const uint4* wg = reinterpret_cast<const uint4*>(a.w);
+      constexpr int UNITS = 9 * MT * 64;
+#pragma unroll
+      for (int u0 = 0; u0 < UNITS; u0 += 256) {
+        const int u = u0 + tid;
+        if (u < UNITS) {
+          const int tap = u / (MT * 64), r = u - tap * (MT * 64);
+          const size_t gi = (((size_t)ch * 9 + tap) * mt_total + m0) * 64 + r;
+          *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[gi];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      uint4 A[3][MT];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          A[dy][m] = *reinterpret_cast<const uint4*>(s_w + ((dy * 3 + dx) * MT + m) * 1024 + lane * 16);
+#pragma unroll
+      for (int rr = 0; rr < NW + 2; ++rr) {
+        const uint4 Bf = *reinterpret_cast<const uint4*>(
+            s_x + kq * PLANE + (((wv * NW + rr) * HC + dx + px) * 16));
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int j = rr - dy;
+          if (j >= 0 && j < NW) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[dy][m], Bf);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, statistics, NHWC store.  lane holds channels 16m+4kq..+3 of pixel px.
+  T* out = reinterpret_cast<T*>(a.out);
+  const int gx = tx0 + px;
+  float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int co = (m0 + m) * 16 + kq * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int gy = ty0 + wv * NW + j;
+      const bool valid = gy < H && gx < W;
+      float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
+      if (valid) {
+        store4<T>(out + (((size_t)b * H + gy) * W + gx) * a.Cout + co, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
+      }
+    }
+  }
+  if (a.ostats) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
+        if (px == 0) {
+          atomicAdd(&s_stat[m * 16 + kq * 4 + r], s1);
+          atomicAdd(&s_stat[16 * MT + m * 16 + kq * 4 + r], s2);
+        }
+      }
+    __syncthreads();
+    const int gs = a.Cout / a.ogroups;          // channels per group; gs <= 16*MT by construction
+    const int ngrp_blk = (16 * MT) / gs;
+    if (tid < ngrp_blk) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int c = 0; c < gs; ++c) { s1 += s_stat[tid * gs + c]; s2 += s_stat[16 * MT + tid * gs + c]; }
+      const int g = (m0 * 16) / gs + tid;
+      atomicAdd(&a.ostats[((size_t)b * a.ogroups + g) * 2 + 0], s1);
+      atomicAdd(&a.ostats[((size_t)b * a.ogroups + g) * 2 + 1], s2);
+    }
+  }
+}
+
+template <typename T, int MT, int NW>
+int launch(const Conv3Dev& a, hipStream_t st) {
+  constexpr int TR = 4 * NW, HR = TR + 2, HC = 18;
+  constexpr int NPIXP = (HR * HC + 15) / 16 * 16;
+  const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
+  const size_t lds = 4 * NPIXP * 16 + 9 * MT * 1024 + 2 * ctot * sizeof(float) + 2 * 16 * MT * sizeof(float);
+  static size_t allowed = 0;
+  if (lds > allowed) {
+    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW>, lds));
+    allowed = lds;
+  }
+  Conv3Dev d = a;
+  d.tiles_x = (a.W + 15) / 16;
+  const int tiles_y = (a.H + TR - 1) / TR;
+  dim3 grid(d.tiles_x * tiles_y, a.Cout / (16 * MT), a.B);
+  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NW>), grid, dim3(256), lds, st, d);
+  LD_LAUNCH_CHECK("conv3x3");
+  return LD_OK;
+}
+
+template <typename T>
+int dispatch(const Conv3Dev& a, hipStream_t st) {
+  const bool mt4 = (a.Cout % 64) == 0;
+  // enough workgroups to fill 256 CUs a couple of times over with the big tile?
+  const long blocks16 = (long)((a.W + 15) / 16) * ((a.H + 15) / 16) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
+  const bool big = blocks16 >= 512 && a.H >= 16;
+  if (mt4) return big ? launch<T, 4, 4>(a, st) : launch<T, 4, 2>(a, st);
+  return big ? launch<T, 2, 4>(a, st) : launch<T, 2, 2>(a, st);
+}
+
+}  // namespace
+
+extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
+  LD_REQUIRE(p != nullptr, "ld_conv3x3: null args");
+  LD_REQUIRE(p->nsrc == 1 || p->nsrc == 2, "ld_conv3x3: nsrc must be 1 or 2 (got %d)", p->nsrc);
+  LD_REQUIRE(p->dtype == LD_F32 || p->dtype == LD_BF16, "ld_conv3x3: bad dtype %d", p->dtype);
+  LD_REQUIRE(p->Cout > 0 && p->Cout % 32 == 0, "ld_conv3x3: Cout %d must be a multiple of 32", p->Cout);
+  LD_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0, "ld_conv3x3: bad shape");
+  LD_REQUIRE(p->weight && p->bias && p->out, "ld_conv3x3: null weight/bias/out");
+  Conv3Dev a;
+  a.nsrc = p->nsrc;
+  for (int s = 0; s < p->nsrc; ++s) {
+    const ld_src& S = p->src[s];
+    LD_REQUIRE(S.data != nullptr, "ld_conv3x3: src[%d] null", s);
+    LD_REQUIRE(S.C > 0 && S.C % 32 == 0, "ld_conv3x3: src[%d].C=%d must be a multiple of 32", s, S.C);
+    if (S.upsample) LD_REQUIRE(p->H % 2 == 0 && p->W % 2 == 0, "ld_conv3x3: upsample needs even H,W");
+    if (S.gn_stats) {
+      LD_REQUIRE(S.gn_gamma && S.gn_beta && S.gn_groups > 0 && S.C % S.gn_groups == 0,
+                 "ld_conv3x3: src[%d] GroupNorm prologue incomplete", s);
+    }
+    a.s[s] = to_dev(S);
+  }
+  if (p->nsrc == 1) a.s[1] = a.s[0];
+  if (p->out_stats) {
+    LD_REQUIRE(p->out_groups > 0 && p->Cout % p->out_groups == 0 && (p->Cout / p->out_groups) <= 32,
+               "ld_conv3x3: out_groups %d incompatible with Cout %d", p->out_groups, p->Cout);
+  }
+  a.w = p->weight; a.bias = p->bias; a.out = p->out; a.ostats = p->out_stats;
+  a.ogroups = p->out_groups > 0 ? p->out_groups : 1;
+  a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout; a.t_ptr = p->t_ptr; a.tiles_x = 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return p->dtype == LD_F32 ? dispatch<float>(a, st) : dispatch<bf16>(a, st);
+}

@@ -1,0 +1,56 @@
+// Weight repacking into MFMA fragment order (run once at model load).
+//
+// Packed layout, storage dtype, E = 16/sizeof(T) elements per fragment, CK = 4E channels/chunk:
+//   k=3:  [chunk][tap 0..8][mtile][kq 0..3][i 0..15][e]   = W[16*mtile+i][chunk*CK+kq*E+e][tap/3][tap%3]
+//   k=1:  [chunk][mtile][kq][i][e]                         = W[16*mtile+i][chunk*CK+kq*E+e]
+// so that lane l = kq*16+i of a wave reads its A fragment (16 B) at byte offset 16*l of a 1 KiB
+// block: global->LDS staging is a linear copy and LDS fragment reads are conflict-free.
+#include "common.cuh"
+
+namespace {
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ w, const float* __restrict__ scale_in, T* out,
+                            int cout, int cin, int ks, int unshuffle) {
+  constexpr int E = DT<T>::E, CK = DT<T>::CK;
+  const long total = (long)cout * cin * ks * ks;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int mt_total = cout / 16, taps = ks * ks;
+  long r = idx;
+  const int e = r % E; r /= E;
+  const int i = r % 16; r /= 16;
+  const int kq = r % 4; r /= 4;
+  const int m = r % mt_total; r /= mt_total;
+  const int tap = r % taps; r /= taps;
+  const int ch = (int)r;
+  const int co = m * 16 + i;
+  int ci = ch * CK + kq * E + e;
+  if (unshuffle) {            // packed K order (p1,p2,c) <- reference order (c,p1,p2)
+    const int c4 = cin / 4, pp = ci / c4, c = ci - pp * c4;
+    ci = c * 4 + pp;
+  }
+  float v = w[((long)co * cin + ci) * taps + tap];
+  if (scale_in) v *= scale_in[ci];
+  out[idx] = from_f<T>(v);
+}
+}  // namespace
+
+extern "C" int ld_pack_conv_weight(const float* w, const float* scale_in, void* out, int cout, int cin,
+                                   int ksize, int unshuffle, int dtype, void* stream) {
+  LD_REQUIRE(w && out, "ld_pack_conv_weight: null pointer");
+  LD_REQUIRE(ksize == 1 || ksize == 3, "ld_pack_conv_weight: ksize %d", ksize);
+  LD_REQUIRE(cout % 16 == 0 && cin % 32 == 0, "ld_pack_conv_weight: cout %% 16 / cin %% 32 (%d,%d)", cout, cin);
+  LD_REQUIRE(!(unshuffle && (ksize != 1 || cin % 128 != 0)), "ld_pack_conv_weight: unshuffle needs k=1, cin %% 128 == 0");
+  const long total = (long)cout * cin * ksize * ksize;
+  const int bs = 256;
+  const unsigned grid = (unsigned)((total + bs - 1) / bs);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == LD_F32)
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(bs), 0, st, w, scale_in, (float*)out, cout, cin, ksize, unshuffle);
+  else if (dtype == LD_BF16)
+    hipLaunchKernelGGL(pack_kernel<bf16>, dim3(grid), dim3(bs), 0, st, w, scale_in, (bf16*)out, cout, cin, ksize, unshuffle);
+  else
+    return ld_fail(LD_EINVAL, "ld_pack_conv_weight: bad dtype %d", dtype);
+  LD_LAUNCH_CHECK("pack_conv_weight");
+  return LD_OK;
+}

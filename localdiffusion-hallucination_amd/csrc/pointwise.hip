@@ -1,0 +1,268 @@
+// Pointwise kernels of the reverse process (NCHW fp32 boundary tensors) and the final 1x1 conv.
+// All are HBM-streaming; the per-step coefficients come from a device schedule table indexed
+// through t_ptr so the whole step is HIP-graph replayable.
+#include "common.cuh"
+
+namespace {
+constexpr int BS = 256;
+inline unsigned nblocks(long n, int per = 1) {
+  long b = (n + (long)BS * per - 1) / ((long)BS * per);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * BS + threadIdx.x; i < (n); i += (long)gridDim.x * BS)
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+__device__ __forceinline__ float to_x0(float x, float mo, const float* row, int obj) {
+  if (obj == LD_OBJ_X0) return mo;
+  if (obj == LD_OBJ_NOISE) return row[LD_SCHED_SQRT_RECIP] * x - row[LD_SCHED_SQRT_RECIPM1] * mo;
+  return row[LD_SCHED_SQRT_AB] * x - row[LD_SCHED_SQRT_1MAB] * mo;
+}
+
+// ---------------------------------------------------------------- RNG (rng.py, same integers)
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void randn_kernel(float* out, long n, unsigned long long seed, long stream_base, long stream_tmul,
+                             const int* t_ptr) {
+  const long stream = stream_base + (t_ptr ? stream_tmul * (long)(*t_ptr) : 0);
+  const unsigned long long base = mix64(seed ^ ((unsigned long long)stream * 0xD1B54A32D192ED03ull));
+  GRID_STRIDE(i, n) {
+    const unsigned long long h = mix64(base + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull);
+    const float u1 = ((float)(unsigned)(h >> 40) + 1.0f) * 5.9604644775390625e-8f;          // 2^-24
+    const float u2 = (float)(unsigned)((h >> 16) & 0xFFFFFFu) * 5.9604644775390625e-8f;
+    out[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+  }
+}
+__global__ void step_add_kernel(int* t, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *t += delta; }
+
+// ---------------------------------------------------------------- DDPM / DDIM steps
+__global__ void ddpm_step_kernel(const float* x, const float* mo, const float* z, float* xp, float* x0o,
+                                 const float* sched, const int* t_ptr, float lo, float hi, int obj, long n) {
+  const int t = t_ptr ? *t_ptr : 0;
+  const float* row = sched + (size_t)t * LD_SCHED_COLS;
+  const float c1 = row[LD_SCHED_COEF1], c2 = row[LD_SCHED_COEF2], sg = row[LD_SCHED_SIGMA];
+  GRID_STRIDE(i, n) {
+    const float xi = x[i];
+    const float x0 = clampf(to_x0(xi, mo[i], row, obj), lo, hi);
+    const float mean = c1 * x0 + c2 * xi;
+    xp[i] = (t > 0) ? mean + sg * z[i] : mean;
+    if (x0o) x0o[i] = x0;
+  }
+}
+__global__ void posterior_step_kernel(const float* x, const float* x0, const float* z, float* xp,
+                                      const float* sched, const int* t_ptr, long n) {
+  const int t = t_ptr ? *t_ptr : 0;
+  const float* row = sched + (size_t)t * LD_SCHED_COLS;
+  const float c1 = row[LD_SCHED_COEF1], c2 = row[LD_SCHED_COEF2], sg = row[LD_SCHED_SIGMA];
+  GRID_STRIDE(i, n) {
+    const float mean = c1 * x0[i] + c2 * x[i];
+    xp[i] = (t > 0) ? mean + sg * z[i] : mean;
+  }
+}
+struct DdimK { float sr, srm1, sab, s1mab, san, c, sigma, lo, hi; int obj, last; };
+__global__ void ddim_step_kernel(const float* x, const float* mo, const float* z, float* xn, DdimK k, long n) {
+  GRID_STRIDE(i, n) {
+    const float xi = x[i], m = mo[i];
+    float x0;
+    if (k.obj == LD_OBJ_X0) x0 = m;
+    else if (k.obj == LD_OBJ_NOISE) x0 = k.sr * xi - k.srm1 * m;
+    else x0 = k.sab * xi - k.s1mab * m;
+    x0 = clampf(x0, k.lo, k.hi);
+    if (k.last) { xn[i] = x0; continue; }
+    const float eps = (k.sr * xi - x0) / k.srm1;
+    xn[i] = x0 * k.san + k.c * eps + k.sigma * (z ? z[i] : 0.f);
+  }
+}
+
+// ---------------------------------------------------------------- branch / fusion
+__global__ void branch_cond_kernel(const float* cond, const float* mask, float* co, float* ci, float lo_clip,
+                                   int C, int HW, long n) {
+  GRID_STRIDE(i, n) {
+    const long bc = i / HW, p = i - bc * HW, b = bc / C;
+    const float bin = mask[b * HW + p] >= 1.0f ? 1.0f : 0.0f;
+    const float c = cond[i];
+    co[i] = c * bin;
+    ci[i] = c * clampf(1.0f - bin, lo_clip, 1.0f);
+  }
+}
+__global__ void mask_out_kernel(float* mo, const float* mask, float min_val, int C, int HW, long n) {
+  GRID_STRIDE(i, n) {
+    const long bc = i / HW, p = i - bc * HW, b = bc / C;
+    const float bin = mask[b * HW + p] >= 1.0f ? 1.0f : 0.0f;
+    mo[i] = (bin == 0.0f) ? min_val : mo[i] * bin;
+  }
+}
+__global__ void fuse_ddpm_kernel(const float* xo, const float* xi, const float* x0o, const float* x0i,
+                                 const float* mask, float* x, float* x0, float lo, float hi, int C, int HW, long n) {
+  GRID_STRIDE(i, n) {
+    const long bc = i / HW, p = i - bc * HW, b = bc / C;
+    const float m = mask[b * HW + p] >= 1.0f ? 1.0f : 0.0f;
+    // per-branch clamp (ddpm.py:775-776) then recomposition + clamp (:785-786, :803-804)
+    x0[i] = clampf(clampf(x0i[i], lo, hi) * (1.0f - m) + clampf(x0o[i], lo, hi), lo, hi);
+    const float a = xo[i] * m, c = xi[i] * (1.0f - m);
+    x[i] = (a == 0.0f) ? c : a;
+  }
+}
+struct FuseDdimK { float sr, srm1, san, c, sigma, lo, hi; };
+__global__ void fuse_ddim_kernel(const float* xo, const float* xi, const float* x0o, const float* x0i,
+                                 const float* mask, const float* z, float* xn, FuseDdimK k, int C, int HW, long n) {
+  GRID_STRIDE(i, n) {
+    const long bc = i / HW, p = i - bc * HW, b = bc / C;
+    const float m = mask[b * HW + p] >= 1.0f ? 1.0f : 0.0f;
+    const float a0 = clampf(x0o[i], k.lo, k.hi), b0 = clampf(x0i[i], k.lo, k.hi);   // clip_x_start (:726-727)
+    const float eo = (k.sr * xo[i] - a0) / k.srm1, ei = (k.sr * xi[i] - b0) / k.srm1;
+    const float x0 = clampf((a0 == 0.0f) ? b0 : a0, k.lo, k.hi);
+    const float po = eo * m, pi = ei * (1.0f - m);
+    const float eps = (po == 0.0f) ? pi : po;
+    xn[i] = x0 * k.san + k.c * eps + k.sigma * (z ? z[i] : 0.f);
+  }
+}
+__global__ void q_sample_kernel(const float* x0, const float* z, float* out, float sab, float s1mab, long n) {
+  GRID_STRIDE(i, n) out[i] = sab * x0[i] + s1mab * z[i];
+}
+__global__ void recompose_kernel(const float* patches, const float* masks, float* out, int K, int C, int HW, long n) {
+  GRID_STRIDE(i, n) {                       // i over [B, C, HW]
+    const long bc = i / HW, p = i - bc * HW, b = bc / C, c = bc - b * C;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float m = masks[(size_t)k * HW + p] >= 1.0f ? 1.0f : 0.0f;
+      acc += patches[(((size_t)b * K + k) * C + c) * HW + p] * m;
+    }
+    out[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------- final 1x1 conv -> NCHW fp32
+template <typename T>
+__global__ void final_conv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float* __restrict__ out, int HW, int Cin, int Cout, long npix) {
+  GRID_STRIDE(i, npix) {                    // i over [B, HW]
+    const long b = i / HW, p = i - b * HW;
+    const T* xp = x + (size_t)i * Cin;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < Cin; c += 4) {
+      float v[4];
+      load4<T>(xp + c, v);
+      for (int o = 0; o < Cout; ++o) {
+        const float* wr = w + (size_t)o * Cin + c;
+        acc[o] = fmaf(v[0], wr[0], fmaf(v[1], wr[1], fmaf(v[2], wr[2], fmaf(v[3], wr[3], acc[o]))));
+      }
+    }
+    for (int o = 0; o < Cout; ++o) out[((size_t)b * Cout + o) * HW + p] = acc[o] + bias[o];
+  }
+}
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int ld_randn(float* out, int64_t n, uint64_t seed, int64_t stream_base, int64_t stream_tmul,
+                        const int32_t* t_ptr, void* stream) {
+  LD_REQUIRE(out && n > 0, "ld_randn: bad args");
+  hipLaunchKernelGGL(randn_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), out, (long)n,
+                     (unsigned long long)seed, (long)stream_base, (long)stream_tmul, t_ptr);
+  LD_LAUNCH_CHECK("randn");
+  return LD_OK;
+}
+extern "C" int ld_step_add(int32_t* t_ptr, int delta, void* stream) {
+  LD_REQUIRE(t_ptr, "ld_step_add: null");
+  hipLaunchKernelGGL(step_add_kernel, dim3(1), dim3(64), 0, ST(stream), t_ptr, delta);
+  LD_LAUNCH_CHECK("step_add");
+  return LD_OK;
+}
+extern "C" int ld_ddpm_step(const float* x_t, const float* model_out, const float* noise, float* x_prev,
+                            float* x0_out, const float* sched, const int32_t* t_ptr, float lo, float hi,
+                            int objective, int64_t n, void* stream) {
+  LD_REQUIRE(x_t && model_out && x_prev && sched && n > 0, "ld_ddpm_step: null pointer");
+  LD_REQUIRE(objective >= 0 && objective <= 2, "ld_ddpm_step: objective %d", objective);
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, model_out, noise, x_prev,
+                     x0_out, sched, t_ptr, lo, hi, objective, (long)n);
+  LD_LAUNCH_CHECK("ddpm_step");
+  return LD_OK;
+}
+extern "C" int ld_posterior_step(const float* x_t, const float* x0, const float* noise, float* x_prev,
+                                 const float* sched, const int32_t* t_ptr, int64_t n, void* stream) {
+  LD_REQUIRE(x_t && x0 && x_prev && sched && n > 0, "ld_posterior_step: null pointer");
+  hipLaunchKernelGGL(posterior_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, x0, noise, x_prev,
+                     sched, t_ptr, (long)n);
+  LD_LAUNCH_CHECK("posterior_step");
+  return LD_OK;
+}
+extern "C" int ld_ddim_step(const float* x_t, const float* model_out, const float* noise, float* x_next,
+                            float sqrt_recip, float sqrt_recipm1, float sqrt_ab, float sqrt_1mab,
+                            float sqrt_abar_next, float c, float sigma, float lo, float hi, int objective,
+                            int last, int64_t n, void* stream) {
+  LD_REQUIRE(x_t && model_out && x_next && n > 0, "ld_ddim_step: null pointer");
+  DdimK k{sqrt_recip, sqrt_recipm1, sqrt_ab, sqrt_1mab, sqrt_abar_next, c, sigma, lo, hi, objective, last};
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, model_out, noise, x_next, k, (long)n);
+  LD_LAUNCH_CHECK("ddim_step");
+  return LD_OK;
+}
+extern "C" int ld_branch_conditions(const float* cond, const float* mask, float* cond_out, float* cond_in,
+                                    float lo_clip, int B, int C, int HW, void* stream) {
+  LD_REQUIRE(cond && mask && cond_out && cond_in, "ld_branch_conditions: null pointer");
+  const long n = (long)B * C * HW;
+  hipLaunchKernelGGL(branch_cond_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), cond, mask, cond_out, cond_in, lo_clip, C, HW, n);
+  LD_LAUNCH_CHECK("branch_conditions");
+  return LD_OK;
+}
+extern "C" int ld_mask_out(float* model_out, const float* mask, float min_val, int B, int C, int HW, void* stream) {
+  LD_REQUIRE(model_out && mask, "ld_mask_out: null pointer");
+  const long n = (long)B * C * HW;
+  hipLaunchKernelGGL(mask_out_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), model_out, mask, min_val, C, HW, n);
+  LD_LAUNCH_CHECK("mask_out");
+  return LD_OK;
+}
+extern "C" int ld_fuse_ddpm(const float* x_out, const float* x_in, const float* x0_out, const float* x0_in,
+                            const float* mask, float* x, float* x0, float lo, float hi, int B, int C, int HW,
+                            void* stream) {
+  LD_REQUIRE(x_out && x_in && x0_out && x0_in && mask && x && x0, "ld_fuse_ddpm: null pointer");
+  const long n = (long)B * C * HW;
+  hipLaunchKernelGGL(fuse_ddpm_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_out, x_in, x0_out, x0_in, mask, x, x0, lo, hi, C, HW, n);
+  LD_LAUNCH_CHECK("fuse_ddpm");
+  return LD_OK;
+}
+extern "C" int ld_fuse_ddim(const float* x_out, const float* x_in, const float* x0_out, const float* x0_in,
+                            const float* mask, const float* noise, float* x_next, float sqrt_recip,
+                            float sqrt_recipm1, float sqrt_abar_next, float c, float sigma, float lo, float hi,
+                            int B, int C, int HW, void* stream) {
+  LD_REQUIRE(x_out && x_in && x0_out && x0_in && mask && x_next, "ld_fuse_ddim: null pointer");
+  const long n = (long)B * C * HW;
+  FuseDdimK k{sqrt_recip, sqrt_recipm1, sqrt_abar_next, c, sigma, lo, hi};
+  hipLaunchKernelGGL(fuse_ddim_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_out, x_in, x0_out, x0_in, mask, noise, x_next, k, C, HW, n);
+  LD_LAUNCH_CHECK("fuse_ddim");
+  return LD_OK;
+}
+extern "C" int ld_q_sample(const float* x0, const float* noise, float* out, float sqrt_ab, float sqrt_1mab,
+                           int64_t n, void* stream) {
+  LD_REQUIRE(x0 && noise && out && n > 0, "ld_q_sample: null pointer");
+  hipLaunchKernelGGL(q_sample_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x0, noise, out, sqrt_ab, sqrt_1mab, (long)n);
+  LD_LAUNCH_CHECK("q_sample");
+  return LD_OK;
+}
+extern "C" int ld_recompose(const float* patches, const float* masks, float* out, int B, int K, int C, int HW,
+                            void* stream) {
+  LD_REQUIRE(patches && masks && out && K > 0, "ld_recompose: bad args");
+  const long n = (long)B * C * HW;
+  hipLaunchKernelGGL(recompose_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), patches, masks, out, K, C, HW, n);
+  LD_LAUNCH_CHECK("recompose");
+  return LD_OK;
+}
+extern "C" int ld_final_conv(const void* x, const float* w, const float* b, float* out_nchw, int B, int H, int W,
+                             int Cin, int Cout, int dtype, void* stream) {
+  LD_REQUIRE(x && w && b && out_nchw, "ld_final_conv: null pointer");
+  LD_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 4 == 0, "ld_final_conv: Cout %d (1..4), Cin %d", Cout, Cin);
+  const long npix = (long)B * H * W;
+  if (dtype == LD_F32)
+    hipLaunchKernelGGL(final_conv_kernel<float>, dim3(nblocks(npix)), dim3(BS), 0, ST(stream), (const float*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
+  else if (dtype == LD_BF16)
+    hipLaunchKernelGGL(final_conv_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), 0, ST(stream), (const bf16*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
+  else
+    return ld_fail(LD_EINVAL, "ld_final_conv: bad dtype %d", dtype);
+  LD_LAUNCH_CHECK("final_conv");
+  return LD_OK;
+}

@@ -1,0 +1,385 @@
+"""Host-side mirror of the sampling half of the reference's ``GaussianDiffusion``
+(/root/reference/ddpm.py:496-1125) over the gfx950 HIP kernels.
+
+Kept from the reference: the constructor signature (:497-513), the registered schedule buffers and
+their names (:567-615, so ``state_dict`` round-trips), ``sample`` (:1078), ``p_sample_loop``
+(:930), ``ddim_sample`` (:980), ``p_sample`` (:841), ``call_classifier`` (:622), and the
+attributes ``is_ddim_sampling / image_size / channels / num_timesteps``.
+
+Changed in form (results identical, see tests/): the reference flips entries of ``self.config``
+while sampling (:780-781, :1023-1024, :1093-1117); here ``config`` is only read, and the phase
+BRANCH -> (FUSE) -> JOINT is explicit.  No tensor leaves the GPU inside the loop (the reference
+ping-pongs ``.cpu()``/``.to(device)`` every step, :700-708, :865-869), the conditioning encoder
+runs once per phase instead of once per step (its input is constant over t, :434), both branches
+are evaluated as ONE batched denoiser call, and the dead OOD-branch evaluation for non-MRI data
+(:704-708) is skipped.  ``np.save`` debugging side effects (:793-794, :866-868) are not reproduced.
+
+Noise: ``noise_source='device'`` draws z_t with the counter-based generator on the GPU
+(``ld_randn``); ``'host'`` uploads the same stream from ``rng.py`` (bit-identical to the golden
+fixtures); a callable ``f(shape, k) -> tensor`` may be supplied instead.
+"""
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _cabi as cabi
+from . import rng, schedule
+
+_REPLACE_OUT = ("mnist", "mvtec", "oct", "imagenet")
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, config, model, *, image_size, timesteps=1000, sampling_timesteps=None,
+                 objective="pred_v", beta_schedule="sigmoid", schedule_fn_kwargs=dict(),
+                 ddim_sampling_eta=0.0, auto_normalize=False, offset_noise_strength=0.0,
+                 min_snr_loss_weight=False, min_snr_gamma=5):
+        super().__init__()
+        assert not (type(self) == GaussianDiffusion and model.channels != model.out_dim)
+        assert not model.random_or_learned_sinusoidal_cond
+        assert objective in {"pred_noise", "pred_x0", "pred_v"}
+        if auto_normalize:
+            raise NotImplementedError("auto_normalize=True is never used by the reference's callers (test.py:138)")
+        self.config = config
+        self.branch_out = bool(config["branch_out"])
+        self.start_intermediate = bool(config["start_intermediate"])
+        self.model = model
+        self.channels = model.channels
+        self.self_condition = model.self_condition
+        self.image_size = image_size
+        self.objective = objective
+        bufs = schedule.make_buffers(timesteps, beta_schedule, objective, min_snr_loss_weight,
+                                     min_snr_gamma, **schedule_fn_kwargs)
+        for k, v in bufs.items():
+            self.register_buffer(k, v)
+        self.num_timesteps = int(timesteps)
+        self.num_timesteps_ori = int(timesteps)
+        self.sampling_timesteps = timesteps if sampling_timesteps is None else sampling_timesteps
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        self.offset_noise_strength = offset_noise_strength
+        self.cnt = -1
+        self.instance = 0
+        # build-specific knobs (additive; defaults reproduce the reference's behaviour)
+        self.noise_source = "device"
+        self.noise_seed = 10                      # torch.manual_seed(10), ddpm.py:934
+        self.use_graph = False
+        self._sched = None
+        self._graphs = {}
+
+    # ------------------------------------------------------------------ small API pieces
+    def call_classifier(self):
+        if self.config.get("classifier", False):
+            raise NotImplementedError("the PatchCore x0 classifier gate (ddpm.py:883-916) needs anomalib "
+                                      "weights that the reference does not ship; it is off in config.yaml:34")
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def _st(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def _sched_table(self):
+        """[T, 8] fp32 device table of the per-step scalars (layout: LD_SCHED_* in the header)."""
+        if self._sched is None or self._sched.device != self.device:
+            cols = [self.posterior_mean_coef1, self.posterior_mean_coef2,
+                    (0.5 * self.posterior_log_variance_clipped).exp(),          # ddpm.py:853,858
+                    self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
+                    self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, self.alphas_cumprod]
+            self._sched = torch.stack([c.to(torch.float32) for c in cols], dim=1).contiguous()
+        return self._sched
+
+    # ------------------------------------------------------------------ noise
+    def _noise(self, buf, k, t_dev=None):
+        """Fill ``buf`` with draw #k of the run's noise stream."""
+        src = self.noise_source
+        if callable(src):
+            buf.copy_(src(tuple(buf.shape), k).to(buf.device, torch.float32))
+        elif src == "host":
+            buf.copy_(torch.from_numpy(rng.randn(tuple(buf.shape), self.noise_seed, k)))
+        elif src == "device":
+            cabi.check(cabi.lib().ld_randn(buf.data_ptr(), buf.numel(), self.noise_seed, k, 0, None, self._st()),
+                       "randn")
+        else:
+            raise ValueError(f"noise_source {src!r}")
+
+    # ------------------------------------------------------------------ flags
+    def _flags(self, mask):
+        """Effective (branch, fuse, mask_x) of this call: ddpm.py:1093-1117 without the mutation."""
+        c = self.config
+        branch = bool(c["branch_out"]) or self.branch_out
+        fuse = bool(c["start_intermediate"]) or self.start_intermediate
+        mask_x = bool(c.get("mask_x", False)) or bool(c.get("ood_AD", False)) or bool(c.get("ood_confidence", False))
+        if branch and mask is not None:
+            u = torch.unique(mask)
+            if len(u) == 1 and float(u[0]) == 1.0:        # "Original reverse process as AD is low"
+                branch, fuse, mask_x = False, False, False
+        return branch, fuse, mask_x
+
+    def _replaced_out(self, mask_x):
+        d = self.config["data"]
+        return mask_x and any(k in d for k in _REPLACE_OUT) and "mri" not in d
+
+    # ------------------------------------------------------------------ public sampling surface
+    @torch.inference_mode()
+    def sample(self, cond_img, gt, batch_size=16, return_all_timesteps=False, return_all_outputs=False,
+               mask=None, ood_confidence_ad=False, min_max_val=None, instance=0):
+        self.instance = instance
+        self.cnt += 1
+        self.min_max_val = min_max_val
+        self.hr = gt
+        shape = (batch_size, self.channels, self.image_size, self.image_size)
+        if self.is_ddim_sampling:
+            return self.ddim_sample(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps)
+        return self.p_sample_loop(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps,
+                                  return_all_outputs=return_all_outputs)
+
+    @torch.inference_mode()
+    def p_sample(self, x, mask, min_max_val, cond_img, t: int, x_self_cond=None):
+        """One ancestral step, single branch (ddpm.py:841-860 non-branch arm): -> (x_{t-1}, x0)."""
+        lib, st = cabi.lib(), self._st()
+        B, C, H, W = x.shape
+        model_out = self.model(x, cond_img, torch.full((B,), t, device=x.device, dtype=torch.long))
+        z = torch.empty_like(x)
+        if t > 0:
+            self._noise(z, getattr(self, "_draw", 1))
+        x_prev, x0 = torch.empty_like(x), torch.empty_like(x)
+        row = self._sched_table()[t:t + 1].contiguous()
+        cabi.check(lib.ld_ddpm_step(x.data_ptr(), model_out.data_ptr(), z.data_ptr(), x_prev.data_ptr(),
+                                    x0.data_ptr(), row.data_ptr(), None, float(min_max_val[0]),
+                                    float(min_max_val[1]), cabi.OBJ[self.objective], x.numel(), st), "ddpm_step")
+        return x_prev, x0
+
+    # ------------------------------------------------------------------ DDPM loop
+    @torch.inference_mode()
+    def p_sample_loop(self, cond_img, mask, min_max_val, shape, return_all_timesteps=False,
+                      return_all_outputs=False):
+        lib, st, dev = cabi.lib(), self._st(), self.device
+        B, C, H, W = shape
+        HW, n = H * W, B * C * H * W
+        lo, hi = float(min_max_val[0]), float(min_max_val[1])
+        T = self.num_timesteps
+        branch, fuse, mask_x = self._flags(mask)
+        obj = cabi.OBJ[self.objective]
+        sched = self._sched_table()
+        cond = cond_img.to(dev, torch.float32).contiguous()
+        if mask is not None:
+            mask = mask.to(dev, torch.float32).contiguous()
+        start_t = T - 1
+        x_T = torch.empty(shape, dtype=torch.float32, device=dev)
+        self._noise(x_T, 0)
+        if (bool(self.config["start_intermediate"]) or self.start_intermediate) and self.config.get("use_gt", False):
+            t0 = int(self.config["use_gt_timestep"])              # ddpm.py:937-944
+            hr = self.hr.to(dev, torch.float32).contiguous()
+            cabi.check(lib.ld_q_sample(hr.data_ptr(), x_T.data_ptr(), x_T.data_ptr(),
+                                       float(self.sqrt_alphas_cumprod[t0]),
+                                       float(self.sqrt_one_minus_alphas_cumprod[t0]), n, st), "q_sample")
+            start_t = t0 - 1
+        z = torch.empty(shape, dtype=torch.float32, device=dev)
+        x0_buf = torch.empty(shape, dtype=torch.float32, device=dev) if return_all_outputs else None
+        hist_x, hist_x0 = [x_T.clone()] if return_all_timesteps else None, []
+        draw = 1
+        t = start_t
+        xs = None
+        # ---------------- BRANCH phase
+        if branch:
+            assert self.objective == "pred_x0", "branch mode exists only for pred_x0 (ddpm.py:739-749)"
+            assert mask is not None
+            if mask_x:
+                assert len(torch.unique((mask >= 1.0).float())) == 2, "mask should be binary"   # ddpm.py:698
+            lo_clip = 0.5 if self.config["data"] == "mnist" else 0.95
+            cond_out, cond_in = torch.empty_like(cond), torch.empty_like(cond)
+            cabi.check(lib.ld_branch_conditions(cond.data_ptr(), mask.data_ptr(), cond_out.data_ptr(),
+                                                cond_in.data_ptr(), lo_clip, B, cond.shape[1], HW, st), "branch_conditions")
+            replaced = self._replaced_out(mask_x)
+            nb = B if replaced else 2 * B
+            plan = self.model.plan(nb, H, W, table_T=self.num_timesteps_ori)
+            if replaced:
+                plan.cond_in.copy_(cond_in)
+            else:
+                plan.cond_in[:B].copy_(cond_out)
+                plan.cond_in[B:].copy_(cond_in)
+            plan.run_cond(st)
+            # x_out lives in its own buffer when the OOD branch is not evaluated
+            x_in_view = plan.x_in if replaced else plan.x_in[B:]
+            x_out_view = torch.empty(shape, dtype=torch.float32, device=dev) if replaced else plan.x_in[:B]
+            x_out_view.copy_(x_T)
+            x_in_view.copy_(x_T)
+            mo_in = plan.model_out if replaced else plan.model_out[B:]
+            mo_out = cond_out if replaced else plan.model_out[:B]
+            while t >= 0:
+                plan.set_step(t)
+                plan.run_main(st)
+                if mask_x and not replaced:
+                    cabi.check(lib.ld_mask_out(mo_out.data_ptr(), mask.data_ptr(), lo, B, C, HW, st), "mask_out")
+                if t > 0:
+                    self._noise(z, draw)
+                    draw += 1
+                if fuse and t <= int(self.config["start_timestep"]):
+                    jp = self.model.plan(B, H, W, table_T=self.num_timesteps_ori)
+                    x0f = torch.empty(shape, dtype=torch.float32, device=dev)
+                    cabi.check(lib.ld_fuse_ddpm(x_out_view.data_ptr(), x_in_view.data_ptr(), mo_out.data_ptr(),
+                                                mo_in.data_ptr(), mask.data_ptr(), jp.x_in.data_ptr(),
+                                                x0f.data_ptr(), lo, hi, B, C, HW, st), "fuse_ddpm")
+                    jp.set_step(t)
+                    cabi.check(lib.ld_posterior_step(jp.x_in.data_ptr(), x0f.data_ptr(), z.data_ptr(),
+                                                     jp.x_in.data_ptr(), sched.data_ptr(), jp.t_dev.data_ptr(), n, st),
+                               "posterior_step")
+                    if return_all_outputs:
+                        hist_x0.append(x0f.cpu())
+                    if return_all_timesteps:
+                        hist_x.append(jp.x_in.clone())
+                    t -= 1
+                    branch = False
+                    break
+                plan.set_step(t)
+                for xv, mv in ((x_out_view, mo_out), (x_in_view, mo_in)):
+                    cabi.check(lib.ld_ddpm_step(xv.data_ptr(), mv.data_ptr(), z.data_ptr(), xv.data_ptr(), None,
+                                                sched.data_ptr(), plan.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+                t -= 1
+            if branch:                                     # never fused
+                xs = [x_out_view.clone(), x_in_view.clone()]
+        # ---------------- JOINT phase
+        if xs is None:
+            jp = self.model.plan(B, H, W, table_T=self.num_timesteps_ori)
+            if t == start_t:                               # no branch phase ran: start from x_T
+                jp.x_in.copy_(x_T)
+            jp.cond_in.copy_(cond)
+            jp.run_cond(st)
+            while t >= 0:
+                jp.set_step(t)
+                jp.run_main(st)
+                if t > 0:
+                    self._noise(z, draw)
+                    draw += 1
+                cabi.check(lib.ld_ddpm_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), z.data_ptr(),
+                                            jp.x_in.data_ptr(), cabi.ptr(x0_buf), sched.data_ptr(),
+                                            jp.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+                if return_all_outputs:
+                    hist_x0.append(x0_buf.cpu())
+                if return_all_timesteps:
+                    hist_x.append(jp.x_in.clone())
+                t -= 1
+            ret = jp.x_in.clone()
+        else:
+            ret = xs
+        if return_all_timesteps and not isinstance(ret, list):
+            ret = torch.stack(hist_x, dim=1)
+        start_int = bool(self.config["start_intermediate"]) or self.start_intermediate
+        if (not start_int) and self.branch_out:            # ddpm.py:964-970
+            ret = torch.stack(ret, dim=0) if isinstance(ret, list) else torch.stack((ret, ret), dim=0)
+        if return_all_outputs:
+            return ret, hist_x0, []
+        return ret
+
+    # ------------------------------------------------------------------ DDIM loop
+    @torch.inference_mode()
+    def ddim_sample(self, cond_img, mask, min_max_val, shape, return_all_timesteps=False):
+        lib, st, dev = cabi.lib(), self._st(), self.device
+        B, C, H, W = shape
+        HW, n = H * W, B * C * H * W
+        lo, hi = float(min_max_val[0]), float(min_max_val[1])
+        T, S, eta = self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        branch, fuse, mask_x = self._flags(mask)
+        obj = cabi.OBJ[self.objective]
+        times, pairs = schedule.ddim_time_pairs(T, S)
+        t_fuse = times[-int(self.config["start_timestep"]) - 2]                 # ddpm.py:987
+        cond = cond_img.to(dev, torch.float32).contiguous()
+        if mask is not None:
+            mask = mask.to(dev, torch.float32).contiguous()
+        x_T = torch.empty(shape, dtype=torch.float32, device=dev)
+        self._noise(x_T, 0)
+        z = torch.zeros(shape, dtype=torch.float32, device=dev)
+        abar = self.alphas_cumprod
+        sr_all, srm1_all = self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod
+        sab_all, s1m_all = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+
+        def scalars(t, t_next):
+            a, an = abar[t], abar[t_next]
+            sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()             # ddpm.py:1017-1018
+            c = (1 - an - sigma ** 2).sqrt()
+            return float(an.sqrt()), float(c), float(sigma)
+
+        def fwd(plan, t):
+            plan.set_step(t)
+            plan.run_main(st)
+
+        def step(xv, mv, t, t_next, zz):
+            last = 1 if t_next < 0 else 0
+            san, c, sigma = (0.0, 0.0, 0.0) if last else scalars(t, t_next)
+            cabi.check(lib.ld_ddim_step(xv.data_ptr(), mv.data_ptr(), cabi.ptr(zz), xv.data_ptr(),
+                                        float(sr_all[t]), float(srm1_all[t]), float(sab_all[t]), float(s1m_all[t]),
+                                        san, c, sigma, lo, hi, obj, last, n, st), "ddim_step")
+
+        draw, idx = 1, 0
+        xs = None
+        if branch:
+            assert self.objective == "pred_x0" and mask is not None
+            if mask_x:
+                assert len(torch.unique((mask >= 1.0).float())) == 2, "mask should be binary"
+            lo_clip = 0.5 if self.config["data"] == "mnist" else 0.95
+            cond_out, cond_in = torch.empty_like(cond), torch.empty_like(cond)
+            cabi.check(lib.ld_branch_conditions(cond.data_ptr(), mask.data_ptr(), cond_out.data_ptr(),
+                                                cond_in.data_ptr(), lo_clip, B, cond.shape[1], HW, st), "branch_conditions")
+            replaced = self._replaced_out(mask_x)
+            nb = B if replaced else 2 * B
+            plan = self.model.plan(nb, H, W, table_T=self.num_timesteps_ori)
+            if replaced:
+                plan.cond_in.copy_(cond_in)
+            else:
+                plan.cond_in[:B].copy_(cond_out)
+                plan.cond_in[B:].copy_(cond_in)
+            plan.run_cond(st)
+            x_in_view = plan.x_in if replaced else plan.x_in[B:]
+            x_out_view = torch.empty(shape, dtype=torch.float32, device=dev) if replaced else plan.x_in[:B]
+            x_out_view.copy_(x_T)
+            x_in_view.copy_(x_T)
+            mo_in = plan.model_out if replaced else plan.model_out[B:]
+            mo_out = cond_out if replaced else plan.model_out[:B]
+            fused = False
+            while idx < len(pairs):
+                t, t_next = pairs[idx]
+                fwd(plan, t)
+                if mask_x and not replaced:
+                    cabi.check(lib.ld_mask_out(mo_out.data_ptr(), mask.data_ptr(), lo, B, C, HW, st), "mask_out")
+                if t_next < 0:
+                    step(x_out_view, mo_out, t, t_next, None)
+                    step(x_in_view, mo_in, t, t_next, None)
+                    idx += 1
+                    continue
+                self._noise(z, draw)
+                draw += 1
+                if fuse and t <= t_fuse:
+                    jp = self.model.plan(B, H, W, table_T=self.num_timesteps_ori)
+                    san, c, sigma = scalars(t, t_next)
+                    cabi.check(lib.ld_fuse_ddim(x_out_view.data_ptr(), x_in_view.data_ptr(), mo_out.data_ptr(),
+                                                mo_in.data_ptr(), mask.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(),
+                                                float(sr_all[t]), float(srm1_all[t]), san, c, sigma, lo, hi,
+                                                B, C, HW, st), "fuse_ddim")
+                    idx += 1
+                    fused = True
+                    break
+                step(x_out_view, mo_out, t, t_next, z)
+                step(x_in_view, mo_in, t, t_next, z)
+                idx += 1
+            if not fused:
+                xs = [x_out_view.clone(), x_in_view.clone()]
+        if xs is None:
+            jp = self.model.plan(B, H, W, table_T=self.num_timesteps_ori)
+            if idx == 0:
+                jp.x_in.copy_(x_T)
+            jp.cond_in.copy_(cond)
+            jp.run_cond(st)
+            while idx < len(pairs):
+                t, t_next = pairs[idx]
+                fwd(jp, t)
+                if t_next >= 0:
+                    self._noise(z, draw)
+                    draw += 1
+                step(jp.x_in, jp.model_out, t, t_next, z if t_next >= 0 else None)
+                idx += 1
+            return jp.x_in.clone()
+        return xs

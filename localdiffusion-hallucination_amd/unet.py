@@ -1,0 +1,532 @@
+"""Host-side mirror of the reference's conditional denoiser ``Unet``
+(/root/reference/ddpm.py:286-451) over the gfx950 HIP kernels.
+
+* Same constructor signature, same attributes read by ``GaussianDiffusion`` (``channels``,
+  ``out_dim``, ``self_condition``, ``random_or_learned_sinusoidal_cond``, ``downsample_factor``),
+  same ``forward(x, cond_img, time, x_self_cond=None)`` contract (NCHW fp32 in / out), and a
+  ``state_dict`` with exactly the reference's parameter names, so checkpoints
+  written by the reference's ``Trainer.save`` load by name.
+* The arithmetic runs entirely in ``csrc/liblocaldiff_hip.so`` through ctypes: the forward is a
+  *plan* -- a list of C-ABI calls with pre-built argument structs over static NHWC buffers --
+  built once per (batch, H, W) and replayed, eagerly or from a captured HIP graph.  PyTorch only
+  owns device memory and the stream.  Without the library this module raises.
+
+Fusions relative to the reference's op-per-module execution are listed in DESIGN.md; numerically
+the plan computes the same function (fp32 mode agrees with the reference to ~1e-5 per forward).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _cabi as cabi
+from .weights import UnetConfig, unet_param_shapes
+
+_TORCH_DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+def _register(root: nn.Module, dotted: str, tensor: torch.Tensor):
+    """Create bare container modules along ``dotted`` and register the leaf parameter, so that
+    ``state_dict()`` keys equal the reference's (e.g. ``downs.0.0.block1.proj.weight``)."""
+    parts = dotted.split(".")
+    mod = root
+    for name in parts[:-1]:
+        if name not in mod._modules:
+            mod.add_module(name, nn.Module())
+        mod = mod._modules[name]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class Unet(nn.Module):
+    def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=1,
+                 self_condition=False, cond_img=True, resnet_block_groups=8, learned_variance=False,
+                 learned_sinusoidal_cond=False, random_fourier_features=False,
+                 learned_sinusoidal_dim=16, sinusoidal_pos_emb_theta=10000, attn_dim_head=32,
+                 attn_heads=4, full_attn=(False, False, False, True), flash_attn=False, mode="mri",
+                 compute_dtype="fp32"):
+        super().__init__()
+        if self_condition or learned_variance or learned_sinusoidal_cond or random_fourier_features:
+            raise NotImplementedError("self_condition / learned_variance / learned sinusoidal embeddings "
+                                      "are never enabled by the reference's callers (test.py:117-129)")
+        if dim != 32:
+            raise ValueError("dim must be 32: the conditioning encoder hard-codes its widths "
+                             "(unet_model.py:100) and is concatenated with the 8*dim bottleneck")
+        if attn_dim_head != 32:
+            raise ValueError("attn_dim_head must be 32 (MFMA tile of the attention kernels)")
+        if compute_dtype not in _TORCH_DT:
+            raise ValueError(f"compute_dtype {compute_dtype!r} (fp32 | bf16)")
+        full_attn = tuple(full_attn) if isinstance(full_attn, (tuple, list)) else (full_attn,) * len(dim_mults)
+        assert len(full_attn) == len(dim_mults)
+        init_dim = dim if init_dim is None else init_dim
+        self.cfg = UnetConfig(dim=dim, init_dim=init_dim, out_dim=channels if out_dim is None else out_dim,
+                              dim_mults=tuple(dim_mults), channels=channels,
+                              resnet_block_groups=resnet_block_groups, attn_dim_head=attn_dim_head,
+                              attn_heads=attn_heads, full_attn=full_attn, mode=mode)
+        self.mode = mode
+        self.channels = channels
+        self.out_dim = self.cfg.out_dim
+        self.self_condition = False
+        self.cond_img = cond_img
+        self.random_or_learned_sinusoidal_cond = False
+        self.theta = sinusoidal_pos_emb_theta
+        self.compute_dtype = compute_dtype
+        g = torch.Generator().manual_seed(0)
+        shapes = unet_param_shapes(self.cfg)
+        for name, shape in shapes.items():
+            if name.endswith(".g"):
+                t = torch.ones(shape)
+            elif len(shape) == 1 and (".norm." in name or "convblock.1" in name or "convblock.4" in name
+                                      or "identity.1" in name):
+                t = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+            else:
+                wshape = shape if name.endswith("weight") else shapes[name[:-4] + "weight"]
+                bound = 1.0 / math.sqrt(int(np.prod(wshape[1:])))
+                t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            _register(self, name, t)
+        self._packed = None
+        self._packed_key = None
+        self._plans = {}
+
+    # ------------------------------------------------------------------ reference attributes
+    @property
+    def downsample_factor(self):
+        return self.cfg.downsample_factor
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def set_compute_dtype(self, name):
+        if name not in _TORCH_DT:
+            raise ValueError(name)
+        if name != self.compute_dtype:
+            self.compute_dtype = name
+            self.invalidate()
+
+    def invalidate(self):
+        """Drop packed weights and plans (call after changing parameters in place)."""
+        self._packed, self._packed_key, self._plans = None, None, {}
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.invalidate()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate()
+        return out
+
+    # ------------------------------------------------------------------ weight packing
+    def packed(self):
+        """Kernel-layout weights for the current device/dtype (built lazily, cached)."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("the HIP denoiser needs its parameters on a GPU (model.to('cuda')); "
+                               "there is no CPU execution path")
+        key = (str(dev), self.compute_dtype)
+        if self._packed is not None and self._packed_key == key:
+            return self._packed
+        lib = cabi.lib()
+        st = torch.cuda.current_stream().cuda_stream
+        dt, tdt = cabi.dtype_code(self.compute_dtype), _TORCH_DT[self.compute_dtype]
+        sd = {k: v.detach().to(torch.float32).contiguous() for k, v in self.state_dict().items()}
+        P = {"f32": sd, "w": {}, "g2": {}}
+
+        def pack(name, ksize, scale_in=None, unshuffle=0):
+            w = sd[name]
+            cout, cin = w.shape[0], w.shape[1]
+            out = torch.empty(cout * cin * ksize * ksize, dtype=tdt, device=dev)
+            cabi.check(lib.ld_pack_conv_weight(w.data_ptr(), cabi.ptr(scale_in), out.data_ptr(), cout, cin,
+                                               ksize, unshuffle, dt, st), "pack " + name)
+            P["w"][name] = out
+            if scale_in is not None:
+                P.setdefault("keep", []).append(scale_in)
+
+        for name, w in sd.items():
+            if not name.endswith(".weight") or w.dim() != 4:
+                continue
+            k = w.shape[-1]
+            base = name[:-len(".weight")]
+            if k == 7 or w.shape[1] < 32:
+                continue                                  # image convs stay OIHW fp32
+            if base == "final_conv":
+                continue
+            if base.endswith(".to_qkv"):
+                g = sd[base[:-len(".to_qkv")] + ".norm.g"].flatten()
+                pack(name, 1, scale_in=(g * math.sqrt(g.numel())).contiguous())
+            elif k == 1 and base.endswith(".3.1") and base.startswith("downs."):
+                pack(name, 1, unshuffle=1)
+            elif k == 1 and (base.endswith(".to_out.0")):
+                continue                                  # folded per batch with ctx (ld_linattn_fold)
+            else:
+                pack(name, k)
+        for name, w in sd.items():
+            if name.endswith(".to_out.1.g"):
+                g = w.flatten()
+                P["g2"][name] = (g * math.sqrt(g.numel())).contiguous()
+        half = self.cfg.dim // 2
+        step = math.log(self.theta) / (half - 1)
+        P["freqs"] = torch.exp(torch.arange(half) * -step).to(dev)          # ddpm.py:145-146
+        torch.cuda.current_stream().synchronize()
+        self._packed, self._packed_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ plans
+    def plan(self, B, H, W, table_T=None):
+        f = self.downsample_factor
+        assert H % f == 0 and W % f == 0, \
+            f"your input dimensions {(H, W)} need to be divisible by {f}, given the unet"   # ddpm.py:405
+        key = (B, H, W, table_T, self.compute_dtype)
+        if key not in self._plans:
+            self._plans[key] = _Plan(self, B, H, W, table_T)
+        return self._plans[key]
+
+    @torch.no_grad()
+    def forward(self, x, cond_img, time, x_self_cond=None):
+        """ddpm.py:404-451.  x [B,C,H,W], cond_img [B,Cc,H,W], time int64 [B] -> [B,out_dim,H,W]."""
+        B, _, H, W = x.shape
+        p = self.plan(B, H, W)
+        st = torch.cuda.current_stream().cuda_stream
+        p.x_in.copy_(x.to(torch.float32))
+        p.cond_in.copy_(cond_img.to(torch.float32))
+        p.times.copy_(time.to(torch.int32))
+        p.run_time(st)
+        p.run_cond(st)
+        p.run_main(st)
+        return p.model_out.clone()
+
+
+class _Plan:
+    """Static buffers + the C-ABI call list of one denoiser evaluation at a fixed shape.
+
+    table_T=None : per-batch timesteps in ``self.times`` (the general ``Unet.forward`` contract);
+    table_T=T    : FiLM tables for t = 0..T-1 are precomputed and kernels index them through the
+                   device step counter ``self.t_dev`` (sampler fast path, HIP-graph replayable).
+    """
+
+    def __init__(self, net: Unet, B, H, W, table_T=None):
+        self.net, self.B, self.H, self.W, self.table_T = net, B, H, W, table_T
+        self.lib = cabi.lib()
+        self.dev = net.device
+        self.dt = cabi.dtype_code(net.compute_dtype)
+        self.tdt = _TORCH_DT[net.compute_dtype]
+        self.esize = 4 if self.dt == cabi.LD_F32 else 2
+        self.P = net.packed()
+        self.f32 = self.P["f32"]
+        cfg = net.cfg
+        self.cfg = cfg
+        self.keep = []
+        self.named = {}                            # oracle tap name -> NHWC buffer (parity tests)
+        self.ops_time, self.ops_cond, self.ops_main = [], [], []
+        self.nslot = 0
+        self.stats = torch.zeros(160, B, 16, 2, dtype=torch.float64, device=self.dev)
+        self.cond_slots = 16                       # slots [0,16) belong to the conditioning encoder
+        self.x_in = torch.zeros(B, cfg.channels, H, W, dtype=torch.float32, device=self.dev)
+        self.cond_in = torch.zeros(B, cfg.cond_in_channels, H, W, dtype=torch.float32, device=self.dev)
+        self.model_out = torch.zeros(B, cfg.out_dim, H, W, dtype=torch.float32, device=self.dev)
+        self.times = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.rows = table_T if table_T else B
+        self.temb = torch.zeros(self.rows, cfg.time_dim, dtype=torch.float32, device=self.dev)
+        self.films = {}
+        self._build_time()
+        self._slot_cursor = 0
+        self.cond_feat = self._build_cond()
+        self.named["cond_model"] = self.cond_feat
+        self._slot_cursor = self.cond_slots
+        self._build_main()
+        if table_T:
+            st = torch.cuda.current_stream().cuda_stream
+            for op in self.ops_time:
+                op(st)
+            torch.cuda.current_stream().synchronize()
+
+    # ------------------------------------------------------------------ helpers
+    def buf(self, h, w, c):
+        return torch.empty(self.B, h, w, c, dtype=self.tdt, device=self.dev)
+
+    def slot(self):
+        s = self._slot_cursor
+        self._slot_cursor += 1
+        assert s < self.stats.shape[0]
+        return self.stats[s]
+
+    def t_ptr(self):
+        return self.t_dev.data_ptr() if self.table_T else None
+
+    def src(self, t, c, stride=0, ups=0, gn=None, act=cabi.ACT_NONE, film=None):
+        s = cabi.Src()
+        s.data, s.C, s.pix_stride, s.upsample = t.data_ptr(), c, stride, ups
+        if gn is not None:
+            stats, gamma, beta, groups = gn
+            s.gn_stats, s.gn_gamma, s.gn_beta, s.gn_groups = stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), groups
+        s.act = act
+        if film is not None:
+            s.film = film.data_ptr()
+            s.film_tstride = 2 * c if self.table_T else 0
+            s.film_bstride = 0 if self.table_T else 2 * c
+        self.keep.append(t)
+        return s
+
+    def _call(self, ops, fn, args, what):
+        self.keep.append(args)
+        ref = C.byref(args)
+        ops.append(lambda st, fn=fn, ref=ref, what=what: cabi.check(fn(ref, st), what))
+
+    def conv3(self, ops, srcs, wname, cout, h, w, stats=None, groups=8):
+        a = cabi.Conv3x3Args()
+        for i, s in enumerate(srcs):
+            a.src[i] = s
+        a.nsrc = len(srcs)
+        a.weight = self.P["w"][wname + ".weight"].data_ptr()
+        a.bias = self.f32[wname + ".bias"].data_ptr()
+        out = self.buf(h, w, cout)
+        a.out = out.data_ptr()
+        if stats is not None:
+            a.out_stats, a.out_groups = stats.data_ptr(), groups
+        a.B, a.H, a.W, a.Cout = self.B, h, w, cout
+        a.t_ptr = self.t_ptr()
+        a.dtype = self.dt
+        self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname)
+        return out
+
+    def conv1(self, ops, srcs, weight, cout, h, w, bias=None, epi=cabi.EPI_PLAIN, unshuffle=0, rms_in=0,
+              bstride=0, g2=None, residual=None, what="conv1x1", out=None):
+        a = cabi.Conv1x1Args()
+        for i, s in enumerate(srcs):
+            a.src[i] = s
+        a.nsrc, a.unshuffle, a.rms_in = len(srcs), unshuffle, rms_in
+        a.weight, a.weight_bstride = weight.data_ptr(), bstride
+        a.bias = cabi.ptr(bias)
+        a.epilogue, a.hidden, a.q_scale = epi, self.cfg.hidden, self.cfg.attn_dim_head ** -0.5
+        a.g2, a.residual = cabi.ptr(g2), cabi.ptr(residual)
+        out = self.buf(h, w, cout) if out is None else out
+        a.out = out.data_ptr()
+        a.B, a.H, a.W, a.Cout, a.dtype = self.B, h, w, cout, self.dt
+        self.keep += [weight, bias, g2, residual]
+        self._call(ops, self.lib.ld_conv1x1, a, what)
+        return out
+
+    def gn_apply(self, ops, a_src, b_src, h, w, c, final_act=cabi.ACT_NONE, pool=0):
+        g = cabi.GnApplyArgs()
+        g.a = a_src
+        if b_src is not None:
+            g.b = b_src
+        g.final_act, g.pool = final_act, pool
+        out = self.buf(h // 2 if pool else h, w // 2 if pool else w, c)
+        g.out = out.data_ptr()
+        g.B, g.H, g.W, g.t_ptr, g.dtype = self.B, h, w, self.t_ptr(), self.dt
+        self._call(ops, self.lib.ld_gn_apply, g, "gn_apply")
+        return out
+
+    # ------------------------------------------------------------------ time embedding / FiLM
+    def _build_time(self):
+        cfg, f, lib = self.cfg, self.f32, self.lib
+        if self.table_T:
+            times = torch.arange(self.table_T, dtype=torch.int32, device=self.dev)
+        else:
+            times = self.times
+        self.keep.append(times)
+        freqs = self.P["freqs"]
+        n, td = self.rows, cfg.time_dim
+        self.ops_time.append(lambda st: cabi.check(lib.ld_time_mlp(
+            times.data_ptr(), n, freqs.data_ptr(), cfg.dim, f["time_mlp.1.weight"].data_ptr(),
+            f["time_mlp.1.bias"].data_ptr(), f["time_mlp.3.weight"].data_ptr(), f["time_mlp.3.bias"].data_ptr(),
+            td, self.temb.data_ptr(), st), "time_mlp"))
+        for name in f:
+            if name.endswith(".mlp.1.weight") and not name.startswith("conv_fusion"):
+                p = name[:-len(".mlp.1.weight")]
+                two_c = f[name].shape[0]
+                film = torch.zeros(n, two_c, dtype=torch.float32, device=self.dev)
+                self.films[p] = film
+                w, b = f[name], f[p + ".mlp.1.bias"]
+                self.ops_time.append(lambda st, w=w, b=b, film=film, two_c=two_c: cabi.check(lib.ld_film(
+                    self.temb.data_ptr(), n, td, w.data_ptr(), b.data_ptr(), two_c, film.data_ptr(), st), "film"))
+
+    # ------------------------------------------------------------------ blocks
+    def resnet_block(self, ops, p, srcs_fn, cin_total, cout, h, w, res_tensor=None):
+        """ddpm.py:188-212.  ``srcs_fn()`` returns fresh ld_src structs of the block input (one or two
+        concatenated tensors); ``res_tensor`` is the single input tensor when cin == cout."""
+        f, G = self.f32, self.cfg.resnet_block_groups
+        s1, s2 = self.slot(), self.slot()
+        raw1 = self.conv3(ops, srcs_fn(), p + ".block1.proj", cout, h, w, stats=s1, groups=G)
+        film = self.films.get(p)
+        n1 = self.src(raw1, cout, gn=(s1, f[p + ".block1.norm.weight"], f[p + ".block1.norm.bias"], G),
+                      act=cabi.ACT_SILU, film=film)
+        raw2 = self.conv3(ops, [n1], p + ".block2.proj", cout, h, w, stats=s2, groups=G)
+        if (p + ".res_conv.weight") in f:
+            res = self.conv1(ops, srcs_fn(), self.P["w"][p + ".res_conv.weight"], cout, h, w,
+                             bias=f[p + ".res_conv.bias"], what="res_conv " + p)
+        else:
+            assert res_tensor is not None and cin_total == cout
+            res = res_tensor
+        n2 = self.src(raw2, cout, gn=(s2, f[p + ".block2.norm.weight"], f[p + ".block2.norm.bias"], G),
+                      act=cabi.ACT_SILU)
+        out = self.gn_apply(ops, n2, self.src(res, cout), h, w, cout)
+        self.named[p] = out
+        return out
+
+    def linear_attention(self, ops, p, x, c, h, w):
+        """ddpm.py:214-251 (+ residual of the caller, :425/:444)."""
+        f, cfg, lib = self.f32, self.cfg, self.lib
+        n, hid, B = h * w, cfg.hidden, self.B
+        qkv = self.conv1(ops, [self.src(x, c)], self.P["w"][p + ".to_qkv.weight"], 3 * hid, h, w,
+                         epi=cabi.EPI_QKV_LINEAR, rms_in=1, what="to_qkv " + p)
+        nparts = max(1, min(64, n // 256))
+        nchunks = max(1, min(32, n // 2048))
+        kmax = torch.empty(B, nparts, hid, dtype=torch.float32, device=self.dev)
+        ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, cfg.attn_heads, 32, nchunks)),
+                          dtype=torch.float32, device=self.dev)
+        wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)
+        wout = f[p + ".to_out.0.weight"].reshape(c, hid).contiguous()
+        self.keep += [kmax, ctx, wfold, wout, qkv]
+        dt, heads = self.dt, cfg.attn_heads
+        ops.append(lambda st: cabi.check(lib.ld_linattn_kmax(qkv.data_ptr(), kmax.data_ptr(), B, n, heads, 32,
+                                                             nparts, dt, st), "linattn_kmax"))
+        ops.append(lambda st: cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), nparts, ctx.data_ptr(),
+                                                            B, n, heads, 32, nchunks, dt, st), "linattn_ctx"))
+        ops.append(lambda st: cabi.check(lib.ld_linattn_fold(ctx.data_ptr(), nchunks, wout.data_ptr(),
+                                                             wfold.data_ptr(), B, c, heads, 32, dt, st), "linattn_fold"))
+        q = self.src(qkv, hid, stride=3 * hid)
+        return self.conv1(ops, [q], wfold, c, h, w, bias=f[p + ".to_out.0.bias"], epi=cabi.EPI_RMS_RES,
+                          bstride=c * hid * self.esize, g2=self.P["g2"][p + ".to_out.1.g"], residual=x,
+                          what="lin to_out " + p)
+
+    def full_attention(self, ops, p, x, c, h, w):
+        """ddpm.py:253-282 + attend.py:84-113 (+ residual of the caller)."""
+        f, cfg, lib = self.f32, self.cfg, self.lib
+        n, hid, B = h * w, cfg.hidden, self.B
+        qkv = self.conv1(ops, [self.src(x, c)], self.P["w"][p + ".to_qkv.weight"], 3 * hid, h, w,
+                         epi=cabi.EPI_QKV_FULL, rms_in=1, what="to_qkv " + p)
+        att = self.buf(h, w, hid)
+        dt, heads = self.dt, cfg.attn_heads
+        self.keep += [qkv, att]
+        ops.append(lambda st: cabi.check(lib.ld_attention(qkv.data_ptr(), att.data_ptr(), B, n, heads, 32, dt, st),
+                                         "attention"))
+        return self.conv1(ops, [self.src(att, hid)], self.P["w"][p + ".to_out.weight"], c, h, w,
+                          bias=f[p + ".to_out.bias"], epi=cabi.EPI_RES, residual=x, what="full to_out " + p)
+
+    def attention(self, ops, p, x, c, h, w, full):
+        out = (self.full_attention if full else self.linear_attention)(ops, p, x, c, h, w)
+        self.named[p] = out
+        return out
+
+    # ------------------------------------------------------------------ conditioning encoder
+    def _basic_block(self, ops, p, x, cin, cmid, cout, h, w, pool, image=False):
+        """unet_model.py:8-51 (+ MaxPool2d of ResUnet.forward when pool)."""
+        f, lib, G = self.f32, self.lib, 16
+        s1, s2, s3 = self.slot(), self.slot(), self.slot()
+
+        def image_conv(wname, c_out, stats):
+            out = self.buf(h, w, c_out)
+            wt, bs = f[wname + ".weight"], f[wname + ".bias"]
+            B, dt = self.B, self.dt
+            self.keep += [out, wt, bs]
+            ops.append(lambda st: cabi.check(lib.ld_conv_image(
+                self.cond_in.data_ptr(), wt.data_ptr(), bs.data_ptr(), out.data_ptr(), stats.data_ptr(), G,
+                B, cin, h, w, 3, dt, st), "conv_image " + wname))
+            return out
+
+        if image:
+            a1 = image_conv(p + ".convblock.0", cmid, s1)
+            idr = image_conv(p + ".identity.0", cout, s3)
+        else:
+            a1 = self.conv3(ops, [self.src(x, cin)], p + ".convblock.0", cmid, h, w, stats=s1, groups=G)
+            idr = self.conv3(ops, [self.src(x, cin)], p + ".identity.0", cout, h, w, stats=s3, groups=G)
+        n1 = self.src(a1, cmid, gn=(s1, f[p + ".convblock.1.weight"], f[p + ".convblock.1.bias"], G),
+                      act=cabi.ACT_RELU)
+        a2 = self.conv3(ops, [n1], p + ".convblock.3", cout, h, w, stats=s2, groups=G)
+        na = self.src(a2, cout, gn=(s2, f[p + ".convblock.4.weight"], f[p + ".convblock.4.bias"], G))
+        nb = self.src(idr, cout, gn=(s3, f[p + ".identity.1.weight"], f[p + ".identity.1.bias"], G))
+        return self.gn_apply(ops, na, nb, h, w, cout, final_act=cabi.ACT_RELU, pool=1 if pool else 0)
+
+    def _build_cond(self):
+        cfg, ops, H, W = self.cfg, self.ops_cond, self.H, self.W
+        x = self._basic_block(ops, "cond_model.residual_conv1.0", None, cfg.cond_in_channels, 32, 32, H, W,
+                              pool=True, image=True)
+        x = self._basic_block(ops, "cond_model.residual_conv2.0", x, 32, 32, 64, H // 2, W // 2, pool=True)
+        early = cfg.cond_early_exit
+        x = self._basic_block(ops, "cond_model.residual_conv3.0", x, 64, 64, 128, H // 4, W // 4, pool=not early)
+        if early:
+            return x
+        return self._basic_block(ops, "cond_model.mid_conv.0", x, 128, 128, 256, H // 8, W // 8, pool=False)
+
+    # ------------------------------------------------------------------ main trunk (ddpm.py:413-451)
+    def _build_main(self):
+        cfg, ops, f, lib, B = self.cfg, self.ops_main, self.f32, self.lib, self.B
+        H, W = self.H, self.W
+        r = self.buf(H, W, cfg.init_dim)
+        wi, bi = f["init_conv.weight"], f["init_conv.bias"]
+        ops.append(lambda st: cabi.check(lib.ld_conv_image(
+            self.x_in.data_ptr(), wi.data_ptr(), bi.data_ptr(), r.data_ptr(), None, 1, B, cfg.channels, H, W, 7,
+            self.dt, st), "init_conv"))
+        self.named["init_conv"] = r
+        x, c, h, w = r, cfg.init_dim, H, W
+        skips = []
+        io, n = cfg.in_out, len(cfg.in_out)
+        for i, (cin, cout) in enumerate(io):
+            p = f"downs.{i}"
+            x = self.resnet_block(ops, p + ".0", lambda x=x, c=c: [self.src(x, c)], c, c, h, w, res_tensor=x)
+            skips.append((x, c))
+            x = self.resnet_block(ops, p + ".1", lambda x=x, c=c: [self.src(x, c)], c, c, h, w, res_tensor=x)
+            x = self.attention(ops, p + ".2", x, c, h, w, cfg.full_attn[i])
+            skips.append((x, c))
+            if i < n - 1:
+                h, w = h // 2, w // 2
+                x = self.conv1(ops, [self.src(x, c)], self.P["w"][p + ".3.1.weight"], cout, h, w,
+                               bias=f[p + ".3.1.bias"], unshuffle=1, what="downsample " + p)
+            else:
+                x = self.conv3(ops, [self.src(x, c)], p + ".3", cout, h, w)
+            self.named[p + ".3"] = x
+            c = cout
+        x = self.resnet_block(ops, "mid_block1", lambda x=x, c=c: [self.src(x, c)], c, c, h, w, res_tensor=x)
+        x = self.attention(ops, "mid_attn", x, c, h, w, True)
+        x = self.resnet_block(ops, "mid_block2", lambda x=x, c=c: [self.src(x, c)], c, c, h, w, res_tensor=x)
+        feat = self.cond_feat
+        x = self.resnet_block(ops, "conv_fusion", lambda x=x, c=c: [self.src(x, c), self.src(feat, c)], 2 * c, c, h, w)
+        for j, ((cin, cout), full) in enumerate(zip(reversed(io), reversed(cfg.full_attn))):
+            p = f"ups.{j}"
+            for k in (0, 1):
+                sk, sc = skips.pop()
+                x = self.resnet_block(ops, f"{p}.{k}", lambda x=x, c=c, sk=sk, sc=sc: [self.src(x, c), self.src(sk, sc)],
+                                      c + sc, cout, h, w)
+                c = cout
+            x = self.attention(ops, p + ".2", x, c, h, w, full)
+            if j < n - 1:
+                h, w = h * 2, w * 2
+                x = self.conv3(ops, [self.src(x, c, ups=1)], p + ".3.1", cin, h, w)
+            else:
+                x = self.conv3(ops, [self.src(x, c)], p + ".3", cin, h, w)
+            self.named[p + ".3"] = x
+            c = cin
+        x = self.resnet_block(ops, "final_res_block", lambda x=x, c=c: [self.src(x, c), self.src(r, cfg.init_dim)],
+                              c + cfg.init_dim, cfg.dim, h, w)
+        wf = f["final_conv.weight"].reshape(cfg.out_dim, cfg.dim).contiguous()
+        bf = f["final_conv.bias"]
+        self.keep += [wf, bf, x, r]
+        ops.append(lambda st, x=x: cabi.check(lib.ld_final_conv(
+            x.data_ptr(), wf.data_ptr(), bf.data_ptr(), self.model_out.data_ptr(), B, H, W, cfg.dim, cfg.out_dim,
+            self.dt, st), "final_conv"))
+
+    # ------------------------------------------------------------------ execution
+    def run_time(self, st):
+        for op in self.ops_time:
+            op(st)
+
+    def run_cond(self, st):
+        s = self.stats[:self.cond_slots]
+        cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
+        for op in self.ops_cond:
+            op(st)
+
+    def run_main(self, st):
+        s = self.stats[self.cond_slots:]
+        cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
+        for op in self.ops_main:
+            op(st)
+
+    def set_step(self, t):
+        self.t_dev.fill_(int(t))

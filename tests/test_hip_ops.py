@@ -1,0 +1,357 @@
+"""Per-kernel parity: each C-ABI op against the same op in plain PyTorch fp32 on the CPU
+(the building blocks of oracle/unet_ref.py), on seeded inputs, fp32 and bf16 storage."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from localdiffusion_hallucination_amd import _cabi as cabi       # noqa: E402
+from localdiffusion_hallucination_amd import rng, schedule        # noqa: E402
+from oracle import unet_ref                                        # noqa: E402
+import hip_helpers as hh                                           # noqa: E402
+
+DTYPES = ["fp32", "bf16"]
+
+
+def _q(x, dtype):
+    """Round a CPU fp32 tensor to the storage dtype (so both sides see identical inputs)."""
+    return x.to(hh.TDT[dtype]).float()
+
+
+# ------------------------------------------------------------------------------ conv3x3
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 32, 32, 16, 16), (1, 64, 32, 20, 28), (2, 32, 64, 8, 8),
+                                            (1, 128, 64, 7, 7), (1, 32, 32, 40, 48), (1, 256, 256, 8, 8)])
+def test_conv3x3_plain_and_stats(dtype, B, cin, cout, H, W):
+    x, w, b = _q(hh.rand((B, cin, H, W), 1), dtype), _q(hh.rand((cout, cin, 3, 3), 2, -0.1, 0.1), dtype), hh.rand((cout,), 3)
+    ref = F.conv2d(x, w, b, padding=1)
+    stats = torch.zeros(B, 8, 2, dtype=torch.float64, device=hh.DEV)
+    out = hh.conv3x3([hh.make_src(hh.nhwc(x, dtype), cin)], hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype,
+                     stats=stats, groups=8)
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+    sref = hh.gn_stats_ref(ref, 8)
+    assert hh.rel_err(stats.cpu(), sref) < (1e-5 if dtype == "fp32" else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_concat_upsample(dtype):
+    B, c1, c2, cout, H, W = 2, 64, 32, 32, 12, 12
+    x1, x2 = _q(hh.rand((B, c1, H // 2, W // 2), 4), dtype), _q(hh.rand((B, c2, H, W), 5), dtype)
+    w, b = _q(hh.rand((cout, c1 + c2, 3, 3), 6, -0.1, 0.1), dtype), hh.rand((cout,), 7)
+    ref = F.conv2d(torch.cat([F.interpolate(x1, scale_factor=2, mode="nearest"), x2], 1), w, b, padding=1)
+    out = hh.conv3x3([hh.make_src(hh.nhwc(x1, dtype), c1, ups=1), hh.make_src(hh.nhwc(x2, dtype), c2)],
+                     hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype)
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act,groups,use_film", [(cabi.ACT_SILU, 8, True), (cabi.ACT_RELU, 16, False)])
+def test_conv3x3_gn_film_prologue(dtype, act, groups, use_film):
+    """conv(act(GN(x)*(scale+1)+shift)) with GN statistics taken from x itself."""
+    B, cin, cout, H, W = 2, 64, 32, 10, 14
+    x = _q(hh.rand((B, cin, H, W), 8, -2.0, 3.0), dtype)
+    gamma, beta = hh.rand((cin,), 9, 0.5, 1.5), hh.rand((cin,), 10, -0.3, 0.3)
+    film = hh.rand((B, 2 * cin), 11, -0.5, 0.5)
+    w, b = _q(hh.rand((cout, cin, 3, 3), 12, -0.1, 0.1), dtype), hh.rand((cout,), 13)
+    y = F.group_norm(x, groups, gamma, beta, eps=1e-5)
+    if use_film:
+        y = y * (film[:, :cin, None, None] + 1) + film[:, cin:, None, None]
+    y = F.silu(y) if act == cabi.ACT_SILU else F.relu(y)
+    ref = F.conv2d(y, w, b, padding=1)
+    stats = hh.gn_stats_ref(x, groups).to(hh.DEV)
+    g_d, b_d, f_d = gamma.to(hh.DEV), beta.to(hh.DEV), film.to(hh.DEV)
+    src = hh.make_src(hh.nhwc(x, dtype), cin, gn=(stats, g_d, b_d, groups), act=act,
+                      film=f_d if use_film else None, film_b=2 * cin)
+    out = hh.conv3x3([src], hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype)
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
+
+
+# ------------------------------------------------------------------------------ conv1x1
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 32, 16, 16), (1, 384, 256, 8, 8), (1, 96, 64, 14, 14),
+                                            (1, 32, 384, 28, 28), (2, 128, 128, 7, 7)])
+def test_conv1x1_plain(dtype, B, cin, cout, H, W):
+    x, w, b = _q(hh.rand((B, cin, H, W), 20), dtype), _q(hh.rand((cout, cin, 1, 1), 21, -0.2, 0.2), dtype), hh.rand((cout,), 22)
+    ref = F.conv2d(x, w, b)
+    out = hh.conv1x1([hh.make_src(hh.nhwc(x, dtype), cin)], hh.pack(w, dtype, 1), B, H, W, cout, dtype, bias=b.to(hh.DEV))
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv1x1_concat_and_unshuffle(dtype):
+    B, c1, c2, cout, H, W = 1, 64, 32, 64, 12, 10
+    x1, x2 = _q(hh.rand((B, c1, H, W), 23), dtype), _q(hh.rand((B, c2, H, W), 24), dtype)
+    w, b = _q(hh.rand((cout, c1 + c2, 1, 1), 25, -0.2, 0.2), dtype), hh.rand((cout,), 26)
+    ref = F.conv2d(torch.cat([x1, x2], 1), w, b)
+    out = hh.conv1x1([hh.make_src(hh.nhwc(x1, dtype), c1), hh.make_src(hh.nhwc(x2, dtype), c2)], hh.pack(w, dtype, 1),
+                     B, H, W, cout, dtype, bias=b.to(hh.DEV))
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+    # Downsample: pixel-unshuffle + conv1x1 (ddpm.py:120-124)
+    c, cout = 32, 64
+    x = _q(hh.rand((B, c, 2 * H, 2 * W), 27), dtype)
+    w, b = _q(hh.rand((cout, 4 * c, 1, 1), 28, -0.2, 0.2), dtype), hh.rand((cout,), 29)
+    sd = {"d.1.weight": w, "d.1.bias": b}
+    ref = unet_ref.pixel_unshuffle_conv(sd, "d", x)
+    out = hh.conv1x1([hh.make_src(hh.nhwc(x, dtype), c)], hh.pack(w, dtype, 1, unshuffle=1), B, H, W, cout, dtype,
+                     bias=b.to(hh.DEV), unshuffle=1)
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,H,W", [(32, 16, 16), (64, 14, 14), (128, 7, 7)])
+def test_qkv_epilogues(dtype, c, H, W):
+    """RMSNorm -> to_qkv -> (q softmax over d, * scale) as in LinearAttention; and the full-attn form."""
+    B, hid = 2, 128
+    x = _q(hh.rand((B, c, H, W), 30, -2, 2), dtype)
+    g = hh.rand((1, c, 1, 1), 31, 0.5, 1.5)
+    w = _q(hh.rand((3 * hid, c, 1, 1), 32, -0.3, 0.3), dtype)
+    qkv = F.conv2d(unet_ref.rms_norm(x, g), w)
+    q, k, v = qkv.chunk(3, dim=1)
+    qs = q.reshape(B, 4, 32, H * W).softmax(dim=-2).reshape(B, hid, H, W) * 32 ** -0.5
+    wp = hh.pack(w, dtype, 1, scale_in=g.flatten() * math.sqrt(c))
+    out = hh.conv1x1([hh.make_src(hh.nhwc(x, dtype), c)], wp, B, H, W, 3 * hid, dtype, epi=cabi.EPI_QKV_LINEAR, rms_in=1)
+    tol = hh.RTOL[dtype] * (3 if dtype == "bf16" else 5)
+    assert hh.rel_err(hh.nchw(out), torch.cat([qs, k, v], 1)) < tol
+    out = hh.conv1x1([hh.make_src(hh.nhwc(x, dtype), c)], wp, B, H, W, 3 * hid, dtype, epi=cabi.EPI_QKV_FULL, rms_in=1)
+    assert hh.rel_err(hh.nchw(out), torch.cat([q * 32 ** -0.5, k, v], 1)) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c", [32, 64, 128])
+def test_conv1x1_rms_res_epilogue_and_batched_weights(dtype, c):
+    B, hid, H, W = 2, 128, 9, 11
+    x = _q(hh.rand((B, hid, H, W), 33), dtype)
+    res = _q(hh.rand((B, c, H, W), 34), dtype)
+    w = _q(hh.rand((B, c, hid, 1, 1), 35, -0.3, 0.3), dtype)          # a different weight per batch element
+    b, g = hh.rand((c,), 36), hh.rand((1, c, 1, 1), 37, 0.5, 1.5)
+    ref = torch.cat([unet_ref.rms_norm(F.conv2d(x[i:i + 1], w[i], b), g) for i in range(B)]) + res
+    wp = torch.stack([hh.pack(w[i], dtype, 1) for i in range(B)]).contiguous()
+    es = 4 if dtype == "fp32" else 2
+    out = hh.conv1x1([hh.make_src(hh.nhwc(x, dtype), hid)], wp, B, H, W, c, dtype, bias=b.to(hh.DEV),
+                     epi=cabi.EPI_RMS_RES, bstride=c * hid * es, g2=(g.flatten() * math.sqrt(c)).to(hh.DEV),
+                     residual=hh.nhwc(res, dtype))
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 3
+    ref = F.conv2d(x, w[0], b) + res
+    out = hh.conv1x1([hh.make_src(hh.nhwc(x, dtype), hid)], wp, B, H, W, c, dtype, bias=b.to(hh.DEV),
+                     epi=cabi.EPI_RES, residual=hh.nhwc(res, dtype))
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
+
+
+# ------------------------------------------------------------------------------ image convs
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,ks,H,W", [(1, 7, 28, 28), (3, 7, 32, 48), (1, 3, 16, 16), (3, 3, 20, 12)])
+def test_conv_image(dtype, cin, ks, H, W):
+    B = 2
+    x, w, b = hh.rand((B, cin, H, W), 40), hh.rand((32, cin, ks, ks), 41, -0.2, 0.2), hh.rand((32,), 42)
+    ref = F.conv2d(x, w, b, padding=ks // 2)
+    out = torch.empty(B, H, W, 32, dtype=hh.TDT[dtype], device=hh.DEV)
+    stats = torch.zeros(B, 16, 2, dtype=torch.float64, device=hh.DEV)
+    xd, wd, bd = x.to(hh.DEV), w.to(hh.DEV), b.to(hh.DEV)
+    cabi.check(cabi.lib().ld_conv_image(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                                        16, B, cin, H, W, ks, cabi.dtype_code(dtype), hh.st()), "conv_image")
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+    assert hh.rel_err(stats.cpu(), hh.gn_stats_ref(ref, 16)) < 1e-5
+
+
+# ------------------------------------------------------------------------------ gn_apply
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gn_apply_resblock_tail_and_basicblock_tail(dtype):
+    B, c, H, W = 2, 64, 12, 10
+    a, r = _q(hh.rand((B, c, H, W), 50, -2, 3), dtype), _q(hh.rand((B, c, H, W), 51), dtype)
+    ga, ba = hh.rand((c,), 52, 0.5, 1.5), hh.rand((c,), 53, -0.3, 0.3)
+    ref = F.silu(F.group_norm(a, 8, ga, ba)) + r
+    A = cabi.GnApplyArgs()
+    ad, rd = hh.nhwc(a, dtype), hh.nhwc(r, dtype)
+    sa = hh.gn_stats_ref(a, 8).to(hh.DEV)
+    gad, bad = ga.to(hh.DEV), ba.to(hh.DEV)
+    A.a = hh.make_src(ad, c, gn=(sa, gad, bad, 8), act=cabi.ACT_SILU)
+    A.b = hh.make_src(rd, c)
+    out = torch.empty(B, H, W, c, dtype=hh.TDT[dtype], device=hh.DEV)
+    A.out, A.B, A.H, A.W, A.dtype = out.data_ptr(), B, H, W, cabi.dtype_code(dtype)
+    cabi.check(cabi.lib().ld_gn_apply(C.byref(A), hh.st()), "gn_apply")
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+    # BasicBlock tail with pooling: maxpool(relu(GN16(a) + GN16(r)))
+    gr, br = hh.rand((c,), 54, 0.5, 1.5), hh.rand((c,), 55, -0.3, 0.3)
+    ref = F.max_pool2d(F.relu(F.group_norm(a, 16, ga, ba) + F.group_norm(r, 16, gr, br)), 2)
+    sa, sr = hh.gn_stats_ref(a, 16).to(hh.DEV), hh.gn_stats_ref(r, 16).to(hh.DEV)
+    grd, brd = gr.to(hh.DEV), br.to(hh.DEV)
+    A = cabi.GnApplyArgs()
+    A.a = hh.make_src(ad, c, gn=(sa, gad, bad, 16))
+    A.b = hh.make_src(rd, c, gn=(sr, grd, brd, 16))
+    A.final_act, A.pool = cabi.ACT_RELU, 1
+    out = torch.empty(B, H // 2, W // 2, c, dtype=hh.TDT[dtype], device=hh.DEV)
+    A.out, A.B, A.H, A.W, A.dtype = out.data_ptr(), B, H, W, cabi.dtype_code(dtype)
+    cabi.check(cabi.lib().ld_gn_apply(C.byref(A), hh.st()), "gn_apply")
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+
+
+# ------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n_hw", [(7, 7), (16, 16), (32, 32)])
+def test_full_attention(dtype, n_hw):
+    B, hid = 2, 128
+    H, W = n_hw
+    n = H * W
+    qkv = _q(hh.rand((B, 3 * hid, H, W), 60, -1.5, 1.5), dtype)
+    q, k, v = [t.reshape(B, 4, 32, n).transpose(-1, -2) for t in qkv.chunk(3, dim=1)]
+    att = (q @ k.transpose(-1, -2)).softmax(dim=-1) @ v            # q is taken as pre-scaled
+    ref = att.transpose(-1, -2).reshape(B, hid, H, W)
+    out = torch.empty(B, H, W, hid, dtype=hh.TDT[dtype], device=hh.DEV)
+    qd = hh.nhwc(qkv, dtype)
+    cabi.check(cabi.lib().ld_attention(qd.data_ptr(), out.data_ptr(), B, n, 4, 32, cabi.dtype_code(dtype), hh.st()), "attention")
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c,H,W", [(32, 28, 28), (64, 14, 14), (32, 64, 96)])
+def test_linear_attention_block(dtype, c, H, W):
+    """RMSNorm -> qkv -> k softmax over n, ctx, fold, to_out, RMSNorm, + x  vs the oracle block."""
+    B, hid, n = 2, 128, H * W
+    x = _q(hh.rand((B, c, H, W), 70, -2, 2), dtype)
+    sd = {"a.norm.g": hh.rand((1, c, 1, 1), 71, 0.5, 1.5),
+          "a.to_qkv.weight": _q(hh.rand((3 * hid, c, 1, 1), 72, -0.3, 0.3), dtype),
+          "a.to_out.0.weight": hh.rand((c, hid, 1, 1), 73, -0.3, 0.3),
+          "a.to_out.0.bias": hh.rand((c,), 74),
+          "a.to_out.1.g": hh.rand((1, c, 1, 1), 75, 0.5, 1.5)}
+    ref = unet_ref.linear_attention(sd, "a", x) + x
+    lib, dt = cabi.lib(), cabi.dtype_code(dtype)
+    xd = hh.nhwc(x, dtype)
+    wq = hh.pack(sd["a.to_qkv.weight"], dtype, 1, scale_in=sd["a.norm.g"].flatten() * math.sqrt(c))
+    qkv = hh.conv1x1([hh.make_src(xd, c)], wq, B, H, W, 3 * hid, dtype, epi=cabi.EPI_QKV_LINEAR, rms_in=1)
+    nparts, nchunks = max(1, min(64, n // 256)), max(1, min(32, n // 2048))
+    kmax = torch.empty(B, nparts, hid, device=hh.DEV)
+    ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, 4, 32, nchunks)), device=hh.DEV)
+    wfold = torch.empty(B, c * hid, dtype=hh.TDT[dtype], device=hh.DEV)
+    wout = sd["a.to_out.0.weight"].reshape(c, hid).contiguous().to(hh.DEV)
+    cabi.check(lib.ld_linattn_kmax(qkv.data_ptr(), kmax.data_ptr(), B, n, 4, 32, nparts, dt, hh.st()), "kmax")
+    cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), nparts, ctx.data_ptr(), B, n, 4, 32, nchunks, dt, hh.st()), "ctx")
+    cabi.check(lib.ld_linattn_fold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold.data_ptr(), B, c, 4, 32, dt, hh.st()), "fold")
+    # intermediate check: kmax
+    kref = F.conv2d(unet_ref.rms_norm(x, sd["a.norm.g"]), sd["a.to_qkv.weight"]).chunk(3, dim=1)[1].reshape(B, hid, n).amax(-1)
+    assert hh.rel_err(kmax.amax(1).cpu(), kref) < hh.RTOL[dtype] * 3
+    es = 4 if dtype == "fp32" else 2
+    out = hh.conv1x1([hh.make_src(qkv, hid, stride=3 * hid)], wfold, B, H, W, c, dtype, bias=sd["a.to_out.0.bias"].to(hh.DEV),
+                     epi=cabi.EPI_RMS_RES, bstride=c * hid * es, g2=(sd["a.to_out.1.g"].flatten() * math.sqrt(c)).to(hh.DEV),
+                     residual=xd)
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * (5 if dtype == "fp32" else 2)
+
+
+# ------------------------------------------------------------------------------ time embedding
+def test_time_mlp_and_film():
+    dim, td, n, two_c = 32, 128, 7, 64
+    sd = {"time_mlp.1.weight": hh.rand((td, dim), 80, -0.2, 0.2), "time_mlp.1.bias": hh.rand((td,), 81),
+          "time_mlp.3.weight": hh.rand((td, td), 82, -0.1, 0.1), "time_mlp.3.bias": hh.rand((td,), 83)}
+    times = torch.tensor([0, 1, 5, 99, 500, 998, 999])
+    ref = unet_ref.time_embedding(sd, times, dim)
+    half = dim // 2
+    freqs = torch.exp(torch.arange(half) * -(math.log(10000.0) / (half - 1))).to(hh.DEV)
+    td_ = {k: v.to(hh.DEV) for k, v in sd.items()}
+    temb = torch.empty(n, td, device=hh.DEV)
+    tdev = times.to(hh.DEV, torch.int32)
+    lib = cabi.lib()
+    cabi.check(lib.ld_time_mlp(tdev.data_ptr(), n, freqs.data_ptr(), dim, td_["time_mlp.1.weight"].data_ptr(),
+                               td_["time_mlp.1.bias"].data_ptr(), td_["time_mlp.3.weight"].data_ptr(),
+                               td_["time_mlp.3.bias"].data_ptr(), td, temb.data_ptr(), hh.st()), "time_mlp")
+    assert hh.rel_err(temb.cpu(), ref) < 2e-5
+    w, b = hh.rand((two_c, td), 84, -0.1, 0.1), hh.rand((two_c,), 85)
+    fref = F.linear(F.silu(ref), w, b)
+    film = torch.empty(n, two_c, device=hh.DEV)
+    wd, bd = w.to(hh.DEV), b.to(hh.DEV)
+    cabi.check(lib.ld_film(temb.data_ptr(), n, td, wd.data_ptr(), bd.data_ptr(), two_c, film.data_ptr(), hh.st()), "film")
+    assert hh.rel_err(film.cpu(), fref) < 2e-5
+
+
+# ------------------------------------------------------------------------------ pointwise / sampler kernels
+def test_randn_matches_host_stream():
+    n = 1 << 16
+    out = torch.empty(n, device=hh.DEV)
+    tdev = torch.tensor([7], dtype=torch.int32, device=hh.DEV)
+    cabi.check(cabi.lib().ld_randn(out.data_ptr(), n, 10, 3, 0, None, hh.st()), "randn")
+    ref = torch.from_numpy(rng.randn((n,), 10, 3))
+    assert float((out.cpu() - ref).abs().max()) < 2e-5           # fp32 Box-Muller vs fp64 on the host
+    cabi.check(cabi.lib().ld_randn(out.data_ptr(), n, 10, 100, -1, tdev.data_ptr(), hh.st()), "randn")
+    assert float((out.cpu() - torch.from_numpy(rng.randn((n,), 10, 93))).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("objective", ["pred_x0", "pred_noise", "pred_v"])
+def test_ddpm_step(objective):
+    T, shape = 50, (2, 3, 8, 8)
+    buf = schedule.make_buffers(T, "sigmoid", objective)
+    table = torch.stack([buf["posterior_mean_coef1"], buf["posterior_mean_coef2"],
+                         (0.5 * buf["posterior_log_variance_clipped"]).exp(), buf["sqrt_recip_alphas_cumprod"],
+                         buf["sqrt_recipm1_alphas_cumprod"], buf["sqrt_alphas_cumprod"],
+                         buf["sqrt_one_minus_alphas_cumprod"], buf["alphas_cumprod"]], 1).contiguous().to(hh.DEV)
+    x, mo, z = hh.rand(shape, 90, -2, 2), hh.rand(shape, 91, -1, 3), hh.rand(shape, 92, -2, 2)
+    for t in (0, 1, 17, 49):
+        if objective == "pred_x0":
+            x0 = mo
+        elif objective == "pred_noise":
+            x0 = buf["sqrt_recip_alphas_cumprod"][t] * x - buf["sqrt_recipm1_alphas_cumprod"][t] * mo
+        else:
+            x0 = buf["sqrt_alphas_cumprod"][t] * x - buf["sqrt_one_minus_alphas_cumprod"][t] * mo
+        x0 = x0.clamp(0.0, 2.0)
+        ref = buf["posterior_mean_coef1"][t] * x0 + buf["posterior_mean_coef2"][t] * x
+        if t > 0:
+            ref = ref + (0.5 * buf["posterior_log_variance_clipped"][t]).exp() * z
+        xd, md, zd = x.to(hh.DEV), mo.to(hh.DEV), z.to(hh.DEV)
+        out, x0o = torch.empty_like(xd), torch.empty_like(xd)
+        tdev = torch.tensor([t], dtype=torch.int32, device=hh.DEV)
+        cabi.check(cabi.lib().ld_ddpm_step(xd.data_ptr(), md.data_ptr(), zd.data_ptr(), out.data_ptr(), x0o.data_ptr(),
+                                           table.data_ptr(), tdev.data_ptr(), 0.0, 2.0, cabi.OBJ[objective], xd.numel(),
+                                           hh.st()), "ddpm_step")
+        assert float((out.cpu() - ref).abs().max()) < 1e-6
+        assert float((x0o.cpu() - x0).abs().max()) < 1e-6
+
+
+def test_branch_and_fusion_kernels():
+    B, Cc, H = 2, 3, 8
+    HW = H * H
+    lib = cabi.lib()
+    cond, mask = hh.rand((B, Cc, H, H), 93, 0, 2), torch.zeros(B, 1, H, H)
+    mask[:, :, :, :3] = 1.0
+    mask[:, :, 0, 5] = 0.7
+    binary = (mask >= 1).float()
+    cd, md = cond.to(hh.DEV), mask.to(hh.DEV)
+    co, ci = torch.empty_like(cd), torch.empty_like(cd)
+    cabi.check(lib.ld_branch_conditions(cd.data_ptr(), md.data_ptr(), co.data_ptr(), ci.data_ptr(), 0.95, B, Cc, HW, hh.st()), "bc")
+    assert torch.equal(co.cpu(), cond * binary) and torch.equal(ci.cpu(), cond * torch.clip(1 - binary, 0.95, 1.0))
+    mo = hh.rand((B, Cc, H, H), 94, -1, 3)
+    mod = mo.to(hh.DEV)
+    cabi.check(lib.ld_mask_out(mod.data_ptr(), md.data_ptr(), 0.25, B, Cc, HW, hh.st()), "mask_out")
+    assert torch.equal(mod.cpu(), torch.where(binary == 0, torch.tensor(0.25), mo * binary))
+    xo, xi, p0o, p0i = [hh.rand((B, Cc, H, H), k, -1, 3) for k in (95, 96, 97, 98)]
+    x0 = (p0i.clamp(0, 2) * (1 - binary) + p0o.clamp(0, 2)).clamp(0, 2)
+    a, b_ = xo * binary, xi * (1 - binary)
+    xref = torch.where(a == 0, b_, a)
+    d = [t.to(hh.DEV) for t in (xo, xi, p0o, p0i)]
+    xd, x0d = torch.empty_like(d[0]), torch.empty_like(d[0])
+    cabi.check(lib.ld_fuse_ddpm(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), md.data_ptr(),
+                                xd.data_ptr(), x0d.data_ptr(), 0.0, 2.0, B, Cc, HW, hh.st()), "fuse")
+    assert torch.equal(xd.cpu(), xref) and float((x0d.cpu() - x0).abs().max()) < 1e-6
+    # K-mask recomposition
+    K = 4
+    masks = torch.zeros(K, HW)
+    for k in range(K):
+        masks[k].view(H, H)[:, 2 * k:2 * k + 2] = 1.0
+    patches = hh.rand((B, K, Cc, HW), 99)
+    ref = (patches * masks[None, :, None, :]).sum(1).reshape(B, Cc, H, H)
+    pd, mk, od = patches.to(hh.DEV), masks.to(hh.DEV), torch.empty(B, Cc, H, H, device=hh.DEV)
+    cabi.check(lib.ld_recompose(pd.data_ptr(), mk.data_ptr(), od.data_ptr(), B, K, Cc, HW, hh.st()), "recompose")
+    assert float((od.cpu() - ref).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_final_conv(dtype):
+    B, cin, cout, H, W = 2, 32, 3, 9, 13
+    x, w, b = _q(hh.rand((B, cin, H, W), 100), dtype), hh.rand((cout, cin, 1, 1), 101, -0.3, 0.3), hh.rand((cout,), 102)
+    ref = F.conv2d(x, w, b)
+    out = torch.empty(B, cout, H, W, device=hh.DEV)
+    xd, wd, bd = hh.nhwc(x, dtype), w.reshape(cout, cin).contiguous().to(hh.DEV), b.to(hh.DEV)
+    cabi.check(cabi.lib().ld_final_conv(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, cin, cout,
+                                        cabi.dtype_code(dtype), hh.st()), "final_conv")
+    assert hh.rel_err(out.cpu(), ref) < 1e-5

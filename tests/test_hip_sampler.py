@@ -1,0 +1,110 @@
+"""Sampler parity on the GPU: GaussianDiffusion.sample over the HIP kernels against the golden
+vectors generated from the real reference (fp32 storage, host noise stream = the fixtures' stream).
+Gate: max-abs <= 1e-3 (BASELINE.json north_star); observed values are printed."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import localdiffusion_hallucination_amd as ldh                   # noqa: E402
+from localdiffusion_hallucination_amd import rng, weights        # noqa: E402
+
+TOL = 1e-3
+MNIST = dict(dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist")
+
+
+def make(kw, config, H, T, S=None, objective="pred_x0", dtype="fp32"):
+    net = ldh.Unet(dim=32, init_dim=32, compute_dtype=dtype, **kw)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()})
+    cfg = dict(branch_out=False, start_intermediate=False, start_timestep=2, data="mri", mask_x=False,
+               mask_cond=False, ood_AD=False, ood_confidence=False, classifier=False, use_gt=False,
+               use_gt_timestep=100)
+    cfg.update(config)
+    gd = ldh.GaussianDiffusion(cfg, net, image_size=H, timesteps=T, beta_schedule="sigmoid", objective=objective,
+                               auto_normalize=False, sampling_timesteps=S).to("cuda")
+    gd.noise_source = "host"
+    return gd
+
+
+def run(gd, cond, mask, B):
+    out = gd.sample(cond.cuda(), None, batch_size=B, mask=None if mask is None else mask.cuda(), min_max_val=(0.0, 2.0))
+    if isinstance(out, list):
+        out = torch.stack(out)
+    return out.cpu().numpy()
+
+
+def check(tag, got, ref, tol=TOL):
+    assert got.shape == ref.shape, (tag, got.shape, ref.shape)
+    d = float(np.abs(got - ref).max())
+    print(f"{tag}: max-abs vs reference golden = {d:.3e}")
+    assert d <= tol, (tag, d)
+
+
+def test_three_step_runs(golden):
+    g = golden("g3_three_step")
+    cond, mask = torch.from_numpy(g["cond"]), torch.from_numpy(g["mask"])
+    cases = {
+        "nonbranch": dict(data="mnist"),
+        "branch_fuse_mnist": dict(data="mnist", branch_out=True, start_intermediate=True, start_timestep=1, mask_x=True),
+        "branch_fuse_mri": dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=1, mask_x=True),
+        "branch_nofuse": dict(data="mri", branch_out=True, start_intermediate=False, mask_x=True),
+    }
+    for tag, kw in cases.items():
+        check("G3 " + tag, run(make(MNIST, kw, 28, 3), cond, mask, 2), g[tag])
+
+
+def test_cfg1_mnist(golden):
+    """BASELINE.json configs[0]: MNIST 28x28 1-ch, T=100, 4 patches, branch + fusion."""
+    g = golden("g4_cfg1_mnist")
+    gd = make(MNIST, dict(data="mnist", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True, ood_AD=True), 28, 100)
+    check("G4 cfg1", run(gd, torch.from_numpy(g["cond"]), torch.from_numpy(g["mask"]), 4), g["final"])
+
+
+def test_cfg2_mri128_full(golden):
+    """BASELINE.json configs[1]: one 128x128 1-ch patch, T=1000, fp32 -- the 1e-3 parity gate."""
+    g = golden("g5_cfg2_mri128")
+    cond = torch.from_numpy(rng.uniform((1, 1, 128, 128), 5, 1, 0.0, 2.0))
+    gd = make(dict(mode="mri"), dict(data="mri"), 128, 1000)
+    check("G5 cfg2", run(gd, cond, None, 1), g["final"])
+
+
+def test_branch_fusion(golden):
+    g = golden("g6_branch_fusion")
+    for tag, kw, H, data in [("mri32", dict(mode="mri"), 32, "mri"), ("mnist28", MNIST, 28, "mnist")]:
+        cond = torch.from_numpy(rng.uniform((2, 1, H, H), 6, 1, 0.0, 2.0))
+        mask = torch.zeros(2, 1, H, H)
+        mask[:, :, :, :H // 4] = 1.0
+        gd = make(kw, dict(data=data, branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True), H, 50)
+        check("G6 " + tag, run(gd, cond, mask, 2), g[tag + "_final"])
+
+
+def test_ddim(golden):
+    g = golden("g7_ddim")
+    cond = torch.from_numpy(rng.uniform((1, 1, 64, 64), 7, 1, 0.0, 2.0))
+    mask = torch.from_numpy(g["mask"])
+    kw = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True)
+    check("G7 fused", run(make(dict(mode="mri"), kw, 64, 1000, 50), cond, mask, 1), g["fused_final"])
+    kw = dict(data="mri", branch_out=True, start_intermediate=False, mask_x=True)
+    check("G7 nofuse", run(make(dict(mode="mri"), kw, 64, 50, 10), cond, mask, 1), g["nofuse_final"])
+    check("G7 single", run(make(dict(mode="mri"), dict(data="mri"), 64, 50, 10), cond, None, 1), g["single_final"])
+
+
+def test_fallback_and_objectives(golden):
+    g = golden("g8_fallback_objectives")
+    cond = torch.from_numpy(rng.uniform((2, 1, 28, 28), 8, 1, 0.0, 2.0))
+    kw = dict(data="mnist", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True)
+    check("G8 all-ones", run(make(MNIST, kw, 28, 20), cond, torch.ones(2, 1, 28, 28), 2), g["allones_final"])
+    for obj in ("pred_noise", "pred_v"):
+        check("G8 " + obj, run(make(MNIST, dict(data="mnist"), 28, 20, objective=obj), cond, None, 2), g[obj + "_final"])
+
+
+def test_device_noise_runs_and_is_deterministic():
+    gd = make(MNIST, dict(data="mnist"), 28, 10)
+    gd.noise_source = "device"
+    cond = torch.from_numpy(rng.uniform((2, 1, 28, 28), 8, 1, 0.0, 2.0))
+    a, b = run(gd, cond, None, 2), run(gd, cond, None, 2)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    gd.noise_source = "host"
+    c = run(gd, cond, None, 2)
+    assert float(np.abs(a - c).max()) < 1e-3      # device Box-Muller is fp32, host fp64
