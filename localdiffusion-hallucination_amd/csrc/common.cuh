@@ -182,3 +182,8 @@ __device__ __forceinline__ float wave16_sum(float v) {
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
   return v;
 }
+
+__device__ __forceinline__ double wave16_sum_d(double v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}

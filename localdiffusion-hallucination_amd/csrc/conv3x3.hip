@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   char* s_w = smem + 4 * PLANE;
   float* s_coef = reinterpret_cast<float*>(s_w + 9 * MT * 1024);
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
-  float* s_stat = s_coef + 2 * ctot;          // [2][16*MT]
+  // [2][16*MT] fp64: per-lane fp32 partials (<= NW values) are widened before any cross-lane sum, so the
+  // E[x^2]-mean^2 cancellation never sees fp32 partial-sum rounding and the result is order-independent
+  double* s_stat = reinterpret_cast<double*>(s_coef + 2 * ctot + ((2 * ctot) & 1));
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
   const int b = blockIdx.z, m0 = blockIdx.y * MT;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
       }
       off += 2 * S.C;
     }
-    if (tid < 32 * MT) s_stat[tid] = 0.0f;
+    if (tid < 32 * MT) s_stat[tid] = 0.0;
   }
 
   f32x4 acc[MT][NW];
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
+        const double s1 = wave16_sum_d((double)ssum[m][r]), s2 = wave16_sum_d((double)ssq[m][r]);
         if (px == 0) {
           atomicAdd(&s_stat[m * 16 + kq * 4 + r], s1);
           atomicAdd(&s_stat[16 * MT + m * 16 + kq * 4 + r], s2);
@@ -212,7 +214,7 @@ int launch(const Conv3Dev& a, hipStream_t st) {
   constexpr int TR = 4 * NW, HR = TR + 2, HC = 18;
   constexpr int NPIXP = (HR * HC + 15) / 16 * 16;
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
-  const size_t lds = 4 * NPIXP * 16 + 9 * MT * 1024 + 2 * ctot * sizeof(float) + 2 * 16 * MT * sizeof(float);
+  const size_t lds = 4 * NPIXP * 16 + 9 * MT * 1024 + (2 * ctot + 2) * sizeof(float) + 2 * 16 * MT * sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
     LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW>, lds));

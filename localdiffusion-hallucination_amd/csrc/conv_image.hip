@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void conv_image_kernel(const float* __restrict
   constexpr int PAD = KS / 2, HS = TS + KS - 1;
   __shared__ float s_in[3 * HS * HS];
   __shared__ __attribute__((aligned(16))) float s_wt[3 * KS * KS * CO];   // [c*KS*KS + tap][o]
-  __shared__ float s_red[2 * CO];
+  __shared__ double s_red[2 * CO];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int b = blockIdx.y;
   const int y0 = (blockIdx.x / tiles_x) * TS, x0 = (blockIdx.x % tiles_x) * TS;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void conv_image_kernel(const float* __restrict
     const int o = i / ktot, k = i - o * ktot;
     s_wt[k * CO + o] = w[i];
   }
-  if (tid < 2 * CO) s_red[tid] = 0.f;
+  if (tid < 2 * CO) s_red[tid] = 0.0;
   __syncthreads();
   float acc[CO];
 #pragma unroll
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_image_kernel(const float* __restrict
     // per-channel sums over the tile: wave shuffle tree, then LDS, then one fp64 atomic per group
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
-      float s1 = valid ? acc[o] : 0.f, s2 = valid ? acc[o] * acc[o] : 0.f;
+      double s1 = valid ? (double)acc[o] : 0.0, s2 = valid ? (double)acc[o] * (double)acc[o] : 0.0;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) { s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); }
       if ((tid & 63) == 0) { atomicAdd(&s_red[o], s1); atomicAdd(&s_red[CO + o], s2); }

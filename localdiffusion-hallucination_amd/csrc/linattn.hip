@@ -106,13 +106,15 @@ __global__ __launch_bounds__(256) void ctx_kernel(const T* __restrict__ qkv, con
 }
 
 // ------------------------------------------------------------------ fold ctx into per-batch 1x1 weights
+// grid = (C/16 channel tiles, B): every workgroup reduces the chunk partials of ctx (L2-resident,
+// heads*1056 floats per chunk) into LDS, then produces one 16-row tile of M_b.
 template <typename T>
 __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctx_part, int nchunks,
                                                    const float* __restrict__ w_out, T* __restrict__ w_packed,
                                                    int C, int heads) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   extern __shared__ float s_ctx[];                       // [heads][32][32] normalised, then [heads][32] Z
-  const int hidden = heads * 32, b = blockIdx.x, tid = threadIdx.x;
+  const int hidden = heads * 32, b = blockIdx.y, mt = blockIdx.x, tid = threadIdx.x;
   float* s_z = s_ctx + heads * 1024;
   for (int i = tid; i < heads * 32; i += 256) {
     const int h = i / 32, d = i - h * 32;
@@ -130,15 +132,16 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctx
   __syncthreads();
   const int mt_total = C / 16;
   T* dst = w_packed + (size_t)b * C * hidden;
-  for (int i = tid; i < C * hidden; i += 256) {
-    const int co = i / hidden, ci = i - co * hidden;     // ci = h*32 + d
+  for (int i = tid; i < 16 * hidden; i += 256) {
+    const int ii = i / hidden, ci = i - ii * hidden;     // ci = h*32 + d
+    const int co = mt * 16 + ii;
     const int h = ci >> 5, d = ci & 31;
     const float* wrow = w_out + (size_t)co * hidden + h * 32;
     const float* crow = s_ctx + h * 1024 + d * 32;
     float m = 0.f;
 #pragma unroll 8
     for (int e = 0; e < 32; ++e) m = fmaf(wrow[e], crow[e], m);
-    const int mt = co >> 4, ii = co & 15, ch = ci / CK, kq = (ci % CK) / E, e = ci % E;
+    const int ch = ci / CK, kq = (ci % CK) / E, e = ci % E;
     dst[((((size_t)ch * mt_total + mt) * 4 + kq) * 16 + ii) * E + e] = from_f<T>(m);
   }
 }
@@ -196,9 +199,9 @@ extern "C" int ld_linattn_fold(const float* ctx_part, int nchunks, const float* 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds = (size_t)heads * (1024 + 32) * sizeof(float);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(fold_kernel<float>, dim3(B), dim3(256), lds, st, ctx_part, nchunks, w_out, (float*)w_packed, C, heads);
+    hipLaunchKernelGGL(fold_kernel<float>, dim3(C / 16, B), dim3(256), lds, st, ctx_part, nchunks, w_out, (float*)w_packed, C, heads);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(fold_kernel<bf16>, dim3(B), dim3(256), lds, st, ctx_part, nchunks, w_out, (bf16*)w_packed, C, heads);
+    hipLaunchKernelGGL(fold_kernel<bf16>, dim3(C / 16, B), dim3(256), lds, st, ctx_part, nchunks, w_out, (bf16*)w_packed, C, heads);
   else
     return ld_fail(LD_EINVAL, "ld_linattn_fold: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("linattn_fold");

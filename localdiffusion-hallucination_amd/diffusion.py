@@ -153,6 +153,34 @@ class GaussianDiffusion(nn.Module):
                                     float(min_max_val[1]), cabi.OBJ[self.objective], x.numel(), st), "ddpm_step")
         return x_prev, x0
 
+    # ------------------------------------------------------------------ joint reverse steps
+    def run_joint_steps(self, jp, t_start, n_steps, lo, hi, z, draw, x0_buf=None, after=None, timers=None):
+        """``n_steps`` ancestral steps t_start, t_start-1, ... on plan ``jp`` (x_t lives in
+        ``jp.x_in`` and is updated in place; the conditioning features must already be encoded).
+        One step = denoiser evaluation (ddpm.py:716) + x0 clamp + posterior mean + sigma*z
+        (ddpm.py:817-838, 857-858).  Returns the next draw index.  Used by p_sample_loop and bench.py."""
+        lib, st = cabi.lib(), self._st()
+        sched = self._sched_table()
+        obj = cabi.OBJ[self.objective]
+        n = jp.x_in.numel()
+        t = t_start
+        for _ in range(n_steps):
+            jp.set_step(t)
+            if timers is None:
+                jp.run_main(st)
+            else:
+                jp.run_main_timed(st, timers)
+            if t > 0:
+                self._noise(z, draw)
+                draw += 1
+            cabi.check(lib.ld_ddpm_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), z.data_ptr(),
+                                        jp.x_in.data_ptr(), cabi.ptr(x0_buf), sched.data_ptr(),
+                                        jp.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+            if after is not None:
+                after(t)
+            t -= 1
+        return draw
+
     # ------------------------------------------------------------------ DDPM loop
     @torch.inference_mode()
     def p_sample_loop(self, cond_img, mask, min_max_val, shape, return_all_timesteps=False,
@@ -249,20 +277,13 @@ class GaussianDiffusion(nn.Module):
                 jp.x_in.copy_(x_T)
             jp.cond_in.copy_(cond)
             jp.run_cond(st)
-            while t >= 0:
-                jp.set_step(t)
-                jp.run_main(st)
-                if t > 0:
-                    self._noise(z, draw)
-                    draw += 1
-                cabi.check(lib.ld_ddpm_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), z.data_ptr(),
-                                            jp.x_in.data_ptr(), cabi.ptr(x0_buf), sched.data_ptr(),
-                                            jp.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+            def after(_t):
                 if return_all_outputs:
                     hist_x0.append(x0_buf.cpu())
                 if return_all_timesteps:
                     hist_x.append(jp.x_in.clone())
-                t -= 1
+            self.run_joint_steps(jp, t, t + 1, lo, hi, z, draw, x0_buf=x0_buf,
+                                 after=after if (return_all_outputs or return_all_timesteps) else None)
             ret = jp.x_in.clone()
         else:
             ret = xs

@@ -220,6 +220,7 @@ class _Plan:
         self.cfg = cfg
         self.keep = []
         self.named = {}                            # oracle tap name -> NHWC buffer (parity tests)
+        self.meta = {}                             # index in ops_main -> {what, family, bytes, flops}
         self.ops_time, self.ops_cond, self.ops_main = [], [], []
         self.nslot = 0
         self.stats = torch.zeros(160, B, 16, 2, dtype=torch.float64, device=self.dev)
@@ -271,10 +272,17 @@ class _Plan:
         self.keep.append(t)
         return s
 
-    def _call(self, ops, fn, args, what):
+    def _call(self, ops, fn, args, what, meta=None):
         self.keep.append(args)
         ref = C.byref(args)
         ops.append(lambda st, fn=fn, ref=ref, what=what: cabi.check(fn(ref, st), what))
+        if ops is self.ops_main:
+            self.meta[len(ops) - 1] = dict(what=what, **(meta or {}))
+
+    def _raw(self, ops, fn, what, nbytes=0, flops=0):
+        ops.append(fn)
+        if ops is self.ops_main:
+            self.meta[len(ops) - 1] = dict(what=what, family=what, bytes=nbytes, flops=flops)
 
     def conv3(self, ops, srcs, wname, cout, h, w, stats=None, groups=8):
         a = cabi.Conv3x3Args()
@@ -290,7 +298,15 @@ class _Plan:
         a.B, a.H, a.W, a.Cout = self.B, h, w, cout
         a.t_ptr = self.t_ptr()
         a.dtype = self.dt
-        self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname)
+        cin = sum(s.C for s in srcs)
+        npx = self.B * h * w
+        mt4 = cout % 64 == 0
+        big = ((w + 15) // 16) * ((h + 15) // 16) * (cout // (64 if mt4 else 32)) * self.B >= 512 and h >= 16
+        fam = f"conv3x3<{'f32' if self.dt == cabi.LD_F32 else 'bf16'},{4 if mt4 else 2},{4 if big else 2}>"
+        in_el = sum(s.C * (npx // 4 if s.upsample else npx) for s in srcs)
+        self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname,
+                   dict(family=fam, bytes=(in_el + npx * cout + 9 * cin * cout) * self.esize + 4 * cout,
+                        flops=2 * 9 * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"))
         return out
 
     def conv1(self, ops, srcs, weight, cout, h, w, bias=None, epi=cabi.EPI_PLAIN, unshuffle=0, rms_in=0,
@@ -307,7 +323,11 @@ class _Plan:
         a.out = out.data_ptr()
         a.B, a.H, a.W, a.Cout, a.dtype = self.B, h, w, cout, self.dt
         self.keep += [weight, bias, g2, residual]
-        self._call(ops, self.lib.ld_conv1x1, a, what)
+        cin = sum(s.C for s in srcs) * (4 if unshuffle else 1)
+        npx = self.B * h * w
+        el = npx * cin + npx * cout + cin * cout * (self.B if bstride else 1) + (npx * cout if residual is not None else 0)
+        self._call(ops, self.lib.ld_conv1x1, a, what,
+                   dict(family="conv1x1", bytes=el * self.esize, flops=2 * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"))
         return out
 
     def gn_apply(self, ops, a_src, b_src, h, w, c, final_act=cabi.ACT_NONE, pool=0):
@@ -319,7 +339,9 @@ class _Plan:
         out = self.buf(h // 2 if pool else h, w // 2 if pool else w, c)
         g.out = out.data_ptr()
         g.B, g.H, g.W, g.t_ptr, g.dtype = self.B, h, w, self.t_ptr(), self.dt
-        self._call(ops, self.lib.ld_gn_apply, g, "gn_apply")
+        nel = self.B * h * w * c
+        self._call(ops, self.lib.ld_gn_apply, g, "gn_apply",
+                   dict(family="gn_apply", bytes=(nel * (2 if b_src is not None else 1) + nel // (4 if pool else 1)) * self.esize, flops=0))
         return out
 
     # ------------------------------------------------------------------ time embedding / FiLM
@@ -384,12 +406,16 @@ class _Plan:
         wout = f[p + ".to_out.0.weight"].reshape(c, hid).contiguous()
         self.keep += [kmax, ctx, wfold, wout, qkv]
         dt, heads = self.dt, cfg.attn_heads
-        ops.append(lambda st: cabi.check(lib.ld_linattn_kmax(qkv.data_ptr(), kmax.data_ptr(), B, n, heads, 32,
-                                                             nparts, dt, st), "linattn_kmax"))
-        ops.append(lambda st: cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), nparts, ctx.data_ptr(),
-                                                            B, n, heads, 32, nchunks, dt, st), "linattn_ctx"))
-        ops.append(lambda st: cabi.check(lib.ld_linattn_fold(ctx.data_ptr(), nchunks, wout.data_ptr(),
-                                                             wfold.data_ptr(), B, c, heads, 32, dt, st), "linattn_fold"))
+        es = self.esize
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_kmax(qkv.data_ptr(), kmax.data_ptr(), B, n, heads, 32,
+                                                                 nparts, dt, st), "linattn_kmax"),
+                  "linattn_kmax", nbytes=B * n * hid * es)
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), nparts, ctx.data_ptr(),
+                                                                B, n, heads, 32, nchunks, dt, st), "linattn_ctx"),
+                  "linattn_ctx", nbytes=2 * B * n * hid * es, flops=2 * B * n * hid * 32)
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_fold(ctx.data_ptr(), nchunks, wout.data_ptr(),
+                                                                 wfold.data_ptr(), B, c, heads, 32, dt, st), "linattn_fold"),
+                  "linattn_fold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
         q = self.src(qkv, hid, stride=3 * hid)
         return self.conv1(ops, [q], wfold, c, h, w, bias=f[p + ".to_out.0.bias"], epi=cabi.EPI_RMS_RES,
                           bstride=c * hid * self.esize, g2=self.P["g2"][p + ".to_out.1.g"], residual=x,
@@ -404,8 +430,9 @@ class _Plan:
         att = self.buf(h, w, hid)
         dt, heads = self.dt, cfg.attn_heads
         self.keep += [qkv, att]
-        ops.append(lambda st: cabi.check(lib.ld_attention(qkv.data_ptr(), att.data_ptr(), B, n, heads, 32, dt, st),
-                                         "attention"))
+        self._raw(ops, lambda st: cabi.check(lib.ld_attention(qkv.data_ptr(), att.data_ptr(), B, n, heads, 32, dt, st),
+                                             "attention"),
+                  "attention", nbytes=4 * B * n * hid * self.esize, flops=4 * B * n * n * hid)
         return self.conv1(ops, [self.src(att, hid)], self.P["w"][p + ".to_out.weight"], c, h, w,
                           bias=f[p + ".to_out.bias"], epi=cabi.EPI_RES, residual=x, what="full to_out " + p)
 
@@ -460,9 +487,10 @@ class _Plan:
         H, W = self.H, self.W
         r = self.buf(H, W, cfg.init_dim)
         wi, bi = f["init_conv.weight"], f["init_conv.bias"]
-        ops.append(lambda st: cabi.check(lib.ld_conv_image(
+        self._raw(ops, lambda st: cabi.check(lib.ld_conv_image(
             self.x_in.data_ptr(), wi.data_ptr(), bi.data_ptr(), r.data_ptr(), None, 1, B, cfg.channels, H, W, 7,
-            self.dt, st), "init_conv"))
+            self.dt, st), "init_conv"), "conv_image7x7",
+            nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W)
         self.named["init_conv"] = r
         x, c, h, w = r, cfg.init_dim, H, W
         skips = []
@@ -507,9 +535,10 @@ class _Plan:
         wf = f["final_conv.weight"].reshape(cfg.out_dim, cfg.dim).contiguous()
         bf = f["final_conv.bias"]
         self.keep += [wf, bf, x, r]
-        ops.append(lambda st, x=x: cabi.check(lib.ld_final_conv(
+        self._raw(ops, lambda st, x=x: cabi.check(lib.ld_final_conv(
             x.data_ptr(), wf.data_ptr(), bf.data_ptr(), self.model_out.data_ptr(), B, H, W, cfg.dim, cfg.out_dim,
-            self.dt, st), "final_conv"))
+            self.dt, st), "final_conv"), "final_conv",
+            nbytes=B * H * W * (self.esize * cfg.dim + 4 * cfg.out_dim), flops=2 * cfg.dim * cfg.out_dim * B * H * W)
 
     # ------------------------------------------------------------------ execution
     def run_time(self, st):
@@ -527,6 +556,30 @@ class _Plan:
         cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
         for op in self.ops_main:
             op(st)
+
+    def run_main_timed(self, st, acc):
+        """Like run_main, but brackets every op with HIP events on ``st`` and adds the elapsed time
+        to ``acc[index] = [ms_total, launches]`` (bench.py's per-kernel roofline leg)."""
+        lib = self.lib
+        s = self.stats[self.cond_slots:]
+        cabi.check(lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
+        if not hasattr(self, "_events"):
+            self._events = []
+            for _ in range(len(self.ops_main) + 1):
+                e = C.c_void_p()
+                cabi.check(lib.ld_event_create(C.byref(e)), "event_create")
+                self._events.append(e)
+        ev = self._events
+        cabi.check(lib.ld_event_record(ev[0], st), "event_record")
+        for i, op in enumerate(self.ops_main):
+            op(st)
+            cabi.check(lib.ld_event_record(ev[i + 1], st), "event_record")
+        ms = C.c_float()
+        for i in range(len(self.ops_main)):
+            cabi.check(lib.ld_event_elapsed_ms(ev[i], ev[i + 1], C.byref(ms)), "event_elapsed")
+            a = acc.setdefault(i, [0.0, 0])
+            a[0] += ms.value
+            a[1] += 1
 
     def set_step(self, t):
         self.t_dev.fill_(int(t))

@@ -54,6 +54,7 @@ def make_src(t, c, stride=0, ups=0, gn=None, act=0, film=None, film_b=0, film_t=
     s.act = act
     if film is not None:
         s.film, s.film_bstride, s.film_tstride = film.data_ptr(), film_b, film_t
+    s._keep = (t, gn, film)        # the struct only holds raw pointers: keep the tensors alive with it
     return s
 
 
