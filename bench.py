@@ -205,6 +205,15 @@ def main():
             f["launches"] += cnt
             f["bytes"] += m.get("bytes", 0) * cnt
             f["flops"] += m.get("flops", 0) * cnt
+        if os.environ.get("LD_BENCH_OPS"):
+            with open(os.environ["LD_BENCH_OPS"], "w") as f:
+                for i in sorted(acc):
+                    ms, cnt = acc[i]
+                    m = jp.meta.get(i, {})
+                    us = 1e3 * ms / cnt
+                    f.write(f"{i:4d} {m.get('family', '?'):22s} {m.get('what', '?'):38s} {m.get('shape', ''):20s} "
+                            f"{us:9.1f} us  {m.get('bytes', 0) / max(us, 1e-9) / 1e3:8.1f} GB/s  "
+                            f"{m.get('flops', 0) / max(us, 1e-9) / 1e6:8.1f} TF/s\n")
         name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
         achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["bytes"] else 0.0
         out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -38,6 +38,12 @@ extern "C" {
 #define LD_F32 0
 #define LD_BF16 1
 
+/* GroupNorm statistics buffers are [B, LD_STAT_STRIPES, groups, 2] fp64 (sum, sum of squares):
+ * a producer workgroup adds into stripe (workgroup index % LD_STAT_STRIPES) so that the 256
+ * workgroups of one image do not serialise on 16 addresses (measured: 23 us per launch at
+ * 256x256 with one stripe); the consumer sums the stripes while building its coefficients. */
+#define LD_STAT_STRIPES 16
+
 #define LD_ACT_NONE 0
 #define LD_ACT_SILU 1
 #define LD_ACT_RELU 2
@@ -74,7 +80,7 @@ typedef struct ld_src {
   int32_t pix_stride;      /* elements between consecutive pixels; 0 = C (dense). Lets a conv read a
                               channel slice, e.g. q = channels [0,hidden) of a qkv tensor */
   int32_t upsample;        /* 1: source is [B, H/2, W/2, C], read with nearest x2 */
-  const double* gn_stats;  /* [B, groups, 2] or NULL = no prologue */
+  const double* gn_stats;  /* [B, LD_STAT_STRIPES, groups, 2] or NULL = no prologue */
   const float* gn_gamma;   /* [C] */
   const float* gn_beta;    /* [C] */
   int32_t gn_groups;
@@ -94,7 +100,7 @@ typedef struct ld_conv3x3_args {
   const void* weight;      /* packed by ld_pack_conv_weight, storage dtype */
   const float* bias;       /* [Cout] fp32 */
   void* out;               /* NHWC [B,H,W,Cout] */
-  double* out_stats;       /* [B, out_groups, 2] accumulated (caller zeroes) or NULL */
+  double* out_stats;       /* [B, LD_STAT_STRIPES, out_groups, 2] accumulated (caller zeroes) or NULL */
   int32_t out_groups;
   int32_t B, H, W, Cout;   /* Cout multiple of 32 */
   const int32_t* t_ptr;
@@ -126,6 +132,8 @@ typedef struct ld_conv1x1_args {
   const float* g2;         /* [Cout] g*sqrt(Cout) for LD_EPI_RMS_RES */
   const void* residual;    /* NHWC [B,H,W,Cout] for *_RES */
   void* out;
+  uint32_t* kmax_out;      /* LD_EPI_QKV_LINEAR only, optional: [B, LD_STAT_STRIPES, hidden] order-encoded running max
+                              of the k channels over pixels (integer atomicMax; caller zeroes) -- see ld_linattn_kmax */
   int32_t B, H, W, Cout;
   int32_t dtype;
 } ld_conv1x1_args;
@@ -162,15 +170,21 @@ int ld_gn_apply(const ld_gn_apply_args* args, void* stream);
 /* ---- attention ---------------------------------------------------------------------------- */
 /* Linear attention core (ddpm.py:243,247,249) on a qkv tensor [B, n, 3*hidden] whose q part was
  * already soft-maxed by ld_conv1x1(LD_EPI_QKV_LINEAR):
- *   1. ld_linattn_kmax:  per (b, k-channel) partial maxima over n             (softmax over n)
- *   2. ld_linattn_ctx:   partial  ctx[d,e] = sum_n exp(k-max) v,  Z[d] = sum_n exp(k-max)
- *   3. ld_linattn_fold:  M_b = W_out . (ctx/Z)^T  packed as a per-batch 1x1 weight, so that
+ *   1. ld_linattn_kmax:  kmax[b, c] = max_n k[b, n, c] as an order-preserving uint32 code, combined with
+ *                        integer atomicMax into a zeroed [B, LD_STAT_STRIPES, hidden] buffer (softmax over n; the
+ *                        consumer takes the max over the stripes).
+ *                        The product path gets the same buffer for free from ld_conv1x1's kmax_out.
+ *   2. ld_linattn_ctx:   partial  ctx[d,e] = sum_n exp(k-max) v,  Z[d] = sum_n exp(k-max) per pixel chunk
+ *   3. ld_linattn_ctx_reduce: ctxn[b,h,d,e] = sum_chunks ctx / sum_chunks Z[d]   [B,heads,32,32]
+ *   4. ld_linattn_fold:  M_b = W_out . ctxn^T  packed as a per-batch 1x1 weight, so that
  *                        to_out(ctx^T q) becomes ONE 1x1 convolution over q (ld_conv1x1). */
-int ld_linattn_kmax(const void* qkv, float* kmax_part, int B, int n, int heads, int dim_head,
-                    int nparts, int dtype, void* stream);
-int ld_linattn_ctx(const void* qkv, const float* kmax_part, int nparts, float* ctx_part,
+int ld_linattn_kmax(const void* qkv, uint32_t* kmax_enc, int B, int n, int heads, int dim_head,
+                    int dtype, void* stream);
+int ld_linattn_ctx(const void* qkv, const uint32_t* kmax_enc, float* ctx_part,
                    int B, int n, int heads, int dim_head, int nchunks, int dtype, void* stream);
-int ld_linattn_fold(const float* ctx_part, int nchunks, const float* w_out /*[C,hidden] fp32*/,
+int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* ctxn, int B, int heads,
+                          int dim_head, void* stream);
+int ld_linattn_fold(const float* ctxn, const float* w_out /*[C,hidden] fp32*/,
                     void* w_packed /*[B] packed C x hidden*/, int B, int C, int heads, int dim_head,
                     int dtype, void* stream);
 size_t ld_linattn_ctx_part_floats(int B, int heads, int dim_head, int nchunks);

@@ -15,6 +15,7 @@ ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 EPI_PLAIN, EPI_QKV_LINEAR, EPI_QKV_FULL, EPI_RMS_RES, EPI_RES = 0, 1, 2, 3, 4
 OBJ = {"pred_x0": 0, "pred_noise": 1, "pred_v": 2}
 SCHED_COLS = 8
+STAT_STRIPES = 16      # LD_STAT_STRIPES
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
@@ -34,7 +35,7 @@ class Conv3x3Args(C.Structure):
 class Conv1x1Args(C.Structure):
     _fields_ = [("src", Src * 2), ("nsrc", i32), ("unshuffle", i32), ("rms_in", i32), ("weight", vp),
                 ("weight_bstride", i64), ("bias", vp), ("epilogue", i32), ("hidden", i32),
-                ("q_scale", f32), ("g2", vp), ("residual", vp), ("out", vp), ("B", i32), ("H", i32),
+                ("q_scale", f32), ("g2", vp), ("residual", vp), ("out", vp), ("kmax_out", vp), ("B", i32), ("H", i32),
                 ("W", i32), ("Cout", i32), ("dtype", i32)]
 
 
@@ -63,10 +64,10 @@ _SIGS = {
     "ld_conv_image": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, vp]),
     "ld_gn_apply": (C.c_int, [C.POINTER(GnApplyArgs), vp]),
-    "ld_linattn_kmax": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
-    "ld_linattn_ctx": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 C.c_int, vp]),
-    "ld_linattn_fold": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_linattn_kmax": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_linattn_ctx": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_linattn_ctx_reduce": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_linattn_fold": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_linattn_ctx_part_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ld_attention": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_time_mlp": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),

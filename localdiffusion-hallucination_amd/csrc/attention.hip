@@ -6,8 +6,8 @@
 // = 64 queries of one (batch, head); K/V tiles of 64 keys go through LDS as fp32; wave w scores
 // keys 16w..16w+15 of every tile for all 64 queries (lane = query) with an online softmax
 // (running max m, normaliser l), and the four partial (m, l, o) are merged at the end.
-// Round-1 version: fp32 VALU arithmetic (exact-ish parity path).  The MFMA (bf16 QK^T / PV)
-// version is the planned replacement -- this op is ~2 % of the forward's FLOPs.
+// fp32 storage: VALU arithmetic below (the parity path, exact fp32 products).
+// bf16 storage: attention_mfma_kernel further down (QK^T and PV on v_mfma_f32_16x16x32_bf16).
 #include "common.cuh"
 
 namespace {
@@ -110,6 +110,119 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     }
   }
 }
+
+// ------------------------------------------------------------------ bf16 MFMA flash attention
+// One workgroup = 64 queries (wave w: queries 16w..16w+15) of one (batch, head); key/value tiles of
+// 64 keys stream through LDS.  Orientation chosen so that NOTHING is shuffled between the two
+// products (cdna_hip_programming.md section 3, "an accumulator tile as the next MFMA's operand"):
+//   S^T[j][i] = K Q^T   A = K rows (keys) read as 16-B fragments, B = Q held in registers;
+//                       D: lane = query i (lane&15), regs = keys 4*(lane>>4)+r  -> the softmax row
+//                       state (m, l) of a query lives in ONE lane (replicated over lane>>4);
+//   O^T[d][i] = V^T P^T A = V^T fragments via ds_read_b64_tr_b16 (transposed LDS read of the
+//                       row-major [key][d] tile), B = P^T = the exponentiated S^T registers as they
+//                       stand: k-slot (lane>>4, e) <-> key 4*(lane>>4)+e of tile e<4 ? 0 : 1.
+// LDS: K as [kgrp][key][16 B] planes (conflict-free b128 reads), V as 96-byte rows (64 B data +
+// 32 B pad: the 8 rows a half-wave's transposed read touches land on 8 disjoint bank octets).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr int TKV = 64;
+constexpr int VROW = 96;
+
+__device__ __forceinline__ uint2 tr_read(const char* p) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(const_cast<char*>(p)));
+  return __builtin_bit_cast(uint2, v);
+}
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                             int n, int heads) {
+  __shared__ __attribute__((aligned(16))) uint4 s_k[4][TKV];
+  __shared__ __attribute__((aligned(16))) char s_v[TKV * VROW];
+  const int hidden = heads * D;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kg = lane >> 4;
+  const size_t rowstride = (size_t)3 * hidden;
+  const bf16* base = qkv + (size_t)b * n * rowstride;
+  const int qi = q0 + wv * 16 + li;
+  uint4 qf = make_uint4(0u, 0u, 0u, 0u);
+  if (qi < n) qf = *reinterpret_cast<const uint4*>(base + (size_t)qi * rowstride + h * D + kg * 8);
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+  float m = -1e30f, l = 0.f;
+  const int skey = tid & 63, schunk = tid >> 6;          // staging role: one 16-B chunk of one key
+  const int tq = (lane >> 2) & 3, tp = lane & 3;         // transposed-read role inside the 16-lane group
+  for (int j0 = 0; j0 < n; j0 += TKV) {
+    __syncthreads();
+    {
+      const int j = j0 + skey;
+      uint4 kk = make_uint4(0u, 0u, 0u, 0u), vv = kk;
+      if (j < n) {
+        const bf16* rp = base + (size_t)j * rowstride + h * D + schunk * 8;
+        kk = *reinterpret_cast<const uint4*>(rp + hidden);
+        vv = *reinterpret_cast<const uint4*>(rp + 2 * hidden);
+      }
+      s_k[schunk][skey] = kk;
+      *reinterpret_cast<uint4*>(s_v + skey * VROW + schunk * 16) = vv;
+    }
+    __syncthreads();
+    f32x4 s[4];
+    float mx = -1e30f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const uint4 kf = s_k[kg][kt * 16 + li];
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mma16<bf16>(s[kt], kf, qf);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (j0 + kt * 16 + kg * 4 + r) < n;
+        s[kt][r] = ok ? s[kt][r] : -1e30f;
+        mx = fmaxf(mx, s[kt][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    m = mn;
+    l *= alpha;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    unsigned pk[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (j0 + kt * 16 + kg * 4 + r) < n;
+        pv[r] = ok ? __expf(s[kt][r] - mn) : 0.f;
+        l += pv[r];
+      }
+      pk[kt][0] = pack_bf16x2(pv[0], pv[1]);
+      pk[kt][1] = pack_bf16x2(pv[2], pv[3]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 pf = make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]);
+      const char* vrow = s_v + (ks * 32 + kg * 4 + tq) * VROW + tp * 8;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const uint2 v1 = tr_read(vrow + dt * 32);
+        const uint2 v2 = tr_read(vrow + 16 * VROW + dt * 32);
+        const uint4 vf = make_uint4(v1.x, v1.y, v2.x, v2.y);
+        if (dt == 0) mma16<bf16>(o0, vf, pf);
+        else mma16<bf16>(o1, vf, pf);
+      }
+    }
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (qi < n) {
+    const float inv = 1.0f / l;
+    bf16* op = out + ((size_t)b * n + qi) * hidden + h * D + kg * 4;
+    float r0[4] = {o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv};
+    float r1[4] = {o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
+    store4<bf16>(op, r0);
+    store4<bf16>(op + 16, r1);
+  }
+}
 }  // namespace
 
 extern "C" int ld_attention(const void* qkv, void* out, int B, int n, int heads, int dim_head, int dtype,
@@ -121,7 +234,7 @@ extern "C" int ld_attention(const void* qkv, void* out, int B, int n, int heads,
   if (dtype == LD_F32)
     hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, (float*)out, n, heads);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(attention_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, n, heads);
+    hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, n, heads);
   else
     return ld_fail(LD_EINVAL, "ld_attention: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("attention");

@@ -152,17 +152,24 @@ static inline SrcDev to_dev(const ld_src& s) {
 //   a = rstd*gamma*(scale+1),  s = (beta - mean*rstd*gamma)*(scale+1) + shift
 // (GroupNorm eps 1e-5, biased variance: ddpm.py:174 / unet_model.py:21; FiLM: ddpm.py:181-183).
 // npix = pixels the statistics were accumulated over (the producer's H*W).
+// `red` is LDS scratch for 2*groups doubles.  Contains two __syncthreads(): call from all threads.
 __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, long npix, float* coef,
-                                              int tid, int nthreads) {
-  const int C = S.C, gs = C / S.groups;
+                                              double* red, int tid, int nthreads) {
+  const int C = S.C, G = S.groups, gs = C / G;
+  if (tid < 2 * G) {                       // sum the stripes: entry (g, k) with tid = 2g + k
+    const double* p = S.stats + (size_t)b * LD_STAT_STRIPES * G * 2 + tid;
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < LD_STAT_STRIPES; ++s) acc += p[(size_t)s * G * 2];
+    red[tid] = acc;
+  }
+  __syncthreads();
   const double inv_n = 1.0 / ((double)npix * gs);
   const float* film = S.film ? S.film + (long)trow * S.film_tstride + (long)b * S.film_bstride : nullptr;
   for (int c = tid; c < C; c += nthreads) {
     const int g = c / gs;
-    const double sum = S.stats[((long)b * S.groups + g) * 2 + 0];
-    const double sq = S.stats[((long)b * S.groups + g) * 2 + 1];
-    const double mean = sum * inv_n;
-    double var = sq * inv_n - mean * mean;
+    const double mean = red[2 * g] * inv_n;
+    double var = red[2 * g + 1] * inv_n - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + 1e-5));
     float a = rstd * S.gamma[c];
@@ -175,15 +182,40 @@ __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, 
     coef[c] = a;
     coef[C + c] = s;
   }
+  __syncthreads();
 }
 
+// DPP row rotate inside each 16-lane row (one VALU op, no LDS crossbar): dpp_ctrl 0x120+n = row_ror:n
+template <int N> __device__ __forceinline__ float row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave16_sum(float v) {
-  // sum over the 16 lanes that share (lane >> 4); xor masks < 16 stay inside the group
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  // sum over the 16 lanes that share (lane >> 4); every lane of the row ends with the total
+  v += row_ror<8>(v); v += row_ror<4>(v); v += row_ror<2>(v); v += row_ror<1>(v);
   return v;
 }
 
 __device__ __forceinline__ double wave16_sum_d(double v) {
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
   return v;
+}
+
+// Order-preserving float <-> uint32 map for integer atomicMax on floats; 0 (a memset buffer) is the
+// identity of max.  enc is monotone: a < b  <=>  enc(a) < enc(b).
+__device__ __forceinline__ unsigned enc_max(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_max(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ float wave16_max(float v) {
+  v = fmaxf(v, row_ror<8>(v)); v = fmaxf(v, row_ror<4>(v)); v = fmaxf(v, row_ror<2>(v)); v = fmaxf(v, row_ror<1>(v));
+  return v;
+}
+// atomicMax that skips the atomic when a (possibly stale) plain load already shows a larger value:
+// after the first few workgroups almost every call is a load only, so same-address contention vanishes.
+__device__ __forceinline__ void atomic_max_enc(unsigned* p, float v) {
+  const unsigned e = enc_max(v);
+  if (*reinterpret_cast<volatile unsigned*>(p) < e) atomicMax(p, e);
 }

@@ -28,6 +28,7 @@ struct Conv1Dev {
   const float* g2;
   const void* res;
   void* out;
+  unsigned* kmax;
   int B, H, W, Cout;
 };
 
@@ -132,6 +133,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   T* out = reinterpret_cast<T*>(a.out);
   const T* res = reinterpret_cast<const T*>(a.res);
   const bool q_part = (m0 * 16) < a.hidden;
+  const bool k_part = a.kmax != nullptr && (m0 * 16) >= a.hidden && (m0 * 16) < 2 * a.hidden;
+  float cmax[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cmax[m][r] = -INFINITY;
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     const int qq = (wv * NW + j) * 16 + px;
@@ -157,7 +164,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[m][r] = expf(v[m][r] - mx); v[m + 1][r] = expf(v[m + 1][r] - mx);
+          v[m][r] = DT<T>::precise ? expf(v[m][r] - mx) : __expf(v[m][r] - mx);
+          v[m + 1][r] = DT<T>::precise ? expf(v[m + 1][r] - mx) : __expf(v[m + 1][r] - mx);
           sum += v[m][r] + v[m + 1][r];
         }
         sum += __shfl_xor(sum, 16);
@@ -187,6 +195,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
         for (int r = 0; r < 4; ++r) v[m][r] = v[m][r] * inv * a.g2[co + r];
       }
     }
+    if (k_part && valid) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cmax[m][r] = fmaxf(cmax[m][r], v[m][r]);
+    }
     if (valid) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -200,6 +214,27 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
         }
         store4<T>(out + o, v[m]);
       }
+    }
+  }
+  if (k_part) {
+    // softmax_n(k) needs max_n k per (batch, channel) (ddpm.py:243): row-reduce over the 16 pixel
+    // lanes (DPP), combine the 4 waves through LDS, then ONE 64-lane integer
+    // atomicMax per workgroup into its stripe of the [B, stripes, hidden] buffer.
+    float* s_cm = reinterpret_cast<float*>(s_x);          // the staging tile is dead after the K loop
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float cm = wave16_max(cmax[m][r]);
+        if (px == 0) s_cm[wv * 16 * MT + m * 16 + kq * 4 + r] = cm;
+      }
+    __syncthreads();
+    if (tid < 16 * MT) {
+      const float cm = fmaxf(fmaxf(s_cm[tid], s_cm[16 * MT + tid]), fmaxf(s_cm[32 * MT + tid], s_cm[48 * MT + tid]));
+      const int stripe = blockIdx.x % LD_STAT_STRIPES;    // spread same-address atomics (see LD_STAT_STRIPES)
+      if (cm > -INFINITY)
+        atomicMax(a.kmax + ((size_t)b * LD_STAT_STRIPES + stripe) * a.hidden + m0 * 16 + tid - a.hidden, enc_max(cm));
     }
   }
 }
@@ -262,6 +297,7 @@ extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
   a.epi = p->epilogue;
   a.hidden = (p->epilogue == LD_EPI_QKV_LINEAR || p->epilogue == LD_EPI_QKV_FULL) ? p->hidden : 0;
   a.q_scale = p->q_scale; a.g2 = p->g2; a.res = p->residual; a.out = p->out;
+  a.kmax = (p->epilogue == LD_EPI_QKV_LINEAR) ? p->kmax_out : nullptr;
   a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == LD_F32 ? dispatch<float>(a, st) : dispatch<bf16>(a, st);

@@ -49,9 +49,10 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   char* s_w = smem + 4 * PLANE;
   float* s_coef = reinterpret_cast<float*>(s_w + 9 * MT * 1024);
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
-  // [2][16*MT] fp64: per-lane fp32 partials (<= NW values) are widened before any cross-lane sum, so the
-  // E[x^2]-mean^2 cancellation never sees fp32 partial-sum rounding and the result is order-independent
-  double* s_stat = reinterpret_cast<double*>(s_coef + 2 * ctot + ((2 * ctot) & 1));
+  // fp64 scratch: [4 waves][2][16*MT] per-wave channel sums (also the stripe-reduction scratch of
+  // build_gn_coef, 32 doubles).  Per-lane/per-wave partials are fp32 over <= 16*NW values; every
+  // sum across waves and workgroups is fp64, so E[x^2]-mean^2 does not see fp32 partial-sum rounding.
+  double* s_stat = reinterpret_cast<double*>(s_coef + 2 * ctot);
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
   const int b = blockIdx.z, m0 = blockIdx.y * MT;
@@ -63,14 +64,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   {
     int off = 0;
     for (int s = 0; s < a.nsrc; ++s) {
-      const SrcDev& S = a.s[s];
+      const SrcDev S = s ? a.s[1] : a.s[0];
       if (S.stats) {
         const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
-        build_gn_coef(S, b, trow, npix, s_coef + off, tid, 256);
+        build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, tid, 256);
       }
       off += 2 * S.C;
     }
-    if (tid < 32 * MT) s_stat[tid] = 0.0;
   }
 
   f32x4 acc[MT][NW];
@@ -186,25 +186,28 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
     }
   }
   if (a.ostats) {
+    __syncthreads();                            // s_stat may still be read as build_gn_coef scratch
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double s1 = wave16_sum_d((double)ssum[m][r]), s2 = wave16_sum_d((double)ssq[m][r]);
+        const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
         if (px == 0) {
-          atomicAdd(&s_stat[m * 16 + kq * 4 + r], s1);
-          atomicAdd(&s_stat[16 * MT + m * 16 + kq * 4 + r], s2);
+          s_stat[(wv * 2 + 0) * 16 * MT + m * 16 + kq * 4 + r] = (double)s1;
+          s_stat[(wv * 2 + 1) * 16 * MT + m * 16 + kq * 4 + r] = (double)s2;
         }
       }
     __syncthreads();
     const int gs = a.Cout / a.ogroups;          // channels per group; gs <= 16*MT by construction
     const int ngrp_blk = (16 * MT) / gs;
-    if (tid < ngrp_blk) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int c = 0; c < gs; ++c) { s1 += s_stat[tid * gs + c]; s2 += s_stat[16 * MT + tid * gs + c]; }
-      const int g = (m0 * 16) / gs + tid;
-      atomicAdd(&a.ostats[((size_t)b * a.ogroups + g) * 2 + 0], s1);
-      atomicAdd(&a.ostats[((size_t)b * a.ogroups + g) * 2 + 1], s2);
+    if (tid < 2 * ngrp_blk) {
+      const int gi = tid >> 1, k = tid & 1;
+      double acc1 = 0.0;
+      for (int w4 = 0; w4 < 4; ++w4)
+        for (int c = 0; c < gs; ++c) acc1 += s_stat[(w4 * 2 + k) * 16 * MT + gi * gs + c];
+      const int g = (m0 * 16) / gs + gi;
+      const int stripe = blockIdx.x % LD_STAT_STRIPES;
+      atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + g) * 2 + k], acc1);
     }
   }
 }
@@ -214,7 +217,7 @@ int launch(const Conv3Dev& a, hipStream_t st) {
   constexpr int TR = 4 * NW, HR = TR + 2, HC = 18;
   constexpr int NPIXP = (HR * HC + 15) / 16 * 16;
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
-  const size_t lds = 4 * NPIXP * 16 + 9 * MT * 1024 + (2 * ctot + 2) * sizeof(float) + 2 * 16 * MT * sizeof(double);
+  const size_t lds = 4 * NPIXP * 16 + 9 * MT * 1024 + 2 * ctot * sizeof(float) + 4 * 2 * 16 * MT * sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
     LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW>, lds));

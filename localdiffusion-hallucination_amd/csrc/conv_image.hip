@@ -74,8 +74,9 @@ __global__ __launch_bounds__(256) void conv_image_kernel(const float* __restrict
     if (tid < ogroups) {
       double s1 = 0.0, s2 = 0.0;
       for (int c = 0; c < gs; ++c) { s1 += s_red[tid * gs + c]; s2 += s_red[CO + tid * gs + c]; }
-      atomicAdd(&ostats[((size_t)b * ogroups + tid) * 2 + 0], s1);
-      atomicAdd(&ostats[((size_t)b * ogroups + tid) * 2 + 1], s2);
+      const int stripe = blockIdx.x % LD_STAT_STRIPES;
+      atomicAdd(&ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * ogroups + tid) * 2 + 0], s1);
+      atomicAdd(&ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * ogroups + tid) * 2 + 1], s2);
     }
   }
 }

@@ -51,9 +51,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnDev g) {
   const int C = g.a.C, b = blockIdx.y, tid = threadIdx.x;
   const int trow = g.t_ptr ? *g.t_ptr : 0;
   const long npix_in = (long)g.H * g.W;
-  build_gn_coef(g.a, b, trow, npix_in, s_coef, tid, 256);
-  if (g.has_b && g.b.stats) build_gn_coef(g.b, b, trow, npix_in, s_coef + 2 * C, tid, 256);
-  __syncthreads();
+  double* red = reinterpret_cast<double*>(s_coef + 4 * C);
+  build_gn_coef(g.a, b, trow, npix_in, s_coef, red, tid, 256);
+  if (g.has_b && g.b.stats) build_gn_coef(g.b, b, trow, npix_in, s_coef + 2 * C, red, tid, 256);
   const int fpp = C / E;                               // fragments per pixel
   const int Ho = g.pool ? g.H / 2 : g.H, Wo = g.pool ? g.W / 2 : g.W;
   const long nfrag = (long)Ho * Wo * fpp;
@@ -89,7 +89,7 @@ int run(const GnDev& g, hipStream_t st) {
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks, g.B);
-  const size_t lds = 4 * g.a.C * sizeof(float);
+  const size_t lds = 4 * g.a.C * sizeof(float) + 64 * sizeof(double);
   hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(256), lds, st, g);
   LD_LAUNCH_CHECK("gn_apply");
   return LD_OK;

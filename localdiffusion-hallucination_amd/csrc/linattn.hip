@@ -19,7 +19,7 @@ namespace {
 
 // ------------------------------------------------------------------ per-channel max of k over n
 template <typename T>
-__global__ __launch_bounds__(256) void kmax_kernel(const T* __restrict__ qkv, float* __restrict__ part, int n,
+__global__ __launch_bounds__(256) void kmax_kernel(const T* __restrict__ qkv, unsigned* __restrict__ kmax_enc, int n,
                                                    int hidden, int nparts) {
   constexpr int E = DT<T>::E;
   extern __shared__ float s_max[];                      // [rows][hidden]
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void kmax_kernel(const T* __restrict__ qkv, fl
   for (int c = tid; c < hidden; c += 256) {
     float m = -INFINITY;
     for (int r = 0; r < rows; ++r) m = fmaxf(m, s_max[r * hidden + c]);
-    part[((size_t)b * nparts + pt) * hidden + c] = m;
+    if (m > -INFINITY) atomicMax(kmax_enc + ((size_t)b * LD_STAT_STRIPES + pt % LD_STAT_STRIPES) * hidden + c, enc_max(m));
   }
 }
 
@@ -55,15 +55,17 @@ __global__ __launch_bounds__(256) void kmax_kernel(const T* __restrict__ qkv, fl
 constexpr int CTX_STRIDE = 32 * 32 + 32;   // floats per (b, h, chunk): ctx[d][e] then Z[d]
 
 template <typename T>
-__global__ __launch_bounds__(256) void ctx_kernel(const T* __restrict__ qkv, const float* __restrict__ kmax_part,
-                                                  int nparts, float* __restrict__ ctx_part, int n, int heads,
-                                                  int nchunks) {
+__global__ __launch_bounds__(256) void ctx_kernel(const T* __restrict__ qkv, const unsigned* __restrict__ kmax_enc,
+                                                  float* __restrict__ ctx_part, int n, int heads, int nchunks) {
   __shared__ float s_red[4][CTX_STRIDE];
   const int hidden = heads * 32;
   const int ck = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, half = lane >> 5;
-  float km = -INFINITY;
-  for (int p = 0; p < nparts; ++p) km = fmaxf(km, kmax_part[((size_t)b * nparts + p) * hidden + h * 32 + r]);
+  unsigned kme = 0u;
+#pragma unroll
+  for (int sp = 0; sp < LD_STAT_STRIPES; ++sp)
+    kme = max(kme, kmax_enc[((size_t)b * LD_STAT_STRIPES + sp) * hidden + h * 32 + r]);
+  const float km = dec_max(kme);
   const int npc = (n + nchunks - 1) / nchunks;           // pixels per chunk
   const int lo = ck * npc, hi = min(n, lo + npc);
   const int npw = (hi - lo + 3) / 4;                     // pixels per wave
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void ctx_kernel(const T* __restrict__ qkv, con
       const bool ok = p < whi;
       const size_t off = (size_t)(ok ? p : wlo) * 3 * hidden;
       const float kk = to_f<T>(kbase[off]), vv = to_f<T>(vbase[off]);
-      av[u] = ok ? expf(kk - km) : 0.f;
+      av[u] = ok ? (DT<T>::precise ? expf(kk - km) : __expf(kk - km)) : 0.f;
       bv[u] = ok ? vv : 0.f;
     }
 #pragma unroll
@@ -105,39 +107,136 @@ __global__ __launch_bounds__(256) void ctx_kernel(const T* __restrict__ qkv, con
   for (int i = tid; i < CTX_STRIDE; i += 256) dst[i] = s_red[0][i] + s_red[1][i] + s_red[2][i] + s_red[3][i];
 }
 
-// ------------------------------------------------------------------ fold ctx into per-batch 1x1 weights
-// grid = (C/16 channel tiles, B): every workgroup reduces the chunk partials of ctx (L2-resident,
-// heads*1056 floats per chunk) into LDS, then produces one 16-row tile of M_b.
-template <typename T>
-__global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctx_part, int nchunks,
-                                                   const float* __restrict__ w_out, T* __restrict__ w_packed,
-                                                   int C, int heads) {
-  constexpr int E = DT<T>::E, CK = DT<T>::CK;
-  extern __shared__ float s_ctx[];                       // [heads][32][32] normalised, then [heads][32] Z
-  const int hidden = heads * 32, b = blockIdx.y, mt = blockIdx.x, tid = threadIdx.x;
-  float* s_z = s_ctx + heads * 1024;
-  for (int i = tid; i < heads * 32; i += 256) {
-    const int h = i / 32, d = i - h * 32;
-    float z = 0.f;
-    for (int c = 0; c < nchunks; ++c) z += ctx_part[(((size_t)b * heads + h) * nchunks + c) * CTX_STRIDE + 1024 + d];
-    s_z[i] = z;
+// ------------------------------------------------------------------ ctx partials, bf16 MFMA
+// bf16 storage: ctx = P^T V with the contraction over pixels on v_mfma_f32_16x16x32_bf16.  Both
+// operands have their K index (the pixel) on the strided axis of the row-major [pixel][32 ch] LDS
+// tiles, so both fragments come from ds_read_b64_tr_b16 (transposed LDS read; rows padded to 96 B
+// so the 8 rows a half-wave touches hit disjoint bank octets).  Wave w owns the 16x16 tile
+// (d-tile w>>1, e-tile w&1) of the 32x32 context.  P = exp(k - max) is formed while staging
+// (16-B loads, 8 channels per lane), its column sums Z come from the same registers.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr int TN = 256;          // pixels per LDS tile
+constexpr int CROW = 96;         // bytes per LDS row (64 data + 32 pad)
+
+__device__ __forceinline__ uint2 tr_read8(const char* p) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(const_cast<char*>(p)));
+  return __builtin_bit_cast(uint2, v);
+}
+
+__global__ __launch_bounds__(256) void ctx_mfma_kernel(const bf16* __restrict__ qkv, const unsigned* __restrict__ kmax_enc,
+                                                       float* __restrict__ ctx_part, int n, int heads, int nchunks) {
+  __shared__ __attribute__((aligned(16))) char s_p[TN * CROW];
+  __shared__ __attribute__((aligned(16))) char s_v[TN * CROW];
+  const int hidden = heads * 32;
+  const int ck = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kg = lane >> 4;
+  const int c8 = tid & 3, prow = tid >> 2;               // staging role: 8 channels of pixel prow (+64*it)
+  float km[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    unsigned kme = 0u;
+#pragma unroll
+    for (int sp = 0; sp < LD_STAT_STRIPES; ++sp)
+      kme = max(kme, kmax_enc[((size_t)b * LD_STAT_STRIPES + sp) * hidden + h * 32 + c8 * 8 + e]);
+    km[e] = dec_max(kme);
   }
+  float z[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = 0.f;
+  const int npc = (n + nchunks - 1) / nchunks;
+  const int lo = ck * npc, hi = min(n, lo + npc);
+  const bf16* kbase = qkv + (size_t)b * n * 3 * hidden + hidden + h * 32 + c8 * 8;
+  const int dt = wv >> 1, et = wv & 1;
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int p0 = lo; p0 < hi; p0 += TN) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < TN / 64; ++it) {
+      const int r = prow + 64 * it, p = p0 + r;
+      uint4 pk = make_uint4(0u, 0u, 0u, 0u), vv = pk;
+      if (p < hi) {
+        const bf16* rp = kbase + (size_t)p * 3 * hidden;
+        const uint4 kk = *reinterpret_cast<const uint4*>(rp);
+        vv = *reinterpret_cast<const uint4*>(rp + hidden);
+        float f[8];
+        unpack16<bf16>(kk, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { f[e] = __expf(f[e] - km[e]); z[e] += f[e]; }
+        pk = pack16<bf16>(f);
+      }
+      *reinterpret_cast<uint4*>(s_p + r * CROW + c8 * 16) = pk;
+      *reinterpret_cast<uint4*>(s_v + r * CROW + c8 * 16) = vv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < TN / 32; ++ks) {
+      const int row = ks * 32 + kg * 4 + tq;
+      const char* pa = s_p + row * CROW + dt * 32 + tp * 8;
+      const char* pb = s_v + row * CROW + et * 32 + tp * 8;
+      const uint2 a1 = tr_read8(pa), a2 = tr_read8(pa + 16 * CROW);
+      const uint2 b1 = tr_read8(pb), b2 = tr_read8(pb + 16 * CROW);
+      mma16<bf16>(acc, make_uint4(a1.x, a1.y, a2.x, a2.y), make_uint4(b1.x, b1.y, b2.x, b2.y));
+    }
+  }
+  float* dst = ctx_part + (((size_t)b * heads + h) * nchunks + ck) * CTX_STRIDE;
+  // D: row d = dt*16 + 4*kg + r, col e = et*16 + li
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dst[(dt * 16 + kg * 4 + r) * 32 + et * 16 + li] = acc[r];
+  // Z[d]: deterministic tree over the 64 threads that share c8
   __syncthreads();
-  for (int i = tid; i < heads * 1024; i += 256) {
-    const int h = i / 1024, de = i - h * 1024;
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += ctx_part[(((size_t)b * heads + h) * nchunks + c) * CTX_STRIDE + de];
-    s_ctx[i] = s / s_z[h * 32 + (de >> 5)];
+  float* s_z = reinterpret_cast<float*>(s_p);            // [256][8]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s_z[tid * 8 + e] = z[e];
+  __syncthreads();
+  if (tid < 32) {
+    const int cc = tid >> 3, e = tid & 7;                 // channel = cc*8 + e
+    float t = 0.f;
+    for (int k = 0; k < 64; ++k) t += s_z[(k * 4 + cc) * 8 + e];
+    dst[1024 + tid] = t;
   }
+}
+
+// ------------------------------------------------------------------ reduce the chunk partials
+// grid = (heads, B, 4): ctxn[b,h,d,e] = sum_chunks ctx / sum_chunks Z[d]   (the k-softmax normaliser)
+__global__ __launch_bounds__(256) void ctx_reduce_kernel(const float* __restrict__ ctx_part, int nchunks,
+                                                         float* __restrict__ ctxn, int heads) {
+  __shared__ float s_z[8];
+  const int h = blockIdx.x, b = blockIdx.y, quarter = blockIdx.z, tid = threadIdx.x;
+  const float* src = ctx_part + ((size_t)b * heads + h) * nchunks * CTX_STRIDE;
+  const int i = quarter * 256 + tid;                     // element d*32+e; this block covers d = 8*quarter..+7
+  if (tid < 8) {
+    float z = 0.f;
+    for (int c = 0; c < nchunks; ++c) z += src[(size_t)c * CTX_STRIDE + 1024 + quarter * 8 + tid];
+    s_z[tid] = z;
+  }
+  float s = 0.f;
+#pragma unroll 8
+  for (int c = 0; c < nchunks; ++c) s += src[(size_t)c * CTX_STRIDE + i];
+  __syncthreads();
+  ctxn[((size_t)b * heads + h) * 1024 + i] = s / s_z[tid >> 5];
+}
+
+// ------------------------------------------------------------------ fold ctx into per-batch 1x1 weights
+// grid = (C/16 channel tiles, B): M_b[c, h*32+d] = sum_e Wout[c, h*32+e] * ctxn[b,h,d,e], written in
+// the packed fragment order ld_conv1x1 reads (k=1 layout of pack.hip).
+template <typename T>
+__global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctxn, const float* __restrict__ w_out,
+                                                   T* __restrict__ w_packed, int C, int heads) {
+  constexpr int E = DT<T>::E, CK = DT<T>::CK;
+  extern __shared__ float s_ctx[];                       // [heads][32][33] (padded: conflict-free rows)
+  const int hidden = heads * 32, b = blockIdx.y, mt = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < heads * 1024; i += 256) s_ctx[(i >> 5) * 33 + (i & 31)] = ctxn[(size_t)b * heads * 1024 + i];
   __syncthreads();
   const int mt_total = C / 16;
   T* dst = w_packed + (size_t)b * C * hidden;
   for (int i = tid; i < 16 * hidden; i += 256) {
     const int ii = i / hidden, ci = i - ii * hidden;     // ci = h*32 + d
     const int co = mt * 16 + ii;
-    const int h = ci >> 5, d = ci & 31;
+    const int h = ci >> 5;
     const float* wrow = w_out + (size_t)co * hidden + h * 32;
-    const float* crow = s_ctx + h * 1024 + d * 32;
+    const float* crow = s_ctx + ci * 33;
     float m = 0.f;
 #pragma unroll 8
     for (int e = 0; e < 32; ++e) m = fmaf(wrow[e], crow[e], m);
@@ -153,22 +252,23 @@ extern "C" size_t ld_linattn_ctx_part_floats(int B, int heads, int dim_head, int
   return (size_t)B * heads * nchunks * CTX_STRIDE;
 }
 
-extern "C" int ld_linattn_kmax(const void* qkv, float* kmax_part, int B, int n, int heads, int dim_head,
-                               int nparts, int dtype, void* stream) {
-  LD_REQUIRE(qkv && kmax_part && B > 0 && n > 0 && nparts > 0, "ld_linattn_kmax: bad args");
+extern "C" int ld_linattn_kmax(const void* qkv, uint32_t* kmax_enc, int B, int n, int heads, int dim_head,
+                               int dtype, void* stream) {
+  LD_REQUIRE(qkv && kmax_enc && B > 0 && n > 0, "ld_linattn_kmax: bad args");
   LD_REQUIRE(dim_head == 32, "ld_linattn_*: dim_head must be 32 (got %d)", dim_head);
   const int hidden = heads * dim_head;
+  const int nparts = n >= 16384 ? 64 : (n >= 256 ? n / 256 : 1);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(nparts, B);
   if (dtype == LD_F32) {
     const int rows = 256 / (hidden / 4);
     LD_REQUIRE(rows >= 1, "ld_linattn_kmax: hidden %d too large", hidden);
     hipLaunchKernelGGL(kmax_kernel<float>, grid, dim3(256), rows * hidden * sizeof(float), st,
-                       (const float*)qkv, kmax_part, n, hidden, nparts);
+                       (const float*)qkv, kmax_enc, n, hidden, nparts);
   } else if (dtype == LD_BF16) {
     const int rows = 256 / (hidden / 8);
     hipLaunchKernelGGL(kmax_kernel<bf16>, grid, dim3(256), rows * hidden * sizeof(float), st,
-                       (const bf16*)qkv, kmax_part, n, hidden, nparts);
+                       (const bf16*)qkv, kmax_enc, n, hidden, nparts);
   } else {
     return ld_fail(LD_EINVAL, "ld_linattn_kmax: bad dtype %d", dtype);
   }
@@ -176,32 +276,42 @@ extern "C" int ld_linattn_kmax(const void* qkv, float* kmax_part, int B, int n, 
   return LD_OK;
 }
 
-extern "C" int ld_linattn_ctx(const void* qkv, const float* kmax_part, int nparts, float* ctx_part, int B,
+extern "C" int ld_linattn_ctx(const void* qkv, const uint32_t* kmax_enc, float* ctx_part, int B,
                               int n, int heads, int dim_head, int nchunks, int dtype, void* stream) {
-  LD_REQUIRE(qkv && kmax_part && ctx_part && B > 0 && n > 0 && nchunks > 0, "ld_linattn_ctx: bad args");
+  LD_REQUIRE(qkv && kmax_enc && ctx_part && B > 0 && n > 0 && nchunks > 0, "ld_linattn_ctx: bad args");
   LD_REQUIRE(dim_head == 32, "ld_linattn_*: dim_head must be 32 (got %d)", dim_head);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(nchunks, heads, B);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(ctx_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, kmax_part, nparts, ctx_part, n, heads, nchunks);
+    hipLaunchKernelGGL(ctx_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, kmax_enc, ctx_part, n, heads, nchunks);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(ctx_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)qkv, kmax_part, nparts, ctx_part, n, heads, nchunks);
+    hipLaunchKernelGGL(ctx_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, kmax_enc, ctx_part, n, heads, nchunks);
   else
     return ld_fail(LD_EINVAL, "ld_linattn_ctx: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("linattn_ctx");
   return LD_OK;
 }
 
-extern "C" int ld_linattn_fold(const float* ctx_part, int nchunks, const float* w_out, void* w_packed, int B,
-                               int C, int heads, int dim_head, int dtype, void* stream) {
-  LD_REQUIRE(ctx_part && w_out && w_packed && B > 0 && nchunks > 0, "ld_linattn_fold: bad args");
+extern "C" int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* ctxn, int B, int heads,
+                                     int dim_head, void* stream) {
+  LD_REQUIRE(ctx_part && ctxn && B > 0 && nchunks > 0 && heads > 0, "ld_linattn_ctx_reduce: bad args");
+  LD_REQUIRE(dim_head == 32, "ld_linattn_*: dim_head must be 32 (got %d)", dim_head);
+  hipLaunchKernelGGL(ctx_reduce_kernel, dim3(heads, B, 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     ctx_part, nchunks, ctxn, heads);
+  LD_LAUNCH_CHECK("linattn_ctx_reduce");
+  return LD_OK;
+}
+
+extern "C" int ld_linattn_fold(const float* ctxn, const float* w_out, void* w_packed, int B, int C, int heads,
+                               int dim_head, int dtype, void* stream) {
+  LD_REQUIRE(ctxn && w_out && w_packed && B > 0, "ld_linattn_fold: bad args");
   LD_REQUIRE(dim_head == 32 && C % 16 == 0, "ld_linattn_fold: dim_head 32, C %% 16 == 0");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const size_t lds = (size_t)heads * (1024 + 32) * sizeof(float);
+  const size_t lds = (size_t)heads * 32 * 33 * sizeof(float);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(fold_kernel<float>, dim3(C / 16, B), dim3(256), lds, st, ctx_part, nchunks, w_out, (float*)w_packed, C, heads);
+    hipLaunchKernelGGL(fold_kernel<float>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (float*)w_packed, C, heads);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(fold_kernel<bf16>, dim3(C / 16, B), dim3(256), lds, st, ctx_part, nchunks, w_out, (bf16*)w_packed, C, heads);
+    hipLaunchKernelGGL(fold_kernel<bf16>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (bf16*)w_packed, C, heads);
   else
     return ld_fail(LD_EINVAL, "ld_linattn_fold: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("linattn_fold");

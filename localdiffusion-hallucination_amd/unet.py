@@ -223,8 +223,10 @@ class _Plan:
         self.meta = {}                             # index in ops_main -> {what, family, bytes, flops}
         self.ops_time, self.ops_cond, self.ops_main = [], [], []
         self.nslot = 0
-        self.stats = torch.zeros(160, B, 16, 2, dtype=torch.float64, device=self.dev)
+        self.stats = torch.zeros(160, B, cabi.STAT_STRIPES, 16, 2, dtype=torch.float64, device=self.dev)
         self.cond_slots = 16                       # slots [0,16) belong to the conditioning encoder
+        self.kmax_arena = torch.zeros(8, B, cabi.STAT_STRIPES, cfg.hidden, dtype=torch.int32, device=self.dev)   # zeroed per forward
+        self._kmax_cursor = 0
         self.x_in = torch.zeros(B, cfg.channels, H, W, dtype=torch.float32, device=self.dev)
         self.cond_in = torch.zeros(B, cfg.cond_in_channels, H, W, dtype=torch.float32, device=self.dev)
         self.model_out = torch.zeros(B, cfg.out_dim, H, W, dtype=torch.float32, device=self.dev)
@@ -310,7 +312,7 @@ class _Plan:
         return out
 
     def conv1(self, ops, srcs, weight, cout, h, w, bias=None, epi=cabi.EPI_PLAIN, unshuffle=0, rms_in=0,
-              bstride=0, g2=None, residual=None, what="conv1x1", out=None):
+              bstride=0, g2=None, residual=None, what="conv1x1", out=None, kmax_out=None):
         a = cabi.Conv1x1Args()
         for i, s in enumerate(srcs):
             a.src[i] = s
@@ -319,6 +321,7 @@ class _Plan:
         a.bias = cabi.ptr(bias)
         a.epilogue, a.hidden, a.q_scale = epi, self.cfg.hidden, self.cfg.attn_dim_head ** -0.5
         a.g2, a.residual = cabi.ptr(g2), cabi.ptr(residual)
+        a.kmax_out = cabi.ptr(kmax_out)
         out = self.buf(h, w, cout) if out is None else out
         a.out = out.data_ptr()
         a.B, a.H, a.W, a.Cout, a.dtype = self.B, h, w, cout, self.dt
@@ -395,25 +398,25 @@ class _Plan:
         """ddpm.py:214-251 (+ residual of the caller, :425/:444)."""
         f, cfg, lib = self.f32, self.cfg, self.lib
         n, hid, B = h * w, cfg.hidden, self.B
+        kmax = self.kmax_arena[self._kmax_cursor]
+        self._kmax_cursor += 1
         qkv = self.conv1(ops, [self.src(x, c)], self.P["w"][p + ".to_qkv.weight"], 3 * hid, h, w,
-                         epi=cabi.EPI_QKV_LINEAR, rms_in=1, what="to_qkv " + p)
-        nparts = max(1, min(64, n // 256))
-        nchunks = max(1, min(32, n // 2048))
-        kmax = torch.empty(B, nparts, hid, dtype=torch.float32, device=self.dev)
+                         epi=cabi.EPI_QKV_LINEAR, rms_in=1, what="to_qkv " + p, kmax_out=kmax)
+        nchunks = max(1, min(32, n // 256))       # >= 64 pixels per wave, enough workgroups at small n
+        ctxn = torch.empty(B, cfg.attn_heads, 32, 32, dtype=torch.float32, device=self.dev)
         ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, cfg.attn_heads, 32, nchunks)),
                           dtype=torch.float32, device=self.dev)
         wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)
         wout = f[p + ".to_out.0.weight"].reshape(c, hid).contiguous()
-        self.keep += [kmax, ctx, wfold, wout, qkv]
+        self.keep += [kmax, ctx, ctxn, wfold, wout, qkv]
         dt, heads = self.dt, cfg.attn_heads
         es = self.esize
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_kmax(qkv.data_ptr(), kmax.data_ptr(), B, n, heads, 32,
-                                                                 nparts, dt, st), "linattn_kmax"),
-                  "linattn_kmax", nbytes=B * n * hid * es)
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), nparts, ctx.data_ptr(),
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), ctx.data_ptr(),
                                                                 B, n, heads, 32, nchunks, dt, st), "linattn_ctx"),
                   "linattn_ctx", nbytes=2 * B * n * hid * es, flops=2 * B * n * hid * 32)
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_fold(ctx.data_ptr(), nchunks, wout.data_ptr(),
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, heads,
+                                                                       32, st), "linattn_ctx_reduce"), "linattn_ctx_reduce")
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(),
                                                                  wfold.data_ptr(), B, c, heads, 32, dt, st), "linattn_fold"),
                   "linattn_fold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
         q = self.src(qkv, hid, stride=3 * hid)
@@ -554,6 +557,7 @@ class _Plan:
     def run_main(self, st):
         s = self.stats[self.cond_slots:]
         cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
+        cabi.check(self.lib.ld_memset_zero(self.kmax_arena.data_ptr(), self.kmax_arena.numel() * 4, st), "memset")
         for op in self.ops_main:
             op(st)
 
@@ -563,6 +567,7 @@ class _Plan:
         lib = self.lib
         s = self.stats[self.cond_slots:]
         cabi.check(lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
+        cabi.check(lib.ld_memset_zero(self.kmax_arena.data_ptr(), self.kmax_arena.numel() * 4, st), "memset")
         if not hasattr(self, "_events"):
             self._events = []
             for _ in range(len(self.ops_main) + 1):

@@ -75,7 +75,7 @@ def conv3x3(srcs, wpacked, bias, B, H, W, cout, dtype, stats=None, groups=8, t_p
 
 
 def conv1x1(srcs, wpacked, B, H, W, cout, dtype, bias=None, epi=0, unshuffle=0, rms_in=0, bstride=0, g2=None,
-            residual=None, hidden=128):
+            residual=None, hidden=128, kmax_out=None):
     a = cabi.Conv1x1Args()
     for i, s in enumerate(srcs):
         a.src[i] = s
@@ -83,6 +83,7 @@ def conv1x1(srcs, wpacked, B, H, W, cout, dtype, bias=None, epi=0, unshuffle=0, 
     a.weight, a.weight_bstride, a.bias = wpacked.data_ptr(), bstride, cabi.ptr(bias)
     a.epilogue, a.hidden, a.q_scale = epi, hidden, 32 ** -0.5
     a.g2, a.residual = cabi.ptr(g2), cabi.ptr(residual)
+    a.kmax_out = cabi.ptr(kmax_out)
     out = torch.empty(B, H, W, cout, dtype=TDT[dtype], device=DEV)
     a.out = out.data_ptr()
     a.B, a.H, a.W, a.Cout, a.dtype = B, H, W, cout, cabi.dtype_code(dtype)
@@ -95,3 +96,26 @@ def gn_stats_ref(y, groups):
     B, Cc = y.shape[:2]
     g = y.double().reshape(B, groups, -1)
     return torch.stack([g.sum(-1), (g * g).sum(-1)], dim=-1)
+
+
+def stats_buffer(B, groups):
+    """Zeroed device statistics buffer in the kernels' striped layout [B, stripes, groups, 2]."""
+    return torch.zeros(B, cabi.STAT_STRIPES, groups, 2, dtype=torch.float64, device=DEV)
+
+
+def stats_striped(y, groups):
+    """Reference statistics of y placed in stripe 0 of the striped layout (device)."""
+    s = stats_buffer(y.shape[0], groups)
+    s[:, 0] = gn_stats_ref(y, groups).to(DEV)
+    return s
+
+
+def dec_max(u):
+    """Decode the kernels' order-preserving uint32 max code (int32 tensor) -> float32 (0 -> -inf-ish)."""
+    shape = u.shape
+    u = u.cpu().to(torch.int64).flatten() & 0xFFFFFFFF
+    neg = (u & 0x80000000) == 0
+    bits = torch.where(neg, (~u) & 0xFFFFFFFF, u & 0x7FFFFFFF)
+    f = torch.from_numpy(bits.numpy().astype(np.uint32).view(np.float32).copy())
+    f = torch.where(u == 0, torch.tensor(-3.0e38), f)          # untouched stripes
+    return f.reshape(shape)

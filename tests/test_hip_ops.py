@@ -30,12 +30,12 @@ def _q(x, dtype):
 def test_conv3x3_plain_and_stats(dtype, B, cin, cout, H, W):
     x, w, b = _q(hh.rand((B, cin, H, W), 1), dtype), _q(hh.rand((cout, cin, 3, 3), 2, -0.1, 0.1), dtype), hh.rand((cout,), 3)
     ref = F.conv2d(x, w, b, padding=1)
-    stats = torch.zeros(B, 8, 2, dtype=torch.float64, device=hh.DEV)
+    stats = hh.stats_buffer(B, 8)
     out = hh.conv3x3([hh.make_src(hh.nhwc(x, dtype), cin)], hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype,
                      stats=stats, groups=8)
     assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
     sref = hh.gn_stats_ref(ref, 8)
-    assert hh.rel_err(stats.cpu(), sref) < (1e-5 if dtype == "fp32" else 1e-2)
+    assert hh.rel_err(stats.sum(1).cpu(), sref) < (1e-5 if dtype == "fp32" else 1e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -63,7 +63,7 @@ def test_conv3x3_gn_film_prologue(dtype, act, groups, use_film):
         y = y * (film[:, :cin, None, None] + 1) + film[:, cin:, None, None]
     y = F.silu(y) if act == cabi.ACT_SILU else F.relu(y)
     ref = F.conv2d(y, w, b, padding=1)
-    stats = hh.gn_stats_ref(x, groups).to(hh.DEV)
+    stats = hh.stats_striped(x, groups)
     g_d, b_d, f_d = gamma.to(hh.DEV), beta.to(hh.DEV), film.to(hh.DEV)
     src = hh.make_src(hh.nhwc(x, dtype), cin, gn=(stats, g_d, b_d, groups), act=act,
                       film=f_d if use_film else None, film_b=2 * cin)
@@ -150,12 +150,12 @@ def test_conv_image(dtype, cin, ks, H, W):
     x, w, b = hh.rand((B, cin, H, W), 40), hh.rand((32, cin, ks, ks), 41, -0.2, 0.2), hh.rand((32,), 42)
     ref = F.conv2d(x, w, b, padding=ks // 2)
     out = torch.empty(B, H, W, 32, dtype=hh.TDT[dtype], device=hh.DEV)
-    stats = torch.zeros(B, 16, 2, dtype=torch.float64, device=hh.DEV)
+    stats = hh.stats_buffer(B, 16)
     xd, wd, bd = x.to(hh.DEV), w.to(hh.DEV), b.to(hh.DEV)
     cabi.check(cabi.lib().ld_conv_image(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), stats.data_ptr(),
                                         16, B, cin, H, W, ks, cabi.dtype_code(dtype), hh.st()), "conv_image")
     assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
-    assert hh.rel_err(stats.cpu(), hh.gn_stats_ref(ref, 16)) < 1e-5
+    assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, 16)) < 1e-5
 
 
 # ------------------------------------------------------------------------------ gn_apply
@@ -167,7 +167,7 @@ def test_gn_apply_resblock_tail_and_basicblock_tail(dtype):
     ref = F.silu(F.group_norm(a, 8, ga, ba)) + r
     A = cabi.GnApplyArgs()
     ad, rd = hh.nhwc(a, dtype), hh.nhwc(r, dtype)
-    sa = hh.gn_stats_ref(a, 8).to(hh.DEV)
+    sa = hh.stats_striped(a, 8)
     gad, bad = ga.to(hh.DEV), ba.to(hh.DEV)
     A.a = hh.make_src(ad, c, gn=(sa, gad, bad, 8), act=cabi.ACT_SILU)
     A.b = hh.make_src(rd, c)
@@ -178,7 +178,7 @@ def test_gn_apply_resblock_tail_and_basicblock_tail(dtype):
     # BasicBlock tail with pooling: maxpool(relu(GN16(a) + GN16(r)))
     gr, br = hh.rand((c,), 54, 0.5, 1.5), hh.rand((c,), 55, -0.3, 0.3)
     ref = F.max_pool2d(F.relu(F.group_norm(a, 16, ga, ba) + F.group_norm(r, 16, gr, br)), 2)
-    sa, sr = hh.gn_stats_ref(a, 16).to(hh.DEV), hh.gn_stats_ref(r, 16).to(hh.DEV)
+    sa, sr = hh.stats_striped(a, 16), hh.stats_striped(r, 16)
     grd, brd = gr.to(hh.DEV), br.to(hh.DEV)
     A = cabi.GnApplyArgs()
     A.a = hh.make_src(ad, c, gn=(sa, gad, bad, 16))
@@ -222,18 +222,26 @@ def test_linear_attention_block(dtype, c, H, W):
     lib, dt = cabi.lib(), cabi.dtype_code(dtype)
     xd = hh.nhwc(x, dtype)
     wq = hh.pack(sd["a.to_qkv.weight"], dtype, 1, scale_in=sd["a.norm.g"].flatten() * math.sqrt(c))
-    qkv = hh.conv1x1([hh.make_src(xd, c)], wq, B, H, W, 3 * hid, dtype, epi=cabi.EPI_QKV_LINEAR, rms_in=1)
-    nparts, nchunks = max(1, min(64, n // 256)), max(1, min(32, n // 2048))
-    kmax = torch.empty(B, nparts, hid, device=hh.DEV)
+    kmax = torch.zeros(B, cabi.STAT_STRIPES, hid, dtype=torch.int32, device=hh.DEV)   # fused into the qkv epilogue
+    qkv = hh.conv1x1([hh.make_src(xd, c)], wq, B, H, W, 3 * hid, dtype, epi=cabi.EPI_QKV_LINEAR, rms_in=1, kmax_out=kmax)
+    kmax2 = torch.zeros(B, cabi.STAT_STRIPES, hid, dtype=torch.int32, device=hh.DEV)  # stand-alone kernel, same result
+    cabi.check(lib.ld_linattn_kmax(qkv.data_ptr(), kmax2.data_ptr(), B, n, 4, 32, dt, hh.st()), "kmax")
+    nchunks = max(1, min(32, n // 256))
+    ctxn = torch.empty(B, 4, 32, 32, device=hh.DEV)
     ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, 4, 32, nchunks)), device=hh.DEV)
     wfold = torch.empty(B, c * hid, dtype=hh.TDT[dtype], device=hh.DEV)
     wout = sd["a.to_out.0.weight"].reshape(c, hid).contiguous().to(hh.DEV)
-    cabi.check(lib.ld_linattn_kmax(qkv.data_ptr(), kmax.data_ptr(), B, n, 4, 32, nparts, dt, hh.st()), "kmax")
-    cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), nparts, ctx.data_ptr(), B, n, 4, 32, nchunks, dt, hh.st()), "ctx")
-    cabi.check(lib.ld_linattn_fold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold.data_ptr(), B, c, 4, 32, dt, hh.st()), "fold")
+    cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), ctx.data_ptr(), B, n, 4, 32, nchunks, dt, hh.st()), "ctx")
+    cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, 4, 32, hh.st()), "reduce")
+    cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(), wfold.data_ptr(), B, c, 4, 32, dt, hh.st()), "fold")
+    # intermediate check: normalised context = softmax_n(k) . v^T
+    q_, k_, v_ = [t.reshape(B, 4, 32, n) for t in F.conv2d(unet_ref.rms_norm(x, sd["a.norm.g"]), sd["a.to_qkv.weight"]).chunk(3, dim=1)]
+    cref = torch.einsum("bhdn,bhen->bhde", k_.softmax(dim=-1), v_)
+    assert hh.rel_err(ctxn.cpu(), cref) < hh.RTOL[dtype] * 3
     # intermediate check: kmax
     kref = F.conv2d(unet_ref.rms_norm(x, sd["a.norm.g"]), sd["a.to_qkv.weight"]).chunk(3, dim=1)[1].reshape(B, hid, n).amax(-1)
-    assert hh.rel_err(kmax.amax(1).cpu(), kref) < hh.RTOL[dtype] * 3
+    assert hh.rel_err(hh.dec_max(kmax).amax(1), kref) < hh.RTOL[dtype] * 3
+    assert hh.rel_err(hh.dec_max(kmax2).amax(1), kref) < hh.RTOL[dtype] * 3
     es = 4 if dtype == "fp32" else 2
     out = hh.conv1x1([hh.make_src(qkv, hid, stride=3 * hid)], wfold, B, H, W, c, dtype, bias=sd["a.to_out.0.bias"].to(hh.DEV),
                      epi=cabi.EPI_RMS_RES, bstride=c * hid * es, g2=(sd["a.to_out.1.g"].flatten() * math.sqrt(c)).to(hh.DEV),
