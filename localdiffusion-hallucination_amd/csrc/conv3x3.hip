@@ -20,6 +20,7 @@
 // Inner order: dx outer (3*MT weight fragments live), then halo rows rr: one activation fragment
 // feeds the (up to) 3 taps dy that touch it => 9*MT + 3*(NW+2) LDS reads per 9*MT*NW MFMAs.
 #include "common.cuh"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,6 +35,7 @@ struct Conv3Dev {
   int B, H, W, Cout;
   const int* t_ptr;
   int tiles_x;
+  int dbg;     // ablation switches (LD_CONV_DEBUG env, 0 in production): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
 
 template <typename T, int MT, int NW>
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   constexpr int TR = 4 * NW, TC = 16, HR = TR + 2, HC = TC + 2;
   constexpr int NPIX = HR * HC, NPIXP = (NPIX + 15) / 16 * 16, PLANE = NPIXP * 16;
   constexpr int ITER = (NPIXP + 63) / 64;
+  constexpr int UNITS = 9 * MT * 64, WU = (UNITS + 255) / 256;
   constexpr bool P = DT<T>::precise;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,18 +61,96 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   const int b = blockIdx.z, m0 = blockIdx.y * MT;
   const int ty0 = (blockIdx.x / a.tiles_x) * TR, tx0 = (blockIdx.x % a.tiles_x) * TC;
   const int H = a.H, W = a.W;
-  const int trow = a.t_ptr ? *a.t_ptr : 0;
+  const int nch0 = a.s[0].C / CK;
+  const int nch = nch0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
+  const int mt_total = a.Cout / 16;
+  const uint4* wg = reinterpret_cast<const uint4*>(a.w);
 
-  // ---- prologue coefficients
-  {
-    int off = 0;
-    for (int s = 0; s < a.nsrc; ++s) {
-      const SrcDev S = s ? a.s[1] : a.s[0];
-      if (S.stats) {
-        const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
-        build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, tid, 256);
+  // ---- register-staged pipeline (cdna_hip_programming.md T14): the global loads of chunk k+1
+  // (halo fragments + weight fragments) are issued before the MFMAs of chunk k and written to LDS
+  // after them, so a workgroup pays ONE exposed global round trip instead of one per chunk.
+  uint4 hx[ITER], wx[WU];
+  unsigned hvalid = 0;                                  // bit it: halo item `it` is inside the image
+  auto issue_loads = [&](int ch) {
+    const int si = ch >= nch0 ? 1 : 0;
+    const SrcDev S = si ? a.s[1] : a.s[0];
+    const int c0 = (ch - si * nch0) * CK;
+    const T* sdata = reinterpret_cast<const T*>(S.data);
+    const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
+    hvalid = 0;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int q = (it * 4 + wv) * 16 + px;
+      hx[it] = make_uint4(0u, 0u, 0u, 0u);
+      if (q < NPIX) {
+        const int hy = q / HC, hx_ = q - hy * HC;
+        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W && !(a.dbg & 1)) {
+          const int sy = S.ups ? gy >> 1 : gy, sx = S.ups ? gx >> 1 : gx;
+          hx[it] = *reinterpret_cast<const uint4*>(sdata + (((size_t)b * Hs + sy) * Ws + sx) * S.ld + c0 + kq * E);
+          hvalid |= 1u << it;
+        }
       }
-      off += 2 * S.C;
+    }
+#pragma unroll
+    for (int k = 0; k < WU; ++k) {
+      const int u = k * 256 + tid;
+      wx[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (u < UNITS && !(a.dbg & 2)) {
+        const int tap = u / (MT * 64), r = u - tap * (MT * 64);
+        wx[k] = wg[(((size_t)ch * 9 + tap) * mt_total + m0) * 64 + r];
+      }
+    }
+  };
+  auto write_lds = [&](int ch) {
+    const int si = ch >= nch0 ? 1 : 0;
+    const SrcDev S = si ? a.s[1] : a.s[0];
+    const int c0 = (ch - si * nch0) * CK;
+    const int coef_off = si ? 2 * a.s[0].C : 0;
+    const bool has_coef = S.stats != nullptr;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int q = (it * 4 + wv) * 16 + px;
+      if (q < NPIXP) {
+        uint4 raw = hx[it];
+        if (has_coef && ((hvalid >> it) & 1u)) {        // zero padding stays exactly zero
+          float v[E];
+          unpack16<T>(raw, v);
+          const float* ca = s_coef + coef_off + c0 + kq * E;
+          const float* cs = ca + S.C;
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[e] = act_f<P>(fmaf(v[e], ca[e], cs[e]), S.act);
+          raw = pack16<T>(v);
+        }
+        *reinterpret_cast<uint4*>(s_x + kq * PLANE + q * 16) = raw;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WU; ++k) {
+      const int u = k * 256 + tid;
+      if (u < UNITS) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wx[k];
+    }
+  };
+
+  issue_loads(0);
+  float4 bias[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + (m0 + m) * 16 + kq * 4);
+
+  // ---- prologue coefficients (overlaps the loads above)
+  {
+    const bool any = a.s[0].stats != nullptr || (a.nsrc > 1 && a.s[1].stats != nullptr);
+    if (any) {
+      const int trow = a.t_ptr ? *a.t_ptr : 0;
+      int off = 0;
+      for (int s = 0; s < a.nsrc; ++s) {
+        const SrcDev S = s ? a.s[1] : a.s[0];
+        if (S.stats) {
+          const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
+          build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, tid, 256);
+        }
+        off += 2 * S.C;
+      }
     }
   }
 
@@ -79,64 +160,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nch0 = a.s[0].C / CK;
-  const int nch = nch0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
-  const int mt_total = a.Cout / 16;
-
   for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();   // previous chunk fully consumed (and, first time, coefficients visible)
-    const int si = ch >= nch0 ? 1 : 0;
-    const SrcDev S = si ? a.s[1] : a.s[0];   // uniform select (no dynamic kernarg indexing)
-    const int c0 = (ch - si * nch0) * CK;
-    const int coef_off = si ? 2 * a.s[0].C : 0;
-    const T* sdata = reinterpret_cast<const T*>(S.data);
-    const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
-    const bool has_coef = S.stats != nullptr;
-
-    // ---- stage the halo tile of this channel chunk: wave handles 16 halo pixels x 4 fragments
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int q = (it * 4 + wv) * 16 + px;
-      if (q < NPIXP) {
-        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-        if (q < NPIX) {
-          const int hy = q / HC, hx = q - hy * HC;
-          const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-          if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const int sy = S.ups ? gy >> 1 : gy, sx = S.ups ? gx >> 1 : gx;
-            const size_t idx = (((size_t)b * Hs + sy) * Ws + sx) * S.ld + c0 + kq * E;
-            raw = *reinterpret_cast<const uint4*>(sdata + idx);
-            if (has_coef) {
-              float v[E];
-              unpack16<T>(raw, v);
-              const float* ca = s_coef + coef_off + c0 + kq * E;
-              const float* cs = ca + S.C;
-#pragma unroll
-              for (int e = 0; e < E; ++e) v[e] = act_f<P>(fmaf(v[e], ca[e], cs[e]), S.act);
-              raw = pack16<T>(v);
-            }
-          }
-        }
-        *reinterpret_cast<uint4*>(s_x + kq * PLANE + q * 16) = raw;
-      }
-    }
-    // ---- stage the weights of this chunk: 9 taps x MT tiles x 1 KiB, linear copy
-    {
-      const uint4* wg = reinterpret_cast<const uint4*>(a.w);
-      constexpr int UNITS = 9 * MT * 64;
-#pragma unroll
-      for (int u0 = 0; u0 < UNITS; u0 += 256) {
-        const int u = u0 + tid;
-        if (u < UNITS) {
-          const int tap = u / (MT * 64), r = u - tap * (MT * 64);
-          const size_t gi = (((size_t)ch * 9 + tap) * mt_total + m0) * 64 + r;
-          *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[gi];
-        }
-      }
-    }
+    __syncthreads();                 // previous chunk fully consumed (first time: coefficients visible)
+    write_lds(ch);
     __syncthreads();
+    if (ch + 1 < nch) issue_loads(ch + 1);
 
     // ---- MFMA
+    if (!(a.dbg & 4))
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       uint4 A[3][MT];
@@ -172,14 +203,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int co = (m0 + m) * 16 + kq * 4;
-    const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+    const float4 bv = bias[m];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int gy = ty0 + wv * NW + j;
       const bool valid = gy < H && gx < W;
       float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
       if (valid) {
-        store4<T>(out + (((size_t)b * H + gy) * W + gx) * a.Cout + co, v);
+        if (!(a.dbg & 8)) store4<T>(out + (((size_t)b * H + gy) * W + gx) * a.Cout + co, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
       }
@@ -234,10 +265,18 @@ int launch(const Conv3Dev& a, hipStream_t st) {
 
 template <typename T>
 int dispatch(const Conv3Dev& a, hipStream_t st) {
-  const bool mt4 = (a.Cout % 64) == 0;
+  static const int force_mt = getenv("LD_CONV_MT") ? atoi(getenv("LD_CONV_MT")) : 0;   // tuning overrides
+  static const int force_nw = getenv("LD_CONV_NW") ? atoi(getenv("LD_CONV_NW")) : 0;
+  bool mt4 = (a.Cout % 64) == 0;
   // enough workgroups to fill 256 CUs a couple of times over with the big tile?
   const long blocks16 = (long)((a.W + 15) / 16) * ((a.H + 15) / 16) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
-  const bool big = blocks16 >= 512 && a.H >= 16;
+  // 64-channel tiles keep 2 pixel rows per wave: with the prefetch registers the 4-row variant
+  // drops to one wave per SIMD and measured slower (64->64@128^2: 23.3 vs 19.7 us)
+  bool big = blocks16 >= 512 && a.H >= 16 && !mt4;
+  if (force_mt == 2) mt4 = false;
+  if (force_mt == 4 && (a.Cout % 64) == 0) mt4 = true;
+  if (force_nw == 2) big = false;
+  if (force_nw == 4) big = true;
   if (mt4) return big ? launch<T, 4, 4>(a, st) : launch<T, 4, 2>(a, st);
   return big ? launch<T, 2, 4>(a, st) : launch<T, 2, 2>(a, st);
 }
@@ -272,6 +311,8 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   a.w = p->weight; a.bias = p->bias; a.out = p->out; a.ostats = p->out_stats;
   a.ogroups = p->out_groups > 0 ? p->out_groups : 1;
   a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout; a.t_ptr = p->t_ptr; a.tiles_x = 0;
+  static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
+  a.dbg = dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == LD_F32 ? dispatch<float>(a, st) : dispatch<bf16>(a, st);
 }
