@@ -184,9 +184,22 @@ int ld_linattn_ctx(const void* qkv, const uint32_t* kmax_enc, float* ctx_part,
                    int B, int n, int heads, int dim_head, int nchunks, int dtype, void* stream);
 int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* ctxn, int B, int heads,
                           int dim_head, void* stream);
+/* perm=0: standard k=1 packing (consumed by ld_conv1x1); perm=1 (bf16): chained-MFMA operand order
+ * consumed by ld_linattn_out. */
 int ld_linattn_fold(const float* ctxn, const float* w_out /*[C,hidden] fp32*/,
                     void* w_packed /*[B] packed C x hidden*/, int B, int C, int heads, int dim_head,
-                    int dtype, void* stream);
+                    int perm, int dtype, void* stream);
+/* Fused bf16 path: q, k, v never reach HBM (both kernels recompute their slice of to_qkv from x).
+ *   ld_linattn_kvctx: x [B,n,C] -> ctx partials (same layout/consumers as ld_linattn_ctx), with the
+ *        RMSNorm (ddpm.py:237), the k/v rows of to_qkv (:239) and softmax_n(k) (:243) inside;
+ *        wkv_packed = per head the 64 rows (k_h | v_h) of to_qkv, packed k=1 with g*sqrt(C) folded.
+ *   ld_linattn_out:   x -> out = RMSNorm(to_out(ctx^T softmax_d(q)*scale)) + x  (:242,245,249,251,425);
+ *        wq_packed = the 128 q rows packed the same way, mfold from ld_linattn_fold(perm=1). */
+int ld_linattn_kvctx(const void* x, const void* wkv_packed, float* ctx_part, int B, int n, int C,
+                     int heads, int dim_head, int nchunks, int dtype, void* stream);
+int ld_linattn_out(const void* x, const void* wq_packed, const void* mfold, const float* bias,
+                   const float* g2, void* out, int B, int n, int C, float q_scale, int dtype,
+                   void* stream);
 size_t ld_linattn_ctx_part_floats(int B, int heads, int dim_head, int nchunks);
 
 /* Full softmax attention (attend.py:84-113) on qkv [B, n, 3*hidden] with q pre-scaled;

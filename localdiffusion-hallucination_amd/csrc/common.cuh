@@ -156,24 +156,27 @@ static inline SrcDev to_dev(const ld_src& s) {
 __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, long npix, float* coef,
                                               double* red, int tid, int nthreads) {
   const int C = S.C, G = S.groups, gs = C / G;
-  if (tid < 2 * G) {                       // sum the stripes: entry (g, k) with tid = 2g + k
-    const double* p = S.stats + (size_t)b * LD_STAT_STRIPES * G * 2 + tid;
-    double acc = 0.0;
+  float* gstat = reinterpret_cast<float*>(red);          // after the stripe sum: [G] mean, [G] rstd (floats)
+  if (tid < G) {
+    // sum the stripes in fp64, then ONE double divide/sqrt per group (not per channel)
+    const double* p = S.stats + (size_t)b * LD_STAT_STRIPES * G * 2 + 2 * tid;
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int s = 0; s < LD_STAT_STRIPES; ++s) acc += p[(size_t)s * G * 2];
-    red[tid] = acc;
+    for (int s = 0; s < LD_STAT_STRIPES; ++s) { s1 += p[(size_t)s * G * 2]; s2 += p[(size_t)s * G * 2 + 1]; }
+    const double inv_n = 1.0 / ((double)npix * gs);
+    const double mean = s1 * inv_n;
+    double var = s2 * inv_n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    gstat[tid] = (float)mean;
+    gstat[G + tid] = rstd;
   }
   __syncthreads();
-  const double inv_n = 1.0 / ((double)npix * gs);
   const float* film = S.film ? S.film + (long)trow * S.film_tstride + (long)b * S.film_bstride : nullptr;
   for (int c = tid; c < C; c += nthreads) {
     const int g = c / gs;
-    const double mean = red[2 * g] * inv_n;
-    double var = red[2 * g + 1] * inv_n - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-    float a = rstd * S.gamma[c];
-    float s = S.beta[c] - (float)mean * a;
+    float a = gstat[G + g] * S.gamma[c];
+    float s = S.beta[c] - gstat[g] * a;
     if (film) {
       const float sc = film[c] + 1.0f, sh = film[C + c];
       a *= sc;

@@ -108,6 +108,13 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
     const int c0 = (ch - si * nch0) * CK;
     const int coef_off = si ? 2 * a.s[0].C : 0;
     const bool has_coef = S.stats != nullptr;
+    // this thread always stages the same E channels of the chunk: keep their (a, s) in registers
+    float ca[E], cs[E];
+    if (has_coef) {
+      const float* cap = s_coef + coef_off + c0 + kq * E;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { ca[e] = cap[e]; cs[e] = cap[S.C + e]; }
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int q = (it * 4 + wv) * 16 + px;
@@ -116,8 +123,6 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
         if (has_coef && ((hvalid >> it) & 1u)) {        // zero padding stays exactly zero
           float v[E];
           unpack16<T>(raw, v);
-          const float* ca = s_coef + coef_off + c0 + kq * E;
-          const float* cs = ca + S.C;
 #pragma unroll
           for (int e = 0; e < E; ++e) v[e] = act_f<P>(fmaf(v[e], ca[e], cs[e]), S.act);
           raw = pack16<T>(v);

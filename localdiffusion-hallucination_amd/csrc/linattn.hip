@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void kmax_kernel(const T* __restrict__ qkv, un
 }
 
 // ------------------------------------------------------------------ ctx partials
-constexpr int CTX_STRIDE = 32 * 32 + 32;   // floats per (b, h, chunk): ctx[d][e] then Z[d]
+constexpr int CTX_STRIDE = 32 * 32 + 64;   // floats per (b, h, chunk): ctx[d][e], Z[d], then the max m[d] the chunk's
+                                           // exponentials were taken against (see ctx_reduce_kernel)
 
 template <typename T>
 __global__ __launch_bounds__(256) void ctx_kernel(const T* __restrict__ qkv, const unsigned* __restrict__ kmax_enc,
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(256) void ctx_kernel(const T* __restrict__ qkv, con
   if (half == 0) s_red[wv][1024 + r] = z;
   __syncthreads();
   float* dst = ctx_part + (((size_t)b * heads + h) * nchunks + ck) * CTX_STRIDE;
-  for (int i = tid; i < CTX_STRIDE; i += 256) dst[i] = s_red[0][i] + s_red[1][i] + s_red[2][i] + s_red[3][i];
+  for (int i = tid; i < 1056; i += 256) dst[i] = s_red[0][i] + s_red[1][i] + s_red[2][i] + s_red[3][i];
+  if (wv == 0 && half == 0) dst[1056 + r] = km;       // every chunk used the global max
 }
 
 // ------------------------------------------------------------------ ctx partials, bf16 MFMA
@@ -196,26 +198,46 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const bf16* __restrict__ 
     for (int k = 0; k < 64; ++k) t += s_z[(k * 4 + cc) * 8 + e];
     dst[1024 + tid] = t;
   }
+  if (tid < 4) {                                          // c8 == tid: this thread's km[] are channels 8*tid..
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[1056 + tid * 8 + e] = km[e];
+  }
 }
 
 // ------------------------------------------------------------------ reduce the chunk partials
 // grid = (heads, B, 4): ctxn[b,h,d,e] = sum_chunks ctx / sum_chunks Z[d]   (the k-softmax normaliser)
 __global__ __launch_bounds__(256) void ctx_reduce_kernel(const float* __restrict__ ctx_part, int nchunks,
                                                          float* __restrict__ ctxn, int heads) {
-  __shared__ float s_z[8];
+  // partial c was accumulated against its own max m_c[d]; rescale to M[d] = max_c m_c[d]:
+  //   ctx[d][e] = sum_c w_c[d] ctx_c[d][e],  Z[d] = sum_c w_c[d] Z_c[d],  w_c[d] = exp(m_c[d]-M[d])
+  __shared__ float s_w[8][33], s_zc[8][33], s_z[8];
   const int h = blockIdx.x, b = blockIdx.y, quarter = blockIdx.z, tid = threadIdx.x;
   const float* src = ctx_part + ((size_t)b * heads + h) * nchunks * CTX_STRIDE;
   const int i = quarter * 256 + tid;                     // element d*32+e; this block covers d = 8*quarter..+7
+  {                                                      // (d, chunk) table, one entry per thread (nchunks <= 32)
+    const int dl = tid >> 5, c = tid & 31, d = quarter * 8 + dl;
+    const bool ok = c < nchunks;
+    s_w[dl][c] = ok ? src[(size_t)c * CTX_STRIDE + 1056 + d] : -INFINITY;
+    s_zc[dl][c] = ok ? src[(size_t)c * CTX_STRIDE + 1024 + d] : 0.f;
+  }
+  __syncthreads();
   if (tid < 8) {
+    float M = -INFINITY;
+    for (int c = 0; c < 32; ++c) M = fmaxf(M, s_w[tid][c]);
     float z = 0.f;
-    for (int c = 0; c < nchunks; ++c) z += src[(size_t)c * CTX_STRIDE + 1024 + quarter * 8 + tid];
+    for (int c = 0; c < 32; ++c) {
+      const float wgt = expf(s_w[tid][c] - M);           // exp(-inf) = 0 for unused chunk slots
+      s_w[tid][c] = wgt;
+      z += wgt * s_zc[tid][c];
+    }
     s_z[tid] = z;
   }
+  __syncthreads();
+  const int dl = tid >> 5;
   float s = 0.f;
 #pragma unroll 8
-  for (int c = 0; c < nchunks; ++c) s += src[(size_t)c * CTX_STRIDE + i];
-  __syncthreads();
-  ctxn[((size_t)b * heads + h) * 1024 + i] = s / s_z[tid >> 5];
+  for (int c = 0; c < nchunks; ++c) s += s_w[dl][c] * src[(size_t)c * CTX_STRIDE + i];
+  ctxn[((size_t)b * heads + h) * 1024 + i] = s / s_z[dl];
 }
 
 // ------------------------------------------------------------------ fold ctx into per-batch 1x1 weights
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(256) void ctx_reduce_kernel(const float* __restrict
 // the packed fragment order ld_conv1x1 reads (k=1 layout of pack.hip).
 template <typename T>
 __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctxn, const float* __restrict__ w_out,
-                                                   T* __restrict__ w_packed, int C, int heads) {
+                                                   T* __restrict__ w_packed, int C, int heads, int perm) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   extern __shared__ float s_ctx[];                       // [heads][32][33] (padded: conflict-free rows)
   const int hidden = heads * 32, b = blockIdx.y, mt = blockIdx.x, tid = threadIdx.x;
@@ -240,7 +262,10 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctx
     float m = 0.f;
 #pragma unroll 8
     for (int e = 0; e < 32; ++e) m = fmaf(wrow[e], crow[e], m);
-    const int ch = ci / CK, kq = (ci % CK) / E, e = ci % E;
+    int ch = ci / CK, kq = (ci % CK) / E, e = ci % E;
+    if (perm) {   // chained-MFMA operand order (linattn_fused.hip): ci = 32s + 16(e>>2) + 4kq + (e&3), bf16 only
+      ch = ci >> 5; kq = (ci >> 2) & 3; e = ((ci >> 4) & 1) * 4 + (ci & 3);
+    }
     dst[((((size_t)ch * mt_total + mt) * 4 + kq) * 16 + ii) * E + e] = from_f<T>(m);
   }
 }
@@ -294,7 +319,7 @@ extern "C" int ld_linattn_ctx(const void* qkv, const uint32_t* kmax_enc, float* 
 
 extern "C" int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* ctxn, int B, int heads,
                                      int dim_head, void* stream) {
-  LD_REQUIRE(ctx_part && ctxn && B > 0 && nchunks > 0 && heads > 0, "ld_linattn_ctx_reduce: bad args");
+  LD_REQUIRE(ctx_part && ctxn && B > 0 && nchunks > 0 && nchunks <= 32 && heads > 0, "ld_linattn_ctx_reduce: bad args (nchunks 1..32)");
   LD_REQUIRE(dim_head == 32, "ld_linattn_*: dim_head must be 32 (got %d)", dim_head);
   hipLaunchKernelGGL(ctx_reduce_kernel, dim3(heads, B, 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      ctx_part, nchunks, ctxn, heads);
@@ -303,15 +328,16 @@ extern "C" int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* 
 }
 
 extern "C" int ld_linattn_fold(const float* ctxn, const float* w_out, void* w_packed, int B, int C, int heads,
-                               int dim_head, int dtype, void* stream) {
+                               int dim_head, int perm, int dtype, void* stream) {
+  LD_REQUIRE(!(perm && dtype != LD_BF16), "ld_linattn_fold: perm=1 is the bf16 chained-operand order");
   LD_REQUIRE(ctxn && w_out && w_packed && B > 0, "ld_linattn_fold: bad args");
   LD_REQUIRE(dim_head == 32 && C % 16 == 0, "ld_linattn_fold: dim_head 32, C %% 16 == 0");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds = (size_t)heads * 32 * 33 * sizeof(float);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(fold_kernel<float>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (float*)w_packed, C, heads);
+    hipLaunchKernelGGL(fold_kernel<float>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (float*)w_packed, C, heads, perm);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(fold_kernel<bf16>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (bf16*)w_packed, C, heads);
+    hipLaunchKernelGGL(fold_kernel<bf16>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (bf16*)w_packed, C, heads, perm);
   else
     return ld_fail(LD_EINVAL, "ld_linattn_fold: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("linattn_fold");

@@ -1,0 +1,370 @@
+// Fused linear attention for bf16 storage: q, k and v are NEVER written to HBM.
+//
+// LinearAttention.forward (ddpm.py:234-251) reads x and produces to_out(ctx^T softmax_d(q)) with
+// ctx = softmax_n(k) v^T.  The unfused path materialises the [B,n,384] qkv tensor (403 MB at
+// 256^2, B=8, bf16) and reads it back twice; here both consumers RE-COMPUTE their slice of the 1x1
+// projection from x (32..128 channels per pixel), which is far cheaper than the round trip:
+//
+//   ld_linattn_kvctx : per (batch, head, pixel chunk)  k,v = W_kv[h] rms(x)  (MFMA), two sweeps over
+//        the chunk: (0) per-channel max of k, (1) P = exp(k - max), ctx += P^T V (MFMA, transposed
+//        LDS reads), Z += colsum(P).  Emits partial ctx, Z and the chunk's max per channel; the
+//        reduce kernel rescales partials to the global max (softmax over n, ddpm.py:243,247).
+//   ld_linattn_out   : per pixel tile  q = softmax_d(W_q rms(x)) * scale  (MFMA, ddpm.py:242,245),
+//        then out = M_b q with the q ACCUMULATOR REGISTERS used directly as the next MFMA's B
+//        operand (cdna_hip_programming.md section 3: k-slot (lane>>4, e) of step s is q channel
+//        32s + 16(e>>2) + 4(lane>>4) + (e&3); ld_linattn_fold(perm=1) writes M_b in that order),
+//        + bias, RMSNorm, + x (ddpm.py:229-232,249,251,425).
+#include "common.cuh"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+namespace {
+constexpr int CTX_STRIDE = 32 * 32 + 64;   // ctx[d][e], Z[d], m[d]   (must match linattn.hip)
+constexpr int KTN = 256;                   // pixels per tile in kvctx
+constexpr int PROW = 96;                   // LDS row bytes of the P / V tiles (64 data + 32 pad)
+
+__device__ __forceinline__ uint2 tr8(const char* p) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(const_cast<char*>(p)));
+  return __builtin_bit_cast(uint2, v);
+}
+
+struct KvCtxArgs {
+  const bf16* x;
+  const uint4* wkv;     // [heads][NCH][4 tiles: k0 k1 v0 v1][64] fragments (g*sqrt(C) folded in)
+  float* ctx_part;
+  int n, C, heads, nchunks;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
+  constexpr int PLANE = KTN * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_x = smem;                                     // [NCH][4][KTN][16 B]
+  char* s_p = s_x + NCH * 4 * PLANE;                    // [KTN][96 B]
+  char* s_v = s_p + KTN * PROW;
+  float* s_rinv = reinterpret_cast<float*>(s_v + KTN * PROW);   // [KTN]
+  float* s_m = s_rinv + KTN;                            // [4][32]
+  const int ck = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kq = lane >> 4;
+  const int n = a.n, C = a.C;
+  const int npc = (n + a.nchunks - 1) / a.nchunks;
+  const int lo = ck * npc, hi = min(n, lo + npc);
+  uint4 A[4][NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) A[m][c] = a.wkv[(((size_t)h * NCH + c) * 4 + m) * 64 + lane];
+  float cmax[2][4], mloc[2][4], zs[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cmax[m][r] = -INFINITY; mloc[m][r] = 0.f; zs[m][r] = 0.f; }
+  f32x4 cacc = {0.f, 0.f, 0.f, 0.f};
+  const int dt = wv >> 1, et = wv & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+  const bf16* xb = a.x + (size_t)b * n * C;
+
+  // register-staged prefetch of the next x tile (T14): loads of tile k+1 fly during tile k's MFMAs.
+  // The tile sequence is pass 0: lo..hi, then pass 1: lo..hi again.
+  uint4 xr[NCH][4];
+  auto issue = [&](int p0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int p = p0 + (it * 4 + wv) * 16 + li;
+        xr[c][it] = make_uint4(0u, 0u, 0u, 0u);
+        if (p < hi) xr[c][it] = *reinterpret_cast<const uint4*>(xb + (size_t)p * C + c * 32 + kq * 8);
+      }
+  };
+  issue(lo);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int p0 = lo; p0 < hi; p0 += KTN) {
+      __syncthreads();
+      float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int qq = (it * 4 + wv) * 16 + li;
+          const uint4 raw = xr[c][it];
+          float v[8];
+          unpack16<bf16>(raw, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
+          *reinterpret_cast<uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16) = raw;
+        }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float r = rs[it];
+        r += __shfl_xor(r, 16);
+        r += __shfl_xor(r, 32);
+        if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = 1.0f / fmaxf(sqrtf(r), 1e-12f);
+      }
+      __syncthreads();
+      {
+        const int nxt = p0 + KTN;
+        if (nxt < hi) issue(nxt);
+        else if (pass == 0) issue(lo);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int qq = (wv * 4 + j) * 16 + li;
+        const bool valid = (p0 + qq) < hi;
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) mma16<bf16>(acc[m], A[m][c], Bf);
+        }
+        const float rinv = s_rinv[qq];
+        if (pass == 0) {
+          if (valid) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) cmax[m][r] = fmaxf(cmax[m][r], acc[m][r] * rinv);
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            float pv[4], vv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pv[r] = valid ? __expf(acc[m][r] * rinv - mloc[m][r]) : 0.f;
+              vv[r] = valid ? acc[2 + m][r] * rinv : 0.f;
+              zs[m][r] += pv[r];
+            }
+            *reinterpret_cast<uint2*>(s_p + qq * PROW + (16 * m + 4 * kq) * 2) =
+                make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+            *reinterpret_cast<uint2*>(s_v + qq * PROW + (16 * m + 4 * kq) * 2) =
+                make_uint2(pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3]));
+          }
+        }
+      }
+      if (pass == 1) {
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KTN / 32; ++ks) {
+          const int row = ks * 32 + kq * 4 + tq;
+          const char* pa = s_p + row * PROW + dt * 32 + tp * 8;
+          const char* pb = s_v + row * PROW + et * 32 + tp * 8;
+          const uint2 a1 = tr8(pa), a2 = tr8(pa + 16 * PROW);
+          const uint2 b1 = tr8(pb), b2 = tr8(pb + 16 * PROW);
+          mma16<bf16>(cacc, make_uint4(a1.x, a1.y, a2.x, a2.y), make_uint4(b1.x, b1.y, b2.x, b2.y));
+        }
+      }
+    }
+    if (pass == 0) {
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float cm = wave16_max(cmax[m][r]);
+          if (li == 0) s_m[wv * 32 + 16 * m + 4 * kq + r] = cm;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ch = 16 * m + 4 * kq + r;
+          mloc[m][r] = fmaxf(fmaxf(s_m[ch], s_m[32 + ch]), fmaxf(s_m[64 + ch], s_m[96 + ch]));
+        }
+    }
+  }
+  float* dst = a.ctx_part + (((size_t)b * a.heads + h) * a.nchunks + ck) * CTX_STRIDE;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dst[(dt * 16 + kq * 4 + r) * 32 + et * 16 + li] = cacc[r];
+  // Z: lanes -> waves -> block, fixed order (deterministic)
+  __syncthreads();
+  float* s_z = reinterpret_cast<float*>(s_p);           // [4][32]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float z = wave16_sum(zs[m][r]);
+      if (li == 0) s_z[wv * 32 + 16 * m + 4 * kq + r] = z;
+    }
+  __syncthreads();
+  if (tid < 32) {
+    dst[1024 + tid] = s_z[tid] + s_z[32 + tid] + s_z[64 + tid] + s_z[96 + tid];
+    dst[1056 + tid] = fmaxf(fmaxf(s_m[tid], s_m[32 + tid]), fmaxf(s_m[64 + tid], s_m[96 + tid]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct LinOutArgs {
+  const bf16* x;
+  const uint4* wq;       // [NCH][8][64] fragments of W_q (g*sqrt(C) folded in)
+  const uint4* mfold;    // per batch: [4 k-steps][MT2][64] fragments of M_b in chained-operand order
+  const float* bias;
+  const float* g2;
+  bf16* out;
+  int n, C;
+  float q_scale;
+};
+
+template <int NCH>
+__global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
+  constexpr int NW = 2, NPT = 64 * NW, PLANE = NPT * 16, MT2 = 2 * NCH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_x = smem;                                      // [NCH][4][NPT][16 B]
+  char* s_wq = s_x + NCH * 4 * PLANE;                    // [NCH][8][1 KiB]
+  char* s_mf = s_wq + NCH * 8 * 1024;                    // [4][MT2][1 KiB]
+  float* s_rinv = reinterpret_cast<float*>(s_mf + 4 * MT2 * 1024);
+  const int b = blockIdx.y, p0 = blockIdx.x * NPT;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kq = lane >> 4;
+  const int n = a.n, C = a.C;
+  const bf16* xb = a.x + (size_t)b * n * C;
+  for (int u = tid; u < NCH * 8 * 64; u += 256) *reinterpret_cast<uint4*>(s_wq + u * 16) = a.wq[u];
+  const uint4* mf = a.mfold + (size_t)b * 4 * MT2 * 64;
+  for (int u = tid; u < 4 * MT2 * 64; u += 256) *reinterpret_cast<uint4*>(s_mf + u * 16) = mf[u];
+  float rs[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) rs[i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int qq = (it * 4 + wv) * 16 + li, p = p0 + qq;
+      uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+      if (p < n) {
+        raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * C + c * 32 + kq * 8);
+        float v[8];
+        unpack16<bf16>(raw, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
+      }
+      *reinterpret_cast<uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16) = raw;
+    }
+#pragma unroll
+  for (int it = 0; it < NW; ++it) {
+    float r = rs[it];
+    r += __shfl_xor(r, 16);
+    r += __shfl_xor(r, 32);
+    if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = 1.0f / fmaxf(sqrtf(r), 1e-12f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int qq = (wv * NW + j) * 16 + li, p = p0 + qq;
+    const bool valid = p < n;
+    f32x4 q[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) q[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+        mma16<bf16>(q[m], *reinterpret_cast<const uint4*>(s_wq + (c * 8 + m) * 1024 + lane * 16), Bf);
+    }
+    const float rinv = s_rinv[qq];
+    uint4 B2[4];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {                    // one head = channel tiles 2hh, 2hh+1
+      float v0[4], v1[4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v0[r] = q[2 * hh][r] * rinv; v1[r] = q[2 * hh + 1][r] * rinv;
+        mx = fmaxf(mx, fmaxf(v0[r], v1[r]));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v0[r] = __expf(v0[r] - mx); v1[r] = __expf(v1[r] - mx); sum += v0[r] + v1[r]; }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float sc = a.q_scale / sum;
+      B2[hh] = make_uint4(pack_bf16x2(v0[0] * sc, v0[1] * sc), pack_bf16x2(v0[2] * sc, v0[3] * sc),
+                          pack_bf16x2(v1[0] * sc, v1[1] * sc), pack_bf16x2(v1[2] * sc, v1[3] * sc));
+    }
+    f32x4 o[MT2];
+#pragma unroll
+    for (int m2 = 0; m2 < MT2; ++m2) o[m2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int m2 = 0; m2 < MT2; ++m2)
+        mma16<bf16>(o[m2], *reinterpret_cast<const uint4*>(s_mf + (s * MT2 + m2) * 1024 + lane * 16), B2[s]);
+    float ss = 0.f;
+    float y[MT2][4];
+#pragma unroll
+    for (int m2 = 0; m2 < MT2; ++m2) {
+      const float4 bv = *reinterpret_cast<const float4*>(a.bias + m2 * 16 + kq * 4);
+      y[m2][0] = o[m2][0] + bv.x; y[m2][1] = o[m2][1] + bv.y; y[m2][2] = o[m2][2] + bv.z; y[m2][3] = o[m2][3] + bv.w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ss = fmaf(y[m2][r], y[m2][r], ss);
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    if (valid) {
+#pragma unroll
+      for (int m2 = 0; m2 < MT2; ++m2) {
+        const int co = m2 * 16 + kq * 4;
+        const float4 gv = *reinterpret_cast<const float4*>(a.g2 + co);
+        float xr[4];
+        load4<bf16>(xb + (size_t)p * C + co, xr);
+        float r4[4] = {y[m2][0] * inv * gv.x + xr[0], y[m2][1] * inv * gv.y + xr[1],
+                       y[m2][2] * inv * gv.z + xr[2], y[m2][3] * inv * gv.w + xr[3]};
+        store4<bf16>(a.out + ((size_t)b * n + p) * C + co, r4);
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, float* ctx_part, int B, int n, int C,
+                                int heads, int dim_head, int nchunks, int dtype, void* stream) {
+  LD_REQUIRE(x && wkv_packed && ctx_part && B > 0 && n > 0 && nchunks > 0, "ld_linattn_kvctx: bad args");
+  LD_REQUIRE(dtype == LD_BF16, "ld_linattn_kvctx: bf16 storage only (fp32 uses the unfused path)");
+  LD_REQUIRE(dim_head == 32 && (C == 32 || C == 64 || C == 128), "ld_linattn_kvctx: dim_head 32, C in {32,64,128}");
+  KvCtxArgs a{(const bf16*)x, (const uint4*)wkv_packed, ctx_part, n, C, heads, nchunks};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid(nchunks, heads, B);
+  const int nch = C / 32;
+  const size_t lds = (size_t)nch * 4 * KTN * 16 + 2 * KTN * PROW + KTN * sizeof(float) + 128 * sizeof(float);
+  static bool allowed[5] = {false, false, false, false, false};
+  if (nch == 1) {
+    hipLaunchKernelGGL(kvctx_kernel<1>, grid, dim3(256), lds, st, a);
+  } else if (nch == 2) {
+    if (!allowed[2]) { LD_HIP(ld_allow_lds(kvctx_kernel<2>, lds)); allowed[2] = true; }
+    hipLaunchKernelGGL(kvctx_kernel<2>, grid, dim3(256), lds, st, a);
+  } else {
+    if (!allowed[4]) { LD_HIP(ld_allow_lds(kvctx_kernel<4>, lds)); allowed[4] = true; }
+    hipLaunchKernelGGL(kvctx_kernel<4>, grid, dim3(256), lds, st, a);
+  }
+  LD_LAUNCH_CHECK("linattn_kvctx");
+  return LD_OK;
+}
+
+extern "C" int ld_linattn_out(const void* x, const void* wq_packed, const void* mfold, const float* bias,
+                              const float* g2, void* out, int B, int n, int C, float q_scale, int dtype,
+                              void* stream) {
+  LD_REQUIRE(x && wq_packed && mfold && bias && g2 && out && B > 0 && n > 0, "ld_linattn_out: bad args");
+  LD_REQUIRE(dtype == LD_BF16, "ld_linattn_out: bf16 storage only (fp32 uses the unfused path)");
+  LD_REQUIRE(C == 32 || C == 64 || C == 128, "ld_linattn_out: C in {32,64,128}");
+  LinOutArgs a{(const bf16*)x, (const uint4*)wq_packed, (const uint4*)mfold, bias, g2, (bf16*)out, n, C, q_scale};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((n + 127) / 128, B);
+  const int nch = C / 32;
+  const size_t lds = (size_t)nch * 4 * 128 * 16 + (size_t)nch * 8 * 1024 + (size_t)4 * 2 * nch * 1024 + 128 * sizeof(float);
+  static bool allowed[5] = {false, false, false, false, false};
+  if (nch == 1) {
+    hipLaunchKernelGGL(linout_kernel<1>, grid, dim3(256), lds, st, a);
+  } else if (nch == 2) {
+    hipLaunchKernelGGL(linout_kernel<2>, grid, dim3(256), lds, st, a);
+  } else {
+    if (!allowed[4]) { LD_HIP(ld_allow_lds(linout_kernel<4>, lds)); allowed[4] = true; }
+    hipLaunchKernelGGL(linout_kernel<4>, grid, dim3(256), lds, st, a);
+  }
+  LD_LAUNCH_CHECK("linattn_out");
+  return LD_OK;
+}

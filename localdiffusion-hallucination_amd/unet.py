@@ -163,6 +163,33 @@ class Unet(nn.Module):
                 continue                                  # folded per batch with ctx (ld_linattn_fold)
             else:
                 pack(name, k)
+        P["wq"], P["wkv"] = {}, {}
+        if self.compute_dtype == "bf16":
+            hid, heads = self.cfg.hidden, self.cfg.attn_heads
+            for name, w in sd.items():
+                if not name.endswith(".to_qkv.weight") or (name[:-len(".to_qkv.weight")] + ".to_out.1.g") not in sd:
+                    continue
+                base = name[:-len(".to_qkv.weight")]
+                g = sd[base + ".norm.g"].flatten()
+                scale = (g * math.sqrt(g.numel())).contiguous()
+                c = w.shape[1]
+                if c not in (32, 64, 128):
+                    continue
+
+                def pack_rows(rows):
+                    out = torch.empty(rows.numel(), dtype=tdt, device=dev)
+                    rows = rows.contiguous()
+                    cabi.check(lib.ld_pack_conv_weight(rows.data_ptr(), scale.data_ptr(), out.data_ptr(), rows.shape[0],
+                                                       c, 1, 0, dt, st), "pack " + name)
+                    P.setdefault("keep", []).append(rows)
+                    return out
+                P["wq"][base] = pack_rows(w[:hid])
+                per_head = []
+                for h in range(heads):
+                    kv = torch.cat([w[hid + 32 * h: hid + 32 * h + 32], w[2 * hid + 32 * h: 2 * hid + 32 * h + 32]], 0)
+                    per_head.append(pack_rows(kv))
+                P["wkv"][base] = torch.cat(per_head).contiguous()
+                P["keep"].append(scale)
         for name, w in sd.items():
             if name.endswith(".to_out.1.g"):
                 g = w.flatten()
@@ -381,6 +408,13 @@ class _Plan:
         film = self.films.get(p)
         n1 = self.src(raw1, cout, gn=(s1, f[p + ".block1.norm.weight"], f[p + ".block1.norm.bias"], G),
                       act=cabi.ACT_SILU, film=film)
+        if h * w <= 32 * 32 and cout >= 128:
+            # small, wide maps: the normalise+FiLM+SiLU prologue would be repeated by every cout-tile workgroup
+            # (4x at 256 channels) on the critical path of one-workgroup-per-CU launches; a separate pass over
+            # the (L2-resident) tensor measured cheaper (256->256@32^2: 45 -> 25 us + 9 us).  Everything else keeps
+            # it fused (saves a full HBM round trip of the activation).
+            act1 = self.gn_apply(ops, n1, None, h, w, cout)
+            n1 = self.src(act1, cout)
         raw2 = self.conv3(ops, [n1], p + ".block2.proj", cout, h, w, stats=s2, groups=G)
         if (p + ".res_conv.weight") in f:
             res = self.conv1(ops, srcs_fn(), self.P["w"][p + ".res_conv.weight"], cout, h, w,
@@ -394,8 +428,39 @@ class _Plan:
         self.named[p] = out
         return out
 
+    def linear_attention_fused(self, ops, p, x, c, h, w):
+        """bf16: q/k/v never materialised (csrc/linattn_fused.hip)."""
+        f, cfg, lib = self.f32, self.cfg, self.lib
+        n, hid, B, heads, dt, es = h * w, cfg.hidden, self.B, cfg.attn_heads, self.dt, self.esize
+        nchunks = max(1, min(32, n // 256))
+        ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, heads, 32, nchunks)), dtype=torch.float32, device=self.dev)
+        ctxn = torch.empty(B, heads, 32, 32, dtype=torch.float32, device=self.dev)
+        wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)
+        wout = f[p + ".to_out.0.weight"].reshape(c, hid).contiguous()
+        wq, wkv = self.P["wq"][p], self.P["wkv"][p]
+        bias, g2 = f[p + ".to_out.0.bias"], self.P["g2"][p + ".to_out.1.g"]
+        out = self.buf(h, w, c)
+        self.keep += [ctx, ctxn, wfold, wout, wq, wkv, bias, g2, out, x]
+        npx = B * n
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_kvctx(x.data_ptr(), wkv.data_ptr(), ctx.data_ptr(), B, n, c,
+                                                                  heads, 32, nchunks, dt, st), "linattn_kvctx"),
+                  "linattn_kvctx", nbytes=npx * c * es, flops=2 * npx * c * 2 * hid * 2 + 2 * npx * hid * 32)
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, heads,
+                                                                       32, st), "linattn_ctx_reduce"), "linattn_ctx_reduce")
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(), wfold.data_ptr(), B, c,
+                                                                 heads, 32, 1, dt, st), "linattn_fold"),
+                  "linattn_fold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
+        scale = cfg.attn_dim_head ** -0.5
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_out(x.data_ptr(), wq.data_ptr(), wfold.data_ptr(), bias.data_ptr(),
+                                                                g2.data_ptr(), out.data_ptr(), B, n, c, scale, dt, st),
+                                             "linattn_out"),
+                  "linattn_out", nbytes=2 * npx * c * es, flops=2 * npx * hid * c * 2)
+        return out
+
     def linear_attention(self, ops, p, x, c, h, w):
         """ddpm.py:214-251 (+ residual of the caller, :425/:444)."""
+        if self.dt == cabi.LD_BF16 and c in (32, 64, 128) and p in self.P["wq"]:
+            return self.linear_attention_fused(ops, p, x, c, h, w)
         f, cfg, lib = self.f32, self.cfg, self.lib
         n, hid, B = h * w, cfg.hidden, self.B
         kmax = self.kmax_arena[self._kmax_cursor]
@@ -417,7 +482,7 @@ class _Plan:
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, heads,
                                                                        32, st), "linattn_ctx_reduce"), "linattn_ctx_reduce")
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(),
-                                                                 wfold.data_ptr(), B, c, heads, 32, dt, st), "linattn_fold"),
+                                                                 wfold.data_ptr(), B, c, heads, 32, 0, dt, st), "linattn_fold"),
                   "linattn_fold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
         q = self.src(qkv, hid, stride=3 * hid)
         return self.conv1(ops, [q], wfold, c, h, w, bias=f[p + ".to_out.0.bias"], epi=cabi.EPI_RMS_RES,

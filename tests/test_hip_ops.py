@@ -233,7 +233,7 @@ def test_linear_attention_block(dtype, c, H, W):
     wout = sd["a.to_out.0.weight"].reshape(c, hid).contiguous().to(hh.DEV)
     cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), ctx.data_ptr(), B, n, 4, 32, nchunks, dt, hh.st()), "ctx")
     cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, 4, 32, hh.st()), "reduce")
-    cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(), wfold.data_ptr(), B, c, 4, 32, dt, hh.st()), "fold")
+    cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(), wfold.data_ptr(), B, c, 4, 32, 0, dt, hh.st()), "fold")
     # intermediate check: normalised context = softmax_n(k) . v^T
     q_, k_, v_ = [t.reshape(B, 4, 32, n) for t in F.conv2d(unet_ref.rms_norm(x, sd["a.norm.g"]), sd["a.to_qkv.weight"]).chunk(3, dim=1)]
     cref = torch.einsum("bhdn,bhen->bhde", k_.softmax(dim=-1), v_)
@@ -363,3 +363,40 @@ def test_final_conv(dtype):
     cabi.check(cabi.lib().ld_final_conv(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, cin, cout,
                                         cabi.dtype_code(dtype), hh.st()), "final_conv")
     assert hh.rel_err(out.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("c,H,W", [(32, 28, 28), (64, 14, 14), (32, 64, 96), (128, 32, 32)])
+def test_linear_attention_fused_bf16(c, H, W):
+    """The fused bf16 path (q/k/v recomputed from x, never stored) against the oracle block."""
+    dtype = "bf16"
+    B, hid, n = 2, 128, H * W
+    x = _q(hh.rand((B, c, H, W), 170, -2, 2), dtype)
+    sd = {"a.norm.g": hh.rand((1, c, 1, 1), 171, 0.5, 1.5),
+          "a.to_qkv.weight": _q(hh.rand((3 * hid, c, 1, 1), 172, -0.3, 0.3), dtype),
+          "a.to_out.0.weight": hh.rand((c, hid, 1, 1), 173, -0.3, 0.3),
+          "a.to_out.0.bias": hh.rand((c,), 174),
+          "a.to_out.1.g": hh.rand((1, c, 1, 1), 175, 0.5, 1.5)}
+    ref = unet_ref.linear_attention(sd, "a", x) + x
+    lib, dt = cabi.lib(), cabi.dtype_code(dtype)
+    xd = hh.nhwc(x, dtype)
+    scale = sd["a.norm.g"].flatten() * math.sqrt(c)
+    w = sd["a.to_qkv.weight"]
+    wq = hh.pack(w[:hid].contiguous(), dtype, 1, scale_in=scale)
+    wkv = torch.cat([hh.pack(torch.cat([w[hid + 32 * h: hid + 32 * h + 32], w[2 * hid + 32 * h: 2 * hid + 32 * h + 32]], 0).contiguous(),
+                             dtype, 1, scale_in=scale) for h in range(4)]).contiguous()
+    nchunks = max(1, min(32, n // 256))
+    ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, 4, 32, nchunks)), device=hh.DEV)
+    ctxn = torch.empty(B, 4, 32, 32, device=hh.DEV)
+    wfold = torch.empty(B, c * hid, dtype=hh.TDT[dtype], device=hh.DEV)
+    wout = sd["a.to_out.0.weight"].reshape(c, hid).contiguous().to(hh.DEV)
+    cabi.check(lib.ld_linattn_kvctx(xd.data_ptr(), wkv.data_ptr(), ctx.data_ptr(), B, n, c, 4, 32, nchunks, dt, hh.st()), "kvctx")
+    cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, 4, 32, hh.st()), "reduce")
+    q_, k_, v_ = [t.reshape(B, 4, 32, n) for t in F.conv2d(unet_ref.rms_norm(x, sd["a.norm.g"]), w).chunk(3, dim=1)]
+    cref = torch.einsum("bhdn,bhen->bhde", k_.softmax(dim=-1), v_)
+    assert hh.rel_err(ctxn.cpu(), cref) < 2e-2
+    cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(), wfold.data_ptr(), B, c, 4, 32, 1, dt, hh.st()), "fold")
+    out = torch.empty(B, H, W, c, dtype=hh.TDT[dtype], device=hh.DEV)
+    bias, g2 = sd["a.to_out.0.bias"].to(hh.DEV), (sd["a.to_out.1.g"].flatten() * math.sqrt(c)).to(hh.DEV)
+    cabi.check(lib.ld_linattn_out(xd.data_ptr(), wq.data_ptr(), wfold.data_ptr(), bias.data_ptr(), g2.data_ptr(),
+                                  out.data_ptr(), B, n, c, 32 ** -0.5, dt, hh.st()), "linattn_out")
+    assert hh.rel_err(hh.nchw(out), ref) < 6e-2
