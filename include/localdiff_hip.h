@@ -66,6 +66,9 @@ int ld_event_create(void** ev_out);
 int ld_event_record(void* ev, void* stream);
 int ld_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on stop */
 int ld_event_destroy(void* ev);
+/* make `stream` wait for `ev` (fork/join of independent branches on two streams, e.g. a ResnetBlock's
+ * res_conv beside its 3x3 convs; also captured as graph edges) */
+int ld_stream_wait_event(void* stream, void* ev);
 
 /* ---- one input of a convolution, with an optional normalise-on-load prologue --------------- */
 /* Replaces the separate GroupNorm / FiLM / SiLU / ReLU / concat / nearest-upsample passes of

@@ -58,6 +58,7 @@ _SIGS = {
     "ld_event_record": (C.c_int, [vp, vp]),
     "ld_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "ld_event_destroy": (C.c_int, [vp]),
+    "ld_stream_wait_event": (C.c_int, [vp, vp]),
     "ld_conv3x3": (C.c_int, [C.POINTER(Conv3x3Args), vp]),
     "ld_conv1x1": (C.c_int, [C.POINTER(Conv1x1Args), vp]),
     "ld_pack_conv_weight": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -76,3 +76,9 @@ extern "C" int ld_memset_zero(void* ptr, size_t bytes, void* stream) {
   if (bytes) LD_HIP(hipMemsetAsync(ptr, 0, bytes, reinterpret_cast<hipStream_t>(stream)));
   return LD_OK;
 }
+
+extern "C" int ld_stream_wait_event(void* stream, void* ev) {
+  LD_REQUIRE(ev, "ld_stream_wait_event: null event");
+  LD_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(ev), 0));
+  return LD_OK;
+}

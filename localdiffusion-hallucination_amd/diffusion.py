@@ -163,6 +163,9 @@ class GaussianDiffusion(nn.Module):
         sched = self._sched_table()
         obj = cabi.OBJ[self.objective]
         n = jp.x_in.numel()
+        if (self.use_graph and self.noise_source == "device" and x0_buf is None and after is None
+                and timers is None and n_steps > 1):
+            return self._run_joint_steps_graph(jp, t_start, n_steps, lo, hi, z, draw)
         t = t_start
         for _ in range(n_steps):
             jp.set_step(t)
@@ -180,6 +183,57 @@ class GaussianDiffusion(nn.Module):
                 after(t)
             t -= 1
         return draw
+
+    def _run_joint_steps_graph(self, jp, t_start, n_steps, lo, hi, z, draw):
+        """Same steps as the eager loop, replayed from ONE captured HIP graph: the denoiser plan, the
+        noise draw, the posterior update and the step-counter decrement all read the timestep
+        through ``jp.t_dev``, so the captured launch sequence is identical for every t."""
+        import ctypes as C
+        lib = cabi.lib()
+        sched = self._sched_table()
+        obj = cabi.OBJ[self.objective]
+        n = jp.x_in.numel()
+        base = draw + t_start                       # noise stream index of step t is base - t
+        key = (id(jp), float(lo), float(hi), obj, base, z.data_ptr())
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_gstream", None) is None:
+            self._gstream = torch.cuda.Stream()
+        gs = self._gstream
+        gs.wait_stream(cur)
+        st = gs.cuda_stream
+        first = key not in self._graphs
+        t = t_start
+        with torch.cuda.stream(gs):
+            if first:
+                # one eager step first (lazy hipFuncSetAttribute calls etc. must not happen in capture)
+                jp.set_step(t)
+                jp.run_main(st)
+                cabi.check(lib.ld_randn(z.data_ptr(), n, self.noise_seed, base, -1, jp.t_dev.data_ptr(), st), "randn")
+                cabi.check(lib.ld_ddpm_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(),
+                                            None, sched.data_ptr(), jp.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+                t -= 1
+                n_steps -= 1
+                gs.synchronize()
+                cabi.check(lib.ld_graph_begin(st), "graph_begin")
+                try:
+                    jp.run_main(st)
+                    cabi.check(lib.ld_randn(z.data_ptr(), n, self.noise_seed, base, -1, jp.t_dev.data_ptr(), st), "randn")
+                    cabi.check(lib.ld_ddpm_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), z.data_ptr(),
+                                                jp.x_in.data_ptr(), None, sched.data_ptr(), jp.t_dev.data_ptr(),
+                                                lo, hi, obj, n, st), "ddpm_step")
+                    cabi.check(lib.ld_step_add(jp.t_dev.data_ptr(), -1, st), "step_add")
+                finally:
+                    ex = C.c_void_p()
+                    rc = lib.ld_graph_end(st, C.byref(ex))
+                cabi.check(rc, "graph_end")
+                self._graphs[key] = ex
+            ex = self._graphs[key]
+            if n_steps > 0:
+                jp.set_step(t)
+                for _ in range(n_steps):
+                    cabi.check(lib.ld_graph_launch(ex, st), "graph_launch")
+        cur.wait_stream(gs)
+        return draw + (t_start - t) + n_steps
 
     # ------------------------------------------------------------------ DDPM loop
     @torch.inference_mode()
