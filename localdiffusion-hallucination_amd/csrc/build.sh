@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off"
 mkdir -p build
 pids=()
-for f in runtime pack conv3x3 conv1x1 conv_image gn_apply linattn linattn_fused attention time_embed pointwise; do
+for f in runtime pack conv3x3 conv3x3_c32 conv1x1 conv_image gn_apply linattn linattn_fused attention time_embed pointwise; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.cuh -nt build/$f.o ] || [ ../../include/localdiff_hip.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)

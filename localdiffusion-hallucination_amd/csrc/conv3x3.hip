@@ -22,6 +22,8 @@
 #include "common.cuh"
 #include <stdlib.h>
 
+int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st);   // conv3x3_c32.hip
+
 namespace {
 
 struct Conv3Dev {
@@ -319,5 +321,9 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
   a.dbg = dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  {
+    const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages
+    if (rc != 0) return rc < 0 ? rc : LD_OK;
+  }
   return p->dtype == LD_F32 ? dispatch<float>(a, st) : dispatch<bf16>(a, st);
 }

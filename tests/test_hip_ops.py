@@ -400,3 +400,37 @@ def test_linear_attention_fused_bf16(c, H, W):
     cabi.check(lib.ld_linattn_out(xd.data_ptr(), wq.data_ptr(), wfold.data_ptr(), bias.data_ptr(), g2.data_ptr(),
                                   out.data_ptr(), B, n, c, 32 ** -0.5, dt, hh.st()), "linattn_out")
     assert hh.rel_err(hh.nchw(out), ref) < 6e-2
+
+
+# ------------------------------------------------------------------------------ persistent C=32 conv (conv3x3_c32.hip)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_c32_persistent_path(dtype):
+    """Shapes large enough (>= 1024 tiles, Cout 32, <= 2 K-chunks) to take the persistent LDS-DMA kernel:
+    plain + statistics, concat, nearest-x2 upsample, GroupNorm+FiLM+SiLU prologue, ragged width."""
+    B, H, W, cout = 4, 256, 256, 32
+    cin = 32
+    x, w, b = _q(hh.rand((B, cin, H, W), 201), dtype), _q(hh.rand((cout, cin, 3, 3), 202, -0.1, 0.1), dtype), hh.rand((cout,), 203)
+    ref = F.conv2d(x, w, b, padding=1)
+    stats = hh.stats_buffer(B, 8)
+    out = hh.conv3x3([hh.make_src(hh.nhwc(x, dtype), cin)], hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype,
+                     stats=stats, groups=8)
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+    assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, 8)) < (1e-5 if dtype == "fp32" else 1e-2)
+    # GroupNorm + FiLM + SiLU prologue (statistics of x itself)
+    gamma, beta = hh.rand((cin,), 204, 0.5, 1.5), hh.rand((cin,), 205, -0.3, 0.3)
+    film = hh.rand((B, 2 * cin), 206, -0.5, 0.5)
+    y = F.silu(F.group_norm(x, 8, gamma, beta, eps=1e-5) * (film[:, :cin, None, None] + 1) + film[:, cin:, None, None])
+    ref = F.conv2d(y, w, b, padding=1)
+    g_d, b_d, f_d = gamma.to(hh.DEV), beta.to(hh.DEV), film.to(hh.DEV)
+    src = hh.make_src(hh.nhwc(x, dtype), cin, gn=(hh.stats_striped(x, 8), g_d, b_d, 8), act=cabi.ACT_SILU, film=f_d, film_b=2 * cin)
+    out = hh.conv3x3([src], hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype)
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
+    if dtype == "bf16":
+        # 64 -> 32: (upsampled 32 ch) ++ (32 ch), and a width that is not a multiple of 16
+        Wr = 250
+        x1, x2 = _q(hh.rand((B, 32, H // 2, Wr // 2), 207), dtype), _q(hh.rand((B, 32, H, Wr), 208), dtype)
+        w2 = _q(hh.rand((cout, 64, 3, 3), 209, -0.1, 0.1), dtype)
+        ref = F.conv2d(torch.cat([F.interpolate(x1, scale_factor=2, mode="nearest"), x2], 1), w2, b, padding=1)
+        out = hh.conv3x3([hh.make_src(hh.nhwc(x1, dtype), 32, ups=1), hh.make_src(hh.nhwc(x2, dtype), 32)],
+                         hh.pack(w2, dtype, 3), b.to(hh.DEV), B, H, Wr, cout, dtype)
+        assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
