@@ -119,6 +119,9 @@ int ld_conv3x3(const ld_conv3x3_args* args, void* stream);
                             /* into q                                                           */
 #define LD_EPI_RMS_RES 3    /* to_out conv + RMSNorm + residual (ddpm.py:229-232,251,425,444)    */
 #define LD_EPI_RES 4        /* to_out conv + residual (ddpm.py:269,282,425,431)                  */
+#define LD_EPI_GN_TAIL 5    /* ResnetBlock tail fused into its res_conv (ddpm.py:198,210-212):    */
+                            /* out = res_conv(x) + act(GroupNorm(gn_tail))  -- gn_tail is block2's */
+                            /* raw conv output with its statistics                               */
 typedef struct ld_conv1x1_args {
   ld_src src[2];
   int32_t nsrc;
@@ -134,6 +137,7 @@ typedef struct ld_conv1x1_args {
   float q_scale;           /* dim_head^-0.5 */
   const float* g2;         /* [Cout] g*sqrt(Cout) for LD_EPI_RMS_RES */
   const void* residual;    /* NHWC [B,H,W,Cout] for *_RES */
+  ld_src gn_tail;          /* LD_EPI_GN_TAIL: NHWC [B,H,W,Cout] + GroupNorm prologue fields (no FiLM) */
   void* out;
   uint32_t* kmax_out;      /* LD_EPI_QKV_LINEAR only, optional: [B, LD_STAT_STRIPES, hidden] order-encoded running max
                               of the k channels over pixels (integer atomicMax; caller zeroes) -- see ld_linattn_kmax */

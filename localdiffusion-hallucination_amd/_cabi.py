@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liblocaldiff_hip.so")
 
 LD_F32, LD_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
-EPI_PLAIN, EPI_QKV_LINEAR, EPI_QKV_FULL, EPI_RMS_RES, EPI_RES = 0, 1, 2, 3, 4
+EPI_PLAIN, EPI_QKV_LINEAR, EPI_QKV_FULL, EPI_RMS_RES, EPI_RES, EPI_GN_TAIL = 0, 1, 2, 3, 4, 5
 OBJ = {"pred_x0": 0, "pred_noise": 1, "pred_v": 2}
 SCHED_COLS = 8
 STAT_STRIPES = 16      # LD_STAT_STRIPES
@@ -35,7 +35,7 @@ class Conv3x3Args(C.Structure):
 class Conv1x1Args(C.Structure):
     _fields_ = [("src", Src * 2), ("nsrc", i32), ("unshuffle", i32), ("rms_in", i32), ("weight", vp),
                 ("weight_bstride", i64), ("bias", vp), ("epilogue", i32), ("hidden", i32),
-                ("q_scale", f32), ("g2", vp), ("residual", vp), ("out", vp), ("kmax_out", vp), ("B", i32), ("H", i32),
+                ("q_scale", f32), ("g2", vp), ("residual", vp), ("gn_tail", Src), ("out", vp), ("kmax_out", vp), ("B", i32), ("H", i32),
                 ("W", i32), ("Cout", i32), ("dtype", i32)]
 
 

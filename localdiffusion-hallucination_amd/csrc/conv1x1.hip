@@ -29,6 +29,7 @@ struct Conv1Dev {
   const void* res;
   void* out;
   unsigned* kmax;
+  SrcDev tail;          // LD_EPI_GN_TAIL operand
   int B, H, W, Cout;
 };
 
@@ -41,11 +42,15 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   char* s_x = smem;
   char* s_w = smem + 4 * PLANE;
   float* s_rinv = reinterpret_cast<float*>(s_w + MT * 1024);
+  float* s_tcoef = s_rinv + NPT;                                   // [2*Cout] GN_TAIL coefficients, then 64 doubles scratch
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
   const int b = blockIdx.z, m0 = blockIdx.y * MT;
   const int HW = a.H * a.W, p0 = blockIdx.x * NPT;
   const int mt_total = a.Cout / 16;
+
+  if (a.epi == LD_EPI_GN_TAIL)
+    build_gn_coef(a.tail, b, 0, (long)HW, s_tcoef, reinterpret_cast<double*>(s_tcoef + 2 * a.Cout), tid, 256);
 
   f32x4 acc[MT][NW];
 #pragma unroll
@@ -211,6 +216,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
           load4<T>(res + o, rv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
+        } else if (a.epi == LD_EPI_GN_TAIL) {
+          float rv[4];
+          load4<T>(reinterpret_cast<const T*>(a.tail.data) + o, rv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            v[m][r] += act_f<DT<T>::precise>(fmaf(rv[r], s_tcoef[co + r], s_tcoef[a.Cout + co + r]), a.tail.act);
         }
         store4<T>(out + o, v[m]);
       }
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 template <typename T, int MT, int NW>
 int launch(const Conv1Dev& a, hipStream_t st) {
   constexpr int NPT = 64 * NW;
-  const size_t lds = 4 * NPT * 16 + MT * 1024 + NPT * sizeof(float);
+  const size_t lds = 4 * NPT * 16 + MT * 1024 + NPT * sizeof(float) + (a.epi == LD_EPI_GN_TAIL ? 2 * a.Cout * sizeof(float) + 64 * sizeof(double) : 0);
   const int HW = a.H * a.W;
   dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
   hipLaunchKernelGGL((conv1x1_kernel<T, MT, NW>), grid, dim3(256), lds, st, a);
@@ -277,7 +288,7 @@ extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
   LD_REQUIRE(p->Cout > 0 && p->Cout % 32 == 0, "ld_conv1x1: Cout %d must be a multiple of 32", p->Cout);
   LD_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->weight && p->out, "ld_conv1x1: bad shape/null");
   LD_REQUIRE(!(p->unshuffle && p->nsrc != 1), "ld_conv1x1: unshuffle takes one source");
-  LD_REQUIRE(p->epilogue >= LD_EPI_PLAIN && p->epilogue <= LD_EPI_RES, "ld_conv1x1: bad epilogue");
+  LD_REQUIRE(p->epilogue >= LD_EPI_PLAIN && p->epilogue <= LD_EPI_GN_TAIL, "ld_conv1x1: bad epilogue");
   if (p->epilogue == LD_EPI_QKV_LINEAR || p->epilogue == LD_EPI_QKV_FULL)
     LD_REQUIRE(p->hidden > 0 && p->hidden % 64 == 0 && p->Cout == 3 * p->hidden,
                "ld_conv1x1: QKV epilogue needs Cout == 3*hidden, hidden %% 64 == 0");
@@ -298,6 +309,15 @@ extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
   a.hidden = (p->epilogue == LD_EPI_QKV_LINEAR || p->epilogue == LD_EPI_QKV_FULL) ? p->hidden : 0;
   a.q_scale = p->q_scale; a.g2 = p->g2; a.res = p->residual; a.out = p->out;
   a.kmax = (p->epilogue == LD_EPI_QKV_LINEAR) ? p->kmax_out : nullptr;
+  if (p->epilogue == LD_EPI_GN_TAIL) {
+    const ld_src& t = p->gn_tail;
+    LD_REQUIRE(t.data && t.gn_stats && t.gn_gamma && t.gn_beta && t.gn_groups > 0 && t.C == p->Cout &&
+               t.C % t.gn_groups == 0 && (t.pix_stride == 0 || t.pix_stride == t.C) && !t.film,
+               "ld_conv1x1: GN_TAIL operand incomplete");
+    a.tail = to_dev(t);
+  } else {
+    a.tail = a.s[0];
+  }
   a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return p->dtype == LD_F32 ? dispatch<float>(a, st) : dispatch<bf16>(a, st);

@@ -206,27 +206,30 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const bf16* __restrict__ 
 
 // ------------------------------------------------------------------ reduce the chunk partials
 // grid = (heads, B, 4): ctxn[b,h,d,e] = sum_chunks ctx / sum_chunks Z[d]   (the k-softmax normaliser)
+constexpr int MAXCH = 128;               // chunks the reduce kernel can combine
 __global__ __launch_bounds__(256) void ctx_reduce_kernel(const float* __restrict__ ctx_part, int nchunks,
                                                          float* __restrict__ ctxn, int heads) {
   // partial c was accumulated against its own max m_c[d]; rescale to M[d] = max_c m_c[d]:
   //   ctx[d][e] = sum_c w_c[d] ctx_c[d][e],  Z[d] = sum_c w_c[d] Z_c[d],  w_c[d] = exp(m_c[d]-M[d])
-  __shared__ float s_w[8][33], s_zc[8][33], s_z[8];
+  __shared__ float s_w[8][MAXCH + 1], s_zc[8][MAXCH + 1], s_z[8];
   const int h = blockIdx.x, b = blockIdx.y, quarter = blockIdx.z, tid = threadIdx.x;
   const float* src = ctx_part + ((size_t)b * heads + h) * nchunks * CTX_STRIDE;
   const int i = quarter * 256 + tid;                     // element d*32+e; this block covers d = 8*quarter..+7
-  {                                                      // (d, chunk) table, one entry per thread (nchunks <= 32)
-    const int dl = tid >> 5, c = tid & 31, d = quarter * 8 + dl;
-    const bool ok = c < nchunks;
-    s_w[dl][c] = ok ? src[(size_t)c * CTX_STRIDE + 1056 + d] : -INFINITY;
-    s_zc[dl][c] = ok ? src[(size_t)c * CTX_STRIDE + 1024 + d] : 0.f;
+  {
+    const int dl = tid >> 5, d = quarter * 8 + dl;
+    for (int c = tid & 31; c < MAXCH; c += 32) {
+      const bool ok = c < nchunks;
+      s_w[dl][c] = ok ? src[(size_t)c * CTX_STRIDE + 1056 + d] : -INFINITY;
+      s_zc[dl][c] = ok ? src[(size_t)c * CTX_STRIDE + 1024 + d] : 0.f;
+    }
   }
   __syncthreads();
   if (tid < 8) {
     float M = -INFINITY;
-    for (int c = 0; c < 32; ++c) M = fmaxf(M, s_w[tid][c]);
+    for (int c = 0; c < nchunks; ++c) M = fmaxf(M, s_w[tid][c]);
     float z = 0.f;
-    for (int c = 0; c < 32; ++c) {
-      const float wgt = expf(s_w[tid][c] - M);           // exp(-inf) = 0 for unused chunk slots
+    for (int c = 0; c < nchunks; ++c) {
+      const float wgt = expf(s_w[tid][c] - M);
       s_w[tid][c] = wgt;
       z += wgt * s_zc[tid][c];
     }
@@ -319,7 +322,7 @@ extern "C" int ld_linattn_ctx(const void* qkv, const uint32_t* kmax_enc, float* 
 
 extern "C" int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* ctxn, int B, int heads,
                                      int dim_head, void* stream) {
-  LD_REQUIRE(ctx_part && ctxn && B > 0 && nchunks > 0 && nchunks <= 32 && heads > 0, "ld_linattn_ctx_reduce: bad args (nchunks 1..32)");
+  LD_REQUIRE(ctx_part && ctxn && B > 0 && nchunks > 0 && nchunks <= MAXCH && heads > 0, "ld_linattn_ctx_reduce: bad args (nchunks 1..128)");
   LD_REQUIRE(dim_head == 32, "ld_linattn_*: dim_head must be 32 (got %d)", dim_head);
   hipLaunchKernelGGL(ctx_reduce_kernel, dim3(heads, B, 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      ctx_part, nchunks, ctxn, heads);

@@ -15,6 +15,7 @@
 //        32s + 16(e>>2) + 4(lane>>4) + (e&3); ld_linattn_fold(perm=1) writes M_b in that order),
 //        + bias, RMSNorm, + x (ddpm.py:229-232,249,251,425).
 #include "common.cuh"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -197,6 +198,186 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// kvctx, wave-per-head schedule (heads == 4): one workgroup = (batch, pixel chunk); the x tile is staged
+// and RMS-normalised ONCE for all heads, and wave h computes k_h, v_h, P_h and the whole 32x32 context of
+// head h privately: its P/V rows go to a wave-private LDS strip and come back through transposed reads, so
+// the inner loop has no workgroup barrier at all (one per x tile), and the per-channel max of pass 0 is an
+// in-wave DPP reduction.  Emits the same partials as kvctx_kernel.
+constexpr int SROW = 32;                  // pixels per wave-private P/V strip (= one MFMA K-step)
+
+template <int NCH>
+__global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
+  constexpr int PLANE = KTN * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_x = smem;                                     // [NCH][4][KTN][16 B]
+  float* s_rinv = reinterpret_cast<float*>(s_x + NCH * 4 * PLANE);           // [KTN]
+  char* s_pv = reinterpret_cast<char*>(s_rinv + KTN);   // [4 waves][2 (P,V)][SROW][96 B]
+  const int ck = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kq = lane >> 4;
+  const int h = wv;
+  const int n = a.n, C = a.C;
+  const int npc = (n + a.nchunks - 1) / a.nchunks;
+  const int lo = ck * npc, hi = min(n, lo + npc);
+  uint4 A[4][NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) A[m][c] = a.wkv[(((size_t)h * NCH + c) * 4 + m) * 64 + lane];
+  float cmax[2][4], mloc[2][4], zs[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cmax[m][r] = -INFINITY; mloc[m][r] = 0.f; zs[m][r] = 0.f; }
+  f32x4 cacc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) cacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tq = (lane >> 2) & 3, tp = lane & 3;
+  const bf16* xb = a.x + (size_t)b * n * C;
+  char* my_p = s_pv + (wv * 2 + 0) * SROW * PROW;
+  char* my_v = s_pv + (wv * 2 + 1) * SROW * PROW;
+
+  uint4 xr[NCH][4];
+  auto issue = [&](int p0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int p = p0 + (it * 4 + wv) * 16 + li;
+        xr[c][it] = make_uint4(0u, 0u, 0u, 0u);
+        if (p < hi) xr[c][it] = *reinterpret_cast<const uint4*>(xb + (size_t)p * C + c * 32 + kq * 8);
+      }
+  };
+  issue(lo);
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int p0 = lo; p0 < hi; p0 += KTN) {
+      __syncthreads();                                   // every wave is done with the previous x tile
+      float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int qq = (it * 4 + wv) * 16 + li;
+          const uint4 raw = xr[c][it];
+          float v[8];
+          unpack16<bf16>(raw, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
+          *reinterpret_cast<uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16) = raw;
+        }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float r = rs[it];
+        r += __shfl_xor(r, 16);
+        r += __shfl_xor(r, 32);
+        if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = 1.0f / fmaxf(sqrtf(r), 1e-12f);
+      }
+      __syncthreads();
+      {
+        const int nxt = p0 + KTN;
+        if (nxt < hi) issue(nxt);
+        else if (pass == 0) issue(lo);
+      }
+      const int ngrp = min(KTN, hi - p0 + 15) / 16;      // 16-pixel groups that contain valid pixels
+      if (pass == 0) {
+        for (int g = 0; g < ngrp; ++g) {
+          const int qq = g * 16 + li;
+          f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
+            mma16<bf16>(k0, A[0][c], Bf);
+            mma16<bf16>(k1, A[1][c], Bf);
+          }
+          if (p0 + qq < hi) {
+            const float rinv = s_rinv[qq];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              cmax[0][r] = fmaxf(cmax[0][r], k0[r] * rinv);
+              cmax[1][r] = fmaxf(cmax[1][r], k1[r] * rinv);
+            }
+          }
+        }
+      } else {
+        for (int g2 = 0; g2 < (ngrp + 1) / 2; ++g2) {     // 32 pixels = one context K-step
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int qq = (g2 * 2 + half) * 16 + li;
+            const bool valid = (p0 + qq) < hi;
+            f32x4 acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
+#pragma unroll
+              for (int m = 0; m < 4; ++m) mma16<bf16>(acc[m], A[m][c], Bf);
+            }
+            const float rinv = s_rinv[qq];
+            const int row = half * 16 + li;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              float pv[4], vv[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                pv[r] = valid ? __expf(acc[m][r] * rinv - mloc[m][r]) : 0.f;
+                vv[r] = valid ? acc[2 + m][r] * rinv : 0.f;
+                zs[m][r] += pv[r];
+              }
+              *reinterpret_cast<uint2*>(my_p + row * PROW + (16 * m + 4 * kq) * 2) =
+                  make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+              *reinterpret_cast<uint2*>(my_v + row * PROW + (16 * m + 4 * kq) * 2) =
+                  make_uint2(pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3]));
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: own writes visible to own reads
+          const int row = kq * 4 + tq;
+          uint4 Af[2], Bf2[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const char* pa = my_p + row * PROW + t * 32 + tp * 8;
+            const char* pb = my_v + row * PROW + t * 32 + tp * 8;
+            const uint2 a1 = tr8(pa), a2 = tr8(pa + 16 * PROW);
+            const uint2 b1 = tr8(pb), b2 = tr8(pb + 16 * PROW);
+            Af[t] = make_uint4(a1.x, a1.y, a2.x, a2.y);
+            Bf2[t] = make_uint4(b1.x, b1.y, b2.x, b2.y);
+          }
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int et = 0; et < 2; ++et) mma16<bf16>(cacc[dt][et], Af[dt], Bf2[et]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the strip is rewritten
+        }
+      }
+    }
+    if (pass == 0) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mloc[m][r] = wave16_max(cmax[m][r]);
+    }
+  }
+  float* dst = a.ctx_part + (((size_t)b * a.heads + h) * a.nchunks + ck) * CTX_STRIDE;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(dt * 16 + kq * 4 + r) * 32 + et * 16 + li] = cacc[dt][et][r];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float z = wave16_sum(zs[m][r]);
+      if (li == 0) {
+        dst[1024 + 16 * m + 4 * kq + r] = z;
+        dst[1056 + 16 * m + 4 * kq + r] = mloc[m][r];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct LinOutArgs {
   const bf16* x;
   const uint4* wq;       // [NCH][8][64] fragments of W_q (g*sqrt(C) folded in)
@@ -328,8 +509,24 @@ extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, float* ct
   LD_REQUIRE(dim_head == 32 && (C == 32 || C == 64 || C == 128), "ld_linattn_kvctx: dim_head 32, C in {32,64,128}");
   KvCtxArgs a{(const bf16*)x, (const uint4*)wkv_packed, ctx_part, n, C, heads, nchunks};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid(nchunks, heads, B);
   const int nch = C / 32;
+  static const int no_wph = getenv("LD_KVCTX_V1") ? 1 : 0;
+  if (heads == 4 && !no_wph) {                           // wave-per-head schedule
+    const size_t lds2 = (size_t)nch * 4 * KTN * 16 + KTN * sizeof(float) + 4 * 2 * SROW * PROW;
+    static bool ok2[5] = {false, false, false, false, false};
+    dim3 grid2(nchunks, B);
+    if (nch == 1) {
+      hipLaunchKernelGGL(kvctx_wph_kernel<1>, grid2, dim3(256), lds2, st, a);
+    } else if (nch == 2) {
+      hipLaunchKernelGGL(kvctx_wph_kernel<2>, grid2, dim3(256), lds2, st, a);
+    } else {
+      if (!ok2[4]) { LD_HIP(ld_allow_lds(kvctx_wph_kernel<4>, lds2)); ok2[4] = true; }
+      hipLaunchKernelGGL(kvctx_wph_kernel<4>, grid2, dim3(256), lds2, st, a);
+    }
+    LD_LAUNCH_CHECK("linattn_kvctx(wave-per-head)");
+    return LD_OK;
+  }
+  dim3 grid(nchunks, heads, B);
   const size_t lds = (size_t)nch * 4 * KTN * 16 + 2 * KTN * PROW + KTN * sizeof(float) + 128 * sizeof(float);
   static bool allowed[5] = {false, false, false, false, false};
   if (nch == 1) {

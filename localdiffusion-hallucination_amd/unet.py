@@ -339,7 +339,7 @@ class _Plan:
         return out
 
     def conv1(self, ops, srcs, weight, cout, h, w, bias=None, epi=cabi.EPI_PLAIN, unshuffle=0, rms_in=0,
-              bstride=0, g2=None, residual=None, what="conv1x1", out=None, kmax_out=None):
+              bstride=0, g2=None, residual=None, what="conv1x1", out=None, kmax_out=None, gn_tail=None):
         a = cabi.Conv1x1Args()
         for i, s in enumerate(srcs):
             a.src[i] = s
@@ -349,13 +349,15 @@ class _Plan:
         a.epilogue, a.hidden, a.q_scale = epi, self.cfg.hidden, self.cfg.attn_dim_head ** -0.5
         a.g2, a.residual = cabi.ptr(g2), cabi.ptr(residual)
         a.kmax_out = cabi.ptr(kmax_out)
+        if gn_tail is not None:
+            a.gn_tail = gn_tail
         out = self.buf(h, w, cout) if out is None else out
         a.out = out.data_ptr()
         a.B, a.H, a.W, a.Cout, a.dtype = self.B, h, w, cout, self.dt
         self.keep += [weight, bias, g2, residual]
         cin = sum(s.C for s in srcs) * (4 if unshuffle else 1)
         npx = self.B * h * w
-        el = npx * cin + npx * cout + cin * cout * (self.B if bstride else 1) + (npx * cout if residual is not None else 0)
+        el = npx * cin + npx * cout + cin * cout * (self.B if bstride else 1) + (npx * cout if (residual is not None or gn_tail is not None) else 0)
         self._call(ops, self.lib.ld_conv1x1, a, what,
                    dict(family="conv1x1", bytes=el * self.esize, flops=2 * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"))
         return out
@@ -416,15 +418,15 @@ class _Plan:
             act1 = self.gn_apply(ops, n1, None, h, w, cout)
             n1 = self.src(act1, cout)
         raw2 = self.conv3(ops, [n1], p + ".block2.proj", cout, h, w, stats=s2, groups=G)
-        if (p + ".res_conv.weight") in f:
-            res = self.conv1(ops, srcs_fn(), self.P["w"][p + ".res_conv.weight"], cout, h, w,
-                             bias=f[p + ".res_conv.bias"], what="res_conv " + p)
-        else:
-            assert res_tensor is not None and cin_total == cout
-            res = res_tensor
         n2 = self.src(raw2, cout, gn=(s2, f[p + ".block2.norm.weight"], f[p + ".block2.norm.bias"], G),
                       act=cabi.ACT_SILU)
-        out = self.gn_apply(ops, n2, self.src(res, cout), h, w, cout)
+        if (p + ".res_conv.weight") in f:
+            # block tail fused into the res_conv epilogue: out = res_conv(x) + SiLU(GN(raw2))
+            out = self.conv1(ops, srcs_fn(), self.P["w"][p + ".res_conv.weight"], cout, h, w,
+                             bias=f[p + ".res_conv.bias"], epi=cabi.EPI_GN_TAIL, gn_tail=n2, what="res_conv+tail " + p)
+        else:
+            assert res_tensor is not None and cin_total == cout
+            out = self.gn_apply(ops, n2, self.src(res_tensor, cout), h, w, cout)
         self.named[p] = out
         return out
 
@@ -432,7 +434,8 @@ class _Plan:
         """bf16: q/k/v never materialised (csrc/linattn_fused.hip)."""
         f, cfg, lib = self.f32, self.cfg, self.lib
         n, hid, B, heads, dt, es = h * w, cfg.hidden, self.B, cfg.attn_heads, self.dt, self.esize
-        nchunks = max(1, min(32, n // 256))
+        # one workgroup per (batch, chunk) with a wave per head: 512-pixel chunks give >= 1024 workgroups at 256^2
+        nchunks = max(1, min(128, n // 512)) if heads == 4 else max(1, min(32, n // 256))
         ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, heads, 32, nchunks)), dtype=torch.float32, device=self.dev)
         ctxn = torch.empty(B, heads, 32, 32, dtype=torch.float32, device=self.dev)
         wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)

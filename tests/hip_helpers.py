@@ -75,7 +75,7 @@ def conv3x3(srcs, wpacked, bias, B, H, W, cout, dtype, stats=None, groups=8, t_p
 
 
 def conv1x1(srcs, wpacked, B, H, W, cout, dtype, bias=None, epi=0, unshuffle=0, rms_in=0, bstride=0, g2=None,
-            residual=None, hidden=128, kmax_out=None):
+            residual=None, hidden=128, kmax_out=None, gn_tail=None):
     a = cabi.Conv1x1Args()
     for i, s in enumerate(srcs):
         a.src[i] = s
@@ -84,6 +84,8 @@ def conv1x1(srcs, wpacked, B, H, W, cout, dtype, bias=None, epi=0, unshuffle=0, 
     a.epilogue, a.hidden, a.q_scale = epi, hidden, 32 ** -0.5
     a.g2, a.residual = cabi.ptr(g2), cabi.ptr(residual)
     a.kmax_out = cabi.ptr(kmax_out)
+    if gn_tail is not None:
+        a.gn_tail = gn_tail
     out = torch.empty(B, H, W, cout, dtype=TDT[dtype], device=DEV)
     a.out = out.data_ptr()
     a.B, a.H, a.W, a.Cout, a.dtype = B, H, W, cout, cabi.dtype_code(dtype)

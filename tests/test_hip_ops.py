@@ -434,3 +434,19 @@ def test_conv3x3_c32_persistent_path(dtype):
         out = hh.conv3x3([hh.make_src(hh.nhwc(x1, dtype), 32, ups=1), hh.make_src(hh.nhwc(x2, dtype), 32)],
                          hh.pack(w2, dtype, 3), b.to(hh.DEV), B, H, Wr, cout, dtype)
         assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv1x1_gn_tail_epilogue(dtype):
+    """ResnetBlock tail fused into res_conv: out = conv1x1(cat(x1,x2)) + SiLU(GN(raw2))."""
+    B, c1, c2, cout, H, W = 2, 64, 32, 64, 12, 10
+    x1, x2 = _q(hh.rand((B, c1, H, W), 223), dtype), _q(hh.rand((B, c2, H, W), 224), dtype)
+    raw2 = _q(hh.rand((B, cout, H, W), 225, -2, 3), dtype)
+    w, b = _q(hh.rand((cout, c1 + c2, 1, 1), 226, -0.2, 0.2), dtype), hh.rand((cout,), 227)
+    gamma, beta = hh.rand((cout,), 228, 0.5, 1.5), hh.rand((cout,), 229, -0.3, 0.3)
+    ref = F.conv2d(torch.cat([x1, x2], 1), w, b) + F.silu(F.group_norm(raw2, 8, gamma, beta))
+    gd, bd = gamma.to(hh.DEV), beta.to(hh.DEV)
+    tail = hh.make_src(hh.nhwc(raw2, dtype), cout, gn=(hh.stats_striped(raw2, 8), gd, bd, 8), act=cabi.ACT_SILU)
+    out = hh.conv1x1([hh.make_src(hh.nhwc(x1, dtype), c1), hh.make_src(hh.nhwc(x2, dtype), c2)], hh.pack(w, dtype, 1),
+                     B, H, W, cout, dtype, bias=b.to(hh.DEV), epi=cabi.EPI_GN_TAIL, gn_tail=tail)
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
