@@ -40,7 +40,7 @@ struct Conv3Dev {
   int dbg;     // ablation switches (LD_CONV_DEBUG env, 0 in production): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
 
-template <typename T, int MT, int NW>
+template <typename T, int MT, int NW, bool DEEP>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int TR = 4 * NW, TC = 16, HR = TR + 2, HC = TC + 2;
@@ -71,40 +71,55 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   // ---- register-staged pipeline (cdna_hip_programming.md T14): the global loads of chunk k+1
   // (halo fragments + weight fragments) are issued before the MFMAs of chunk k and written to LDS
   // after them, so a workgroup pays ONE exposed global round trip instead of one per chunk.
-  uint4 hx[ITER], wx[WU];
+  uint4 hxA[ITER], wxA[WU], hxB[DEEP ? ITER : 1], wxB[DEEP ? WU : 1];   // B set: prefetch distance 2 (DEEP)
+  // Loop-invariant addressing (with one wave per SIMD every VALU instruction in the chunk loop is on the
+  // critical path, PMC: MFMA busy ~20 % of wave cycles): per-thread element offsets of the halo pixels for
+  // both source geometries and of the weight units are computed once; a chunk only adds a scalar stride.
   unsigned hvalid = 0;                                  // bit it: halo item `it` is inside the image
-  auto issue_loads = [&](int ch) {
-    const int si = ch >= nch0 ? 1 : 0;
-    const SrcDev S = si ? a.s[1] : a.s[0];
-    const int c0 = (ch - si * nch0) * CK;
-    const T* sdata = reinterpret_cast<const T*>(S.data);
-    const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
-    hvalid = 0;
+  int hoff0[ITER], hoff1[ITER];
+  {
+    const SrcDev S0 = a.s[0], S1 = a.s[1];
+    const int Hs0 = S0.ups ? H / 2 : H, Ws0 = S0.ups ? W / 2 : W;
+    const int Hs1 = S1.ups ? H / 2 : H, Ws1 = S1.ups ? W / 2 : W;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int q = (it * 4 + wv) * 16 + px;
-      hx[it] = make_uint4(0u, 0u, 0u, 0u);
+      hoff0[it] = hoff1[it] = 0;
       if (q < NPIX) {
         const int hy = q / HC, hx_ = q - hy * HC;
         const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
         if (gy >= 0 && gy < H && gx >= 0 && gx < W && !(a.dbg & 1)) {
-          const int sy = S.ups ? gy >> 1 : gy, sx = S.ups ? gx >> 1 : gx;
-          hx[it] = *reinterpret_cast<const uint4*>(sdata + (((size_t)b * Hs + sy) * Ws + sx) * S.ld + c0 + kq * E);
           hvalid |= 1u << it;
+          hoff0[it] = ((b * Hs0 + (S0.ups ? gy >> 1 : gy)) * Ws0 + (S0.ups ? gx >> 1 : gx)) * S0.ld + kq * E;
+          hoff1[it] = ((b * Hs1 + (S1.ups ? gy >> 1 : gy)) * Ws1 + (S1.ups ? gx >> 1 : gx)) * S1.ld + kq * E;
         }
       }
     }
+  }
+  int woff[WU];
+#pragma unroll
+  for (int k = 0; k < WU; ++k) {
+    const int u = k * 256 + tid;
+    const int tap = u / (MT * 64), r = u - tap * (MT * 64);
+    woff[k] = (u < UNITS && !(a.dbg & 2)) ? (tap * mt_total + m0) * 64 + r : -1;
+  }
+  const int wstride = 9 * mt_total * 64;                // uint4 units per chunk
+  auto issue_loads = [&](int ch, uint4 (&hx)[ITER], uint4 (&wx)[WU]) {
+    const int si = ch >= nch0 ? 1 : 0;
+    const T* sdata = reinterpret_cast<const T*>(si ? a.s[1].data : a.s[0].data) + (ch - si * nch0) * CK;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      hx[it] = make_uint4(0u, 0u, 0u, 0u);
+      if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sdata + (si ? hoff1[it] : hoff0[it]));
+    }
+    const uint4* wc = wg + (size_t)ch * wstride;
 #pragma unroll
     for (int k = 0; k < WU; ++k) {
-      const int u = k * 256 + tid;
       wx[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (u < UNITS && !(a.dbg & 2)) {
-        const int tap = u / (MT * 64), r = u - tap * (MT * 64);
-        wx[k] = wg[(((size_t)ch * 9 + tap) * mt_total + m0) * 64 + r];
-      }
+      if (woff[k] >= 0) wx[k] = wc[woff[k]];
     }
   };
-  auto write_lds = [&](int ch) {
+  auto write_lds = [&](int ch, const uint4 (&hx)[ITER], const uint4 (&wx)[WU]) {
     const int si = ch >= nch0 ? 1 : 0;
     const SrcDev S = si ? a.s[1] : a.s[0];
     const int c0 = (ch - si * nch0) * CK;
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
     }
   };
 
-  issue_loads(0);
+  issue_loads(0, hxA, wxA);
   float4 bias[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + (m0 + m) * 16 + kq * 4);
@@ -167,14 +182,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();                 // previous chunk fully consumed (first time: coefficients visible)
-    write_lds(ch);
-    __syncthreads();
-    if (ch + 1 < nch) issue_loads(ch + 1);
-
-    // ---- MFMA
-    if (!(a.dbg & 4))
+  auto compute = [&]() {
+    if (a.dbg & 4) return;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       uint4 A[3][MT];
@@ -195,6 +204,33 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
             for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[dy][m], Bf);
           }
         }
+      }
+    }
+  };
+  if constexpr (!DEEP) {
+    for (int ch = 0; ch < nch; ++ch) {
+      __syncthreads();               // previous chunk fully consumed (first time: coefficients visible)
+      write_lds(ch, hxA, wxA);
+      __syncthreads();
+      if (ch + 1 < nch) issue_loads(ch + 1, hxA, wxA);
+      compute();
+    }
+  } else {
+    // prefetch distance 2 with two register sets (the launches that use this variant run one wave per SIMD,
+    // so the 512-entry register file is theirs): chunk k+2 is requested before chunk k is computed
+    if (nch > 1) issue_loads(1, hxB, wxB);
+    for (int ch = 0; ch < nch; ch += 2) {
+      __syncthreads();
+      write_lds(ch, hxA, wxA);
+      __syncthreads();
+      if (ch + 2 < nch) issue_loads(ch + 2, hxA, wxA);
+      compute();
+      if (ch + 1 < nch) {
+        __syncthreads();
+        write_lds(ch + 1, hxB, wxB);
+        __syncthreads();
+        if (ch + 3 < nch) issue_loads(ch + 3, hxB, wxB);
+        compute();
       }
     }
   }
@@ -250,7 +286,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   }
 }
 
-template <typename T, int MT, int NW>
+template <typename T, int MT, int NW, bool DEEP>
 int launch(const Conv3Dev& a, hipStream_t st) {
   constexpr int TR = 4 * NW, HR = TR + 2, HC = 18;
   constexpr int NPIXP = (HR * HC + 15) / 16 * 16;
@@ -258,14 +294,14 @@ int launch(const Conv3Dev& a, hipStream_t st) {
   const size_t lds = 4 * NPIXP * 16 + 9 * MT * 1024 + 2 * ctot * sizeof(float) + 4 * 2 * 16 * MT * sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
-    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW>, lds));
+    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP>, lds));
     allowed = lds;
   }
   Conv3Dev d = a;
   d.tiles_x = (a.W + 15) / 16;
   const int tiles_y = (a.H + TR - 1) / TR;
   dim3 grid(d.tiles_x * tiles_y, a.Cout / (16 * MT), a.B);
-  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NW>), grid, dim3(256), lds, st, d);
+  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NW, DEEP>), grid, dim3(256), lds, st, d);
   LD_LAUNCH_CHECK("conv3x3");
   return LD_OK;
 }
@@ -284,8 +320,17 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
   if (force_mt == 4 && (a.Cout % 64) == 0) mt4 = true;
   if (force_nw == 2) big = false;
   if (force_nw == 4) big = true;
-  if (mt4) return big ? launch<T, 4, 4>(a, st) : launch<T, 4, 2>(a, st);
-  return big ? launch<T, 2, 4>(a, st) : launch<T, 2, 2>(a, st);
+  static const int force_deep = getenv("LD_CONV_DEEP") ? atoi(getenv("LD_CONV_DEEP")) : -1;
+  const int ck = sizeof(T) == 4 ? 16 : 32;
+  const int nch = (a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0)) / ck;
+  const long wg = (long)((a.W + 15) / 16) * ((a.H + 7) / 8) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
+  // measured: distance-2 prefetch is within noise of distance 1 on every small-map shape (the waits there are
+  // barrier skew, not load latency), so it stays an opt-in experiment (LD_CONV_DEEP=1)
+  bool deep = false;
+  (void)nch; (void)wg;
+  if (force_deep >= 0) deep = force_deep != 0;
+  if (mt4) return big ? launch<T, 4, 4, false>(a, st) : (deep ? launch<T, 4, 2, true>(a, st) : launch<T, 4, 2, false>(a, st));
+  return big ? launch<T, 2, 4, false>(a, st) : (deep ? launch<T, 2, 2, true>(a, st) : launch<T, 2, 2, false>(a, st));
 }
 
 }  // namespace

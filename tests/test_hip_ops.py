@@ -192,7 +192,7 @@ def test_gn_apply_resblock_tail_and_basicblock_tail(dtype):
 
 # ------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("n_hw", [(7, 7), (16, 16), (32, 32)])
+@pytest.mark.parametrize("n_hw", [(7, 7), (16, 16), (32, 32), (64, 64)])
 def test_full_attention(dtype, n_hw):
     B, hid = 2, 128
     H, W = n_hw

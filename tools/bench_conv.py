@@ -29,7 +29,8 @@ def bench(B, cin, cout, H, W, dtype="bf16", stats=False, reps=50):
 if __name__ == "__main__":
     shapes = [(8, 32, 32, 256, 256), (8, 64, 32, 256, 256), (8, 32, 32, 128, 128), (8, 64, 64, 128, 128),
               (8, 64, 64, 64, 64), (8, 128, 128, 64, 64), (8, 128, 128, 32, 32), (8, 256, 256, 32, 32), (8, 512, 256, 32, 32)]
-    print("MT", os.environ.get("LD_CONV_MT", "-"), "NW", os.environ.get("LD_CONV_NW", "-"), "NO_C32", os.environ.get("LD_CONV_NO_C32", "-"))
-    for shape in shapes[:3]:
+    print("MT", os.environ.get("LD_CONV_MT", "-"), "NW", os.environ.get("LD_CONV_NW", "-"), "NO_C32", os.environ.get("LD_CONV_NO_C32", "-"), "DB", os.environ.get("LD_CONV_DB", "-"))
+    sel = shapes[:3] if not os.environ.get("LD_BENCH_SMALL") else shapes[3:]
+    for shape in sel:
         bench(*shape)
         bench(*shape, stats=True)
