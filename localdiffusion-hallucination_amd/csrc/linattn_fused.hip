@@ -378,6 +378,8 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+constexpr int LINOUT_TPB = 1;             // pixel tiles (of 128) per workgroup in linout_kernel (4 measured slower: fewer workgroups)
+
 struct LinOutArgs {
   const bf16* x;
   const uint4* wq;       // [NCH][8][64] fragments of W_q (g*sqrt(C) folded in)
@@ -397,13 +399,18 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
   char* s_wq = s_x + NCH * 4 * PLANE;                    // [NCH][8][1 KiB]
   char* s_mf = s_wq + NCH * 8 * 1024;                    // [4][MT2][1 KiB]
   float* s_rinv = reinterpret_cast<float*>(s_mf + 4 * MT2 * 1024);
-  const int b = blockIdx.y, p0 = blockIdx.x * NPT;
+  const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kq = lane >> 4;
   const int n = a.n, C = a.C;
   const bf16* xb = a.x + (size_t)b * n * C;
+  // W_q and M_b are staged once per workgroup and reused for LINOUT_TPB consecutive pixel tiles
   for (int u = tid; u < NCH * 8 * 64; u += 256) *reinterpret_cast<uint4*>(s_wq + u * 16) = a.wq[u];
   const uint4* mf = a.mfold + (size_t)b * 4 * MT2 * 64;
   for (int u = tid; u < 4 * MT2 * 64; u += 256) *reinterpret_cast<uint4*>(s_mf + u * 16) = mf[u];
+  for (int tl = 0; tl < LINOUT_TPB; ++tl) {
+  const int p0 = (blockIdx.x * LINOUT_TPB + tl) * NPT;
+  if (p0 >= n) break;
+  if (tl > 0) __syncthreads();                          // previous tile's x / rinv fully consumed
   float rs[NW];
 #pragma unroll
   for (int i = 0; i < NW; ++i) rs[i] = 0.f;
@@ -499,6 +506,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
       }
     }
   }
+  }  // tiles of this workgroup
 }
 }  // namespace
 
@@ -550,7 +558,7 @@ extern "C" int ld_linattn_out(const void* x, const void* wq_packed, const void* 
   LD_REQUIRE(C == 32 || C == 64 || C == 128, "ld_linattn_out: C in {32,64,128}");
   LinOutArgs a{(const bf16*)x, (const uint4*)wq_packed, (const uint4*)mfold, bias, g2, (bf16*)out, n, C, q_scale};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid((n + 127) / 128, B);
+  dim3 grid((n + 128 * LINOUT_TPB - 1) / (128 * LINOUT_TPB), B);
   const int nch = C / 32;
   const size_t lds = (size_t)nch * 4 * 128 * 16 + (size_t)nch * 8 * 1024 + (size_t)4 * 2 * nch * 1024 + 128 * sizeof(float);
   static bool allowed[5] = {false, false, false, false, false};
