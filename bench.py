@@ -244,7 +244,7 @@ def main():
                      "path_frac": value / world * ALGO_TB_PER_PATCH * 1e3 / HBM_PEAK_GBS,
                      "families_ms_per_step": {k: round(v["ms"] / 5, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}})
         out["roofline"] = roof
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:        # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(net.cfg, sd, H)
     if rank == 0:
         print(json.dumps(out))

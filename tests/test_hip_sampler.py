@@ -122,3 +122,16 @@ def test_graph_replay_matches_eager():
     assert np.isfinite(graph).all()
     assert float(np.abs(graph - eager).max()) < 1e-5
     assert np.array_equal(graph, again)
+
+
+def test_eval_driver_matches_cfg1_golden(golden, tmp_path):
+    """evalio.evaluate (test.py-equivalent loop) on the 4 golden digits == the reference's cfg1 output."""
+    from localdiffusion_hallucination_amd import evalio
+    g = golden("g4_cfg1_mnist")
+    hr, lr = evalio.mnist_pairs(g["digits"])
+    gd = make(MNIST, dict(data="mnist", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True, ood_AD=True), 28, 100)
+    res = evalio.evaluate(gd, hr, lr, evalio.band_mask(4, 28, 28, 7), (0.0, 2.0), out_dir=str(tmp_path), batch_size=4)
+    check("eval driver cfg1", res["pred"], g["final"])
+    assert abs(res["test_loss"] - float(np.mean((g["final"] - g["hr"]) ** 2))) < 1e-4
+    for f in ("hr_all.npy", "lr_all.npy", "pred_all.npy", "ad_masks.npy"):
+        assert (tmp_path / f).exists()
