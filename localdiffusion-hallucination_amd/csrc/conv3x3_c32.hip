@@ -192,24 +192,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
     }
     const char* xb = s_x + buf * XBUF;
     const char* wb = s_w + ch * WCH;
+    {   // fragment reads of tap column dx+1 are in flight during the MFMAs of column dx (see conv3x3.hip)
+      uint4 A[2][3][MT], Bq[2][NW + 2];
+      auto load_frags = [&](int dx, int set) {
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      uint4 A[3][MT];
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+          for (int m = 0; m < MT; ++m)
+            A[set][dy][m] = *reinterpret_cast<const uint4*>(wb + ((dy * 3 + dx) * MT + m) * 1024 + lane * 16);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-          A[dy][m] = *reinterpret_cast<const uint4*>(wb + ((dy * 3 + dx) * MT + m) * 1024 + lane * 16);
+        for (int rr = 0; rr < NW + 2; ++rr) {
+          const int q = (wv * NW + rr) * HC + dx + px;
+          Bq[set][rr] = *reinterpret_cast<const uint4*>(xb + ((q >> 4) << 10) + kq * 256 + ((q & 15) << 4));
+        }
+      };
+      load_frags(0, 0);
 #pragma unroll
-      for (int rr = 0; rr < NW + 2; ++rr) {
-        const int q = (wv * NW + rr) * HC + dx + px;
-        const uint4 Bf = *reinterpret_cast<const uint4*>(xb + ((q >> 4) << 10) + kq * 256 + ((q & 15) << 4));
+      for (int dx = 0; dx < 3; ++dx) {
+        if (dx + 1 < 3) load_frags(dx + 1, (dx + 1) & 1);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const int j = rr - dy;
-          if (j >= 0 && j < NW) {
+        for (int rr = 0; rr < NW + 2; ++rr) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[dy][m], Bf);
+          for (int dy = 0; dy < 3; ++dy) {
+            const int j = rr - dy;
+            if (j >= 0 && j < NW) {
+#pragma unroll
+              for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[dx & 1][dy][m], Bq[dx & 1][rr]);
+            }
           }
         }
       }
