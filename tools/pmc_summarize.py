@@ -20,6 +20,9 @@ def load(d, counter):
 
 def family(name):
     import re
+    m = re.search(r"conv3x3_c32_kernelI(f|DF16b)E", name)      # persistent variant of the <.,2,4> family
+    if m:
+        return f"conv3x3<{'f32' if m.group(1) == 'f' else 'bf16'},2,4>"
     m = re.search(r"conv3x3_kernelI(f|DF16b)Li(\d)ELi(\d)E", name)
     if m:
         return f"conv3x3<{'f32' if m.group(1) == 'f' else 'bf16'},{m.group(2)},{m.group(3)}>"
