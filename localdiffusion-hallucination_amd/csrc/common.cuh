@@ -119,15 +119,49 @@ template <> __device__ __forceinline__ void mma16<bf16>(f32x4& acc, const uint4&
                                                  __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------- LDS-DMA
+// global_load_lds_dwordx4 as inline asm: 64 lanes x 16 B land at lds_dst + lane*16 (lds_dst wave-uniform).
+// Issued through the builtin, hipcc orders every later LDS access of the wave behind the DMA with
+// s_waitcnt vmcnt(0) (it cannot prove the ds_read does not alias the DMA destination), which serialises the
+// ring; the asm form is invisible to that bookkeeping, so completion is tracked by hand: the issuing wave's
+// counted s_waitcnt vmcnt(N), then a barrier, then the reads (cdna_hip_programming.md "What hipcc does not do").
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)p;            // low 32 bits of a flat LDS address = byte offset in the workgroup's LDS
+}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // ---------------------------------------------------------------- activations
 template <bool PRECISE> __device__ __forceinline__ float silu_f(float v) {
+  // parity mode: libm expf + IEEE divide.  Storage-bf16 mode: v_exp_f32 / v_rcp_f32 (1 ulp each, far below the
+  // bf16 rounding of the result); __frcp_rn would expand to the 11-instruction IEEE division sequence.
   if constexpr (PRECISE) return v / (1.0f + expf(-v));
-  else return v * __frcp_rn(1.0f + __expf(-v));
+  else return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 template <bool PRECISE> __device__ __forceinline__ float act_f(float v, int act) {
   if (act == LD_ACT_SILU) return silu_f<PRECISE>(v);
   if (act == LD_ACT_RELU) return fmaxf(v, 0.0f);
   return v;
+}
+// v[e] = act(v[e]) for N values with ONE (wave-uniform) switch on `act`: called per element, the switch is not
+// hoisted by hipcc and every element pays scalar compares and branches that also split the VALU schedule.
+template <bool PRECISE, int N> __device__ __forceinline__ void act_n(float* v, int act) {
+  if (act == LD_ACT_SILU) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = silu_f<PRECISE>(v[e]);
+  } else if (act == LD_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.0f);
+  }
+}
+// v[e] = act(v[e]*a[e] + s[e])
+template <bool PRECISE, int N> __device__ __forceinline__ void affine_act_n(float* v, const float* a, const float* s, int act) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) v[e] = fmaf(v[e], a[e], s[e]);
+  act_n<PRECISE, N>(v, act);
 }
 
 // ---------------------------------------------------------------- normalise-on-load coefficients

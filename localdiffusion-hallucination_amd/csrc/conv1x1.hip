@@ -219,9 +219,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
         } else if (a.epi == LD_EPI_GN_TAIL) {
           float rv[4];
           load4<T>(reinterpret_cast<const T*>(a.tail.data) + o, rv);
+          affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            v[m][r] += act_f<DT<T>::precise>(fmaf(rv[r], s_tcoef[co + r], s_tcoef[a.Cout + co + r]), a.tail.act);
+          for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
         }
         store4<T>(out + o, v[m]);
       }

@@ -140,8 +140,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
         if (has_coef && ((hvalid >> it) & 1u)) {        // zero padding stays exactly zero
           float v[E];
           unpack16<T>(raw, v);
-#pragma unroll
-          for (int e = 0; e < E; ++e) v[e] = act_f<P>(fmaf(v[e], ca[e], cs[e]), S.act);
+          affine_act_n<P, E>(v, ca, cs, S.act);
           raw = pack16<T>(v);
         }
         *reinterpret_cast<uint4*>(s_x + kq * PLANE + q * 16) = raw;

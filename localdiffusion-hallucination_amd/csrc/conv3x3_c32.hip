@@ -34,6 +34,7 @@ struct C32Dev {
   int B, H, W;
   const int* t_ptr;
   int tiles_x, ntiles;
+  int dbg;     // LD_CONV_DEBUG ablation bits (0 in production): 1 no DMA, 4 no MFMA, 8 no stores, 16 no transform
 };
 
 template <typename T>
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
 
   // ---- DMA of one (tile, chunk) item into buffer `buf`: wave wv owns plane kq = wv
   auto dma = [&](int item, int buf) {
+    if (a.dbg & 1) return;
     const int ti = item / nch, ch = item - ti * nch;
     const int tile = blockIdx.x + ti * G;
     const int ty0 = (tile / a.tiles_x) * TR, tx0 = (tile % a.tiles_x) * TC;
@@ -115,8 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
           }
         }
         if (inb) {
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(sdata + idx),
-                                           (void __attribute__((address_space(3)))*)(xb + blk * 1024), 16, 0, 0);
+          glds16(sdata + idx, __builtin_amdgcn_readfirstlane(lds_addr(xb + blk * 1024)));
         } else {
           *reinterpret_cast<uint4*>(xb + blk * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
     const int ti = item / nch, ch = item - ti * nch;
     const int si = ch >= nch0 ? 1 : 0;
     const SrcDev S = si ? a.s[1] : a.s[0];
-    if (S.stats == nullptr) return false;
+    if (S.stats == nullptr || (a.dbg & 16)) return false;
     const int tile = blockIdx.x + ti * G;
     const int ty0 = (tile / a.tiles_x) * TR, tx0 = (tile % a.tiles_x) * TC;
     const int c0 = (ch - si * nch0) * CK;
@@ -149,8 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
           uint4 raw = *reinterpret_cast<const uint4*>(ptr);
           float v[E];
           unpack16<T>(raw, v);
-#pragma unroll
-          for (int e = 0; e < E; ++e) v[e] = act_f<P>(fmaf(v[e], ca[e], cs[e]), S.act);
+          affine_act_n<P, E>(v, ca, cs, S.act);
           *reinterpret_cast<uint4*>(ptr) = pack16<T>(v);
         }
       }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
     }
     const char* xb = s_x + buf * XBUF;
     const char* wb = s_w + ch * WCH;
-    {   // fragment reads of tap column dx+1 are in flight during the MFMAs of column dx (see conv3x3.hip)
+    if (!(a.dbg & 4)) {   // fragment reads of tap column dx+1 are in flight during the MFMAs of column dx (see conv3x3.hip)
       uint4 A[2][3][MT], Bq[2][NW + 2];
       auto load_frags = [&](int dx, int set) {
 #pragma unroll
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
       const int ty0 = (tile / a.tiles_x) * TR, tx0 = (tile % a.tiles_x) * TC;
       const int gx = tx0 + px;
       // all 8 store instructions execute in this wave iff its 4 rows are inside the image (uniform test)
-      stores_behind = (ty0 + wv * NW + NW <= H) && (i + 1 < total);
+      stores_behind = (ty0 + wv * NW + NW <= H) && (i + 1 < total) && !(a.dbg & 8);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int co = m * 16 + kq * 4;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
           const int gy = ty0 + wv * NW + j;
           if (gy < H && gx < W) {
             float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
-            store4<T>(out + (((size_t)b * H + gy) * W + gx) * 32 + co, v);
+            if (!(a.dbg & 8)) store4<T>(out + (((size_t)b * H + gy) * W + gx) * 32 + co, v);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
           }
@@ -315,6 +315,8 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   a.w = p->weight; a.bias = p->bias; a.out = p->out; a.ostats = p->out_stats;
   a.ogroups = p->out_groups > 0 ? p->out_groups : 1;
   a.B = p->B; a.H = p->H; a.W = p->W; a.t_ptr = p->t_ptr; a.tiles_x = a.ntiles = 0;
+  static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
+  a.dbg = dbg;
   const int rc = p->dtype == LD_F32 ? launch_c32<float>(a, st) : launch_c32<bf16>(a, st);
   return rc == LD_OK ? 1 : rc;
 }

@@ -26,22 +26,17 @@ __device__ __forceinline__ void eval_pixel(const GnDev& g, const float* coefA, c
   const T* xa = reinterpret_cast<const T*>(g.a.data);
   uint4 ra = *reinterpret_cast<const uint4*>(xa + pix * C + c);
   unpack16<T>(ra, v);
-#pragma unroll
-  for (int e = 0; e < E; ++e) v[e] = act_f<P>(fmaf(v[e], coefA[c + e], coefA[C + c + e]), g.a.act);
+  affine_act_n<P, E>(v, coefA + c, coefA + C + c, g.a.act);
   if (g.has_b) {
     const T* xb = reinterpret_cast<const T*>(g.b.data);
     uint4 rb = *reinterpret_cast<const uint4*>(xb + pix * C + c);
     float u[E];
     unpack16<T>(rb, u);
-    if (g.b.stats) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) u[e] = act_f<P>(fmaf(u[e], coefB[c + e], coefB[C + c + e]), g.b.act);
-    }
+    if (g.b.stats) affine_act_n<P, E>(u, coefB + c, coefB + C + c, g.b.act);
 #pragma unroll
     for (int e = 0; e < E; ++e) v[e] += u[e];
   }
-#pragma unroll
-  for (int e = 0; e < E; ++e) v[e] = act_f<P>(v[e], g.final_act);
+  act_n<P, E>(v, g.final_act);
 }
 
 template <typename T>
