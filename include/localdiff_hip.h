@@ -196,14 +196,25 @@ int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* ctxn, int B
 int ld_linattn_fold(const float* ctxn, const float* w_out /*[C,hidden] fp32*/,
                     void* w_packed /*[B] packed C x hidden*/, int B, int C, int heads, int dim_head,
                     int perm, int dtype, void* stream);
+/* Steps 3 + 4 in one launch (grid heads x B x 4): chunk partials -> 8 rows of the normalised context (kept in
+ * LDS) -> the matching 8 columns of the packed M_b.  Same arithmetic and output layout as the two calls above. */
+int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const float* w_out /*[C,hidden] fp32*/,
+                       void* w_packed /*[B] packed C x hidden*/, int B, int C, int heads, int dim_head,
+                       int perm, int dtype, void* stream);
 /* Fused bf16 path: q, k, v never reach HBM (both kernels recompute their slice of to_qkv from x).
  *   ld_linattn_kvctx: x [B,n,C] -> ctx partials (same layout/consumers as ld_linattn_ctx), with the
  *        RMSNorm (ddpm.py:237), the k/v rows of to_qkv (:239) and softmax_n(k) (:243) inside;
  *        wkv_packed = per head the 64 rows (k_h | v_h) of to_qkv, packed k=1 with g*sqrt(C) folded.
+ *        kshift (optional, [heads*32] fp32, heads == 4): an upper bound m_d >= max_n k[d] per k channel.
+ *        softmax over n is shift-invariant, so exp(k - m_d) / sum_n exp(k - m_d) equals the reference's
+ *        exp(k - max) form; with it the kernel makes ONE sweep over x instead of two.  The RMS-normalised
+ *        input has unit 2-norm per pixel, hence |k_d| <= ||W_k[d,:] * g * sqrt(C)||_2 (Cauchy-Schwarz): the
+ *        host passes that norm, and passes NULL (exact two-sweep maximum) when it exceeds 40, where
+ *        exp(k - m_d) could underflow.
  *   ld_linattn_out:   x -> out = RMSNorm(to_out(ctx^T softmax_d(q)*scale)) + x  (:242,245,249,251,425);
  *        wq_packed = the 128 q rows packed the same way, mfold from ld_linattn_fold(perm=1). */
-int ld_linattn_kvctx(const void* x, const void* wkv_packed, float* ctx_part, int B, int n, int C,
-                     int heads, int dim_head, int nchunks, int dtype, void* stream);
+int ld_linattn_kvctx(const void* x, const void* wkv_packed, const float* kshift, float* ctx_part, int B,
+                     int n, int C, int heads, int dim_head, int nchunks, int dtype, void* stream);
 int ld_linattn_out(const void* x, const void* wq_packed, const void* mfold, const float* bias,
                    const float* g2, void* out, int B, int n, int C, float q_scale, int dtype,
                    void* stream);

@@ -273,7 +273,94 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctx
   }
 }
 
+// ------------------------------------------------------------------ reduce + fold in one launch
+// grid = (heads, B, 4): combines the chunk partials of 8 k-channels d of one (batch, head) (ctx_reduce_kernel's
+// arithmetic), keeps the normalised 8x32 context slice in LDS and immediately folds it into the 8 columns
+// h*32+d of M_b = W_out . blockdiag(ctx^T) (fold_kernel's arithmetic and output order): a column of M_b only
+// needs row d of the context, so the quarters are independent.  Two dependent launches of ~10-25 us of latency
+// each become one; the chunk loop keeps 16 loads per thread in flight.
+template <typename T>
+__global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ ctx_part, int nchunks,
+                                                      const float* __restrict__ w_out, T* __restrict__ w_packed,
+                                                      int C, int heads, int perm) {
+  constexpr int E = DT<T>::E, CK = DT<T>::CK;
+  __shared__ float s_w[8][MAXCH + 1], s_z[8], s_ctx[8 * 33];
+  const int h = blockIdx.x, b = blockIdx.y, quarter = blockIdx.z, tid = threadIdx.x;
+  const float* src = ctx_part + ((size_t)b * heads + h) * nchunks * CTX_STRIDE;
+  const int dl = tid >> 5, sub = tid & 31, d = quarter * 8 + dl;
+  {   // per k-channel d (32 threads each): global max of the chunk maxima, rescale weights, Z
+    float mc[MAXCH / 32], zc[MAXCH / 32];
+    float M = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXCH / 32; ++k) {
+      const int c = k * 32 + sub;
+      const bool ok = c < nchunks;
+      mc[k] = ok ? src[(size_t)c * CTX_STRIDE + 1056 + d] : -INFINITY;
+      zc[k] = ok ? src[(size_t)c * CTX_STRIDE + 1024 + d] : 0.f;
+      M = fmaxf(M, mc[k]);
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) M = fmaxf(M, __shfl_xor(M, o));
+    float z = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXCH / 32; ++k) {
+      const int c = k * 32 + sub;
+      const float wgt = c < nchunks ? expf(mc[k] - M) : 0.f;
+      s_w[dl][c] = wgt;
+      z += wgt * zc[k];
+    }
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) z += __shfl_xor(z, o);
+    if (sub == 0) s_z[dl] = z;
+  }
+  __syncthreads();
+  {
+    const int i = quarter * 256 + tid;                   // element d*32+e of the head's context
+    float s = 0.f;
+    for (int c0 = 0; c0 < nchunks; c0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = (c0 + k < nchunks) ? src[(size_t)(c0 + k) * CTX_STRIDE + i] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s = fmaf(s_w[dl][c0 + k < nchunks ? c0 + k : 0], v[k], s);
+    }
+    s_ctx[dl * 33 + sub] = s / s_z[dl];
+  }
+  __syncthreads();
+  const int hidden = heads * 32, mt_total = C / 16;
+  T* dst = w_packed + (size_t)b * C * hidden;
+  for (int idx = tid; idx < C * 8; idx += 256) {
+    const int co = idx >> 3, d8 = idx & 7, ci = h * 32 + quarter * 8 + d8;
+    const float* wrow = w_out + (size_t)co * hidden + h * 32;
+    const float* crow = s_ctx + d8 * 33;
+    float m = 0.f;
+#pragma unroll 8
+    for (int e = 0; e < 32; ++e) m = fmaf(wrow[e], crow[e], m);
+    const int mt = co >> 4, ii = co & 15;
+    int ch = ci / CK, kq = (ci % CK) / E, e = ci % E;
+    if (perm) { ch = ci >> 5; kq = (ci >> 2) & 3; e = ((ci >> 4) & 1) * 4 + (ci & 3); }
+    dst[((((size_t)ch * mt_total + mt) * 4 + kq) * 16 + ii) * E + e] = from_f<T>(m);
+  }
+}
+
 }  // namespace
+
+extern "C" int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const float* w_out, void* w_packed, int B, int C,
+                                  int heads, int dim_head, int perm, int dtype, void* stream) {
+  LD_REQUIRE(ctx_part && w_out && w_packed && B > 0 && heads > 0 && nchunks > 0 && nchunks <= MAXCH,
+             "ld_linattn_ctxfold: bad args (nchunks 1..128)");
+  LD_REQUIRE(dim_head == 32 && C % 16 == 0, "ld_linattn_ctxfold: dim_head 32, C %% 16 == 0");
+  LD_REQUIRE(!(perm && dtype != LD_BF16), "ld_linattn_ctxfold: perm=1 is the bf16 chained-operand order");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == LD_F32)
+    hipLaunchKernelGGL(ctxfold_kernel<float>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (float*)w_packed, C, heads, perm);
+  else if (dtype == LD_BF16)
+    hipLaunchKernelGGL(ctxfold_kernel<bf16>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (bf16*)w_packed, C, heads, perm);
+  else
+    return ld_fail(LD_EINVAL, "ld_linattn_ctxfold: bad dtype %d", dtype);
+  LD_LAUNCH_CHECK("linattn_ctxfold");
+  return LD_OK;
+}
 
 extern "C" size_t ld_linattn_ctx_part_floats(int B, int heads, int dim_head, int nchunks) {
   (void)dim_head;

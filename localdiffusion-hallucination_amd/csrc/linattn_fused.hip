@@ -34,6 +34,7 @@ struct KvCtxArgs {
   const uint4* wkv;     // [heads][NCH][4 tiles: k0 k1 v0 v1][64] fragments (g*sqrt(C) folded in)
   float* ctx_part;
   int n, C, heads, nchunks;
+  const float* kshift;   // optional [heads*32]: softmax_n(k) shift per k-channel (>= max_n k): single-sweep mode
 };
 
 template <int NCH>
@@ -250,7 +251,17 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
       }
   };
   issue(lo);
-  for (int pass = 0; pass < 2; ++pass) {
+  // softmax over n is shift-invariant: with a caller-supplied bound m_d >= max_n k_d (the Cauchy-Schwarz bound
+  // ||W_k[d] g sqrt(C)||_2 of the RMS-normalised input, computed once at weight-packing time) the max sweep
+  // (pass 0) is skipped and every chunk's partial is already on the same scale.
+  const int first_pass = a.kshift ? 1 : 0;
+  if (a.kshift) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mloc[m][r] = a.kshift[h * 32 + 16 * m + 4 * kq + r];
+  }
+  for (int pass = first_pass; pass < 2; ++pass) {
     for (int p0 = lo; p0 < hi; p0 += KTN) {
       __syncthreads();                                   // every wave is done with the previous x tile
       float rs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -510,16 +521,17 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
 }
 }  // namespace
 
-extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, float* ctx_part, int B, int n, int C,
-                                int heads, int dim_head, int nchunks, int dtype, void* stream) {
+extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const float* kshift, float* ctx_part, int B,
+                                int n, int C, int heads, int dim_head, int nchunks, int dtype, void* stream) {
   LD_REQUIRE(x && wkv_packed && ctx_part && B > 0 && n > 0 && nchunks > 0, "ld_linattn_kvctx: bad args");
   LD_REQUIRE(dtype == LD_BF16, "ld_linattn_kvctx: bf16 storage only (fp32 uses the unfused path)");
   LD_REQUIRE(dim_head == 32 && (C == 32 || C == 64 || C == 128), "ld_linattn_kvctx: dim_head 32, C in {32,64,128}");
-  KvCtxArgs a{(const bf16*)x, (const uint4*)wkv_packed, ctx_part, n, C, heads, nchunks};
+  LD_REQUIRE(kshift == nullptr || heads == 4, "ld_linattn_kvctx: the single-sweep mode (kshift) needs heads == 4");
+  KvCtxArgs a{(const bf16*)x, (const uint4*)wkv_packed, ctx_part, n, C, heads, nchunks, kshift};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nch = C / 32;
   static const int no_wph = getenv("LD_KVCTX_V1") ? 1 : 0;
-  if (heads == 4 && !no_wph) {                           // wave-per-head schedule
+  if (heads == 4 && (!no_wph || kshift)) {               // wave-per-head schedule
     const size_t lds2 = (size_t)nch * 4 * KTN * 16 + KTN * sizeof(float) + 4 * 2 * SROW * PROW;
     static bool ok2[5] = {false, false, false, false, false};
     dim3 grid2(nchunks, B);

@@ -16,6 +16,7 @@ the plan computes the same function (fp32 mode agrees with the reference to ~1e-
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -163,7 +164,7 @@ class Unet(nn.Module):
                 continue                                  # folded per batch with ctx (ld_linattn_fold)
             else:
                 pack(name, k)
-        P["wq"], P["wkv"] = {}, {}
+        P["wq"], P["wkv"], P["kshift"] = {}, {}, {}
         if self.compute_dtype == "bf16":
             hid, heads = self.cfg.hidden, self.cfg.attn_heads
             for name, w in sd.items():
@@ -189,6 +190,12 @@ class Unet(nn.Module):
                     kv = torch.cat([w[hid + 32 * h: hid + 32 * h + 32], w[2 * hid + 32 * h: 2 * hid + 32 * h + 32]], 0)
                     per_head.append(pack_rows(kv))
                 P["wkv"][base] = torch.cat(per_head).contiguous()
+                # softmax_n(k) shift for the single-sweep kernel: the RMS-normalised pixel has unit 2-norm, so
+                # |k_d| <= ||W_k[d,:] * g * sqrt(C)||_2 (of the storage-rounded weights, + 1 % slack).  Above 40
+                # exp(k - bound) could underflow in fp32: fall back to the exact two-sweep maximum (None).
+                wk = (w[hid:2 * hid, :, 0, 0].float() * scale[None, :]).to(tdt).float()
+                bound = wk.norm(dim=1) * 1.01
+                P["kshift"][base] = bound.contiguous() if float(bound.max()) <= 40.0 else None
                 P["keep"].append(scale)
         for name, w in sd.items():
             if name.endswith(".to_out.1.g"):
@@ -435,24 +442,25 @@ class _Plan:
         f, cfg, lib = self.f32, self.cfg, self.lib
         n, hid, B, heads, dt, es = h * w, cfg.hidden, self.B, cfg.attn_heads, self.dt, self.esize
         # one workgroup per (batch, chunk) with a wave per head: 512-pixel chunks give >= 1024 workgroups at 256^2
-        nchunks = max(1, min(128, n // 512)) if heads == 4 else max(1, min(32, n // 256))
+        # pixels per kvctx workgroup (measured, cfg3: 512 best up to 128^2; 1024 halves the partials at 256^2)
+        chunk_px = int(os.environ.get("LD_LINATTN_CHUNK_PX", "1024" if n >= 65536 else "512"))
+        nchunks = max(1, min(128, n // chunk_px)) if heads == 4 else max(1, min(32, n // 256))
         ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, heads, 32, nchunks)), dtype=torch.float32, device=self.dev)
-        ctxn = torch.empty(B, heads, 32, 32, dtype=torch.float32, device=self.dev)
         wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)
         wout = f[p + ".to_out.0.weight"].reshape(c, hid).contiguous()
         wq, wkv = self.P["wq"][p], self.P["wkv"][p]
+        kshift = self.P["kshift"].get(p) if heads == 4 else None
+        ksp = kshift.data_ptr() if kshift is not None else None
         bias, g2 = f[p + ".to_out.0.bias"], self.P["g2"][p + ".to_out.1.g"]
         out = self.buf(h, w, c)
-        self.keep += [ctx, ctxn, wfold, wout, wq, wkv, bias, g2, out, x]
+        self.keep += [ctx, wfold, wout, wq, wkv, kshift, bias, g2, out, x]
         npx = B * n
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_kvctx(x.data_ptr(), wkv.data_ptr(), ctx.data_ptr(), B, n, c,
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_kvctx(x.data_ptr(), wkv.data_ptr(), ksp, ctx.data_ptr(), B, n, c,
                                                                   heads, 32, nchunks, dt, st), "linattn_kvctx"),
-                  "linattn_kvctx", nbytes=npx * c * es, flops=2 * npx * c * 2 * hid * 2 + 2 * npx * hid * 32)
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, heads,
-                                                                       32, st), "linattn_ctx_reduce"), "linattn_ctx_reduce")
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(), wfold.data_ptr(), B, c,
-                                                                 heads, 32, 1, dt, st), "linattn_fold"),
-                  "linattn_fold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
+                  "linattn_kvctx", nbytes=npx * c * es, flops=2 * npx * c * 2 * hid * (1 if kshift is not None else 2) + 2 * npx * hid * 32)
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctxfold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold.data_ptr(), B, c,
+                                                                    heads, 32, 1, dt, st), "linattn_ctxfold"),
+                  "linattn_ctxfold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
         scale = cfg.attn_dim_head ** -0.5
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_out(x.data_ptr(), wq.data_ptr(), wfold.data_ptr(), bias.data_ptr(),
                                                                 g2.data_ptr(), out.data_ptr(), B, n, c, scale, dt, st),
@@ -471,22 +479,19 @@ class _Plan:
         qkv = self.conv1(ops, [self.src(x, c)], self.P["w"][p + ".to_qkv.weight"], 3 * hid, h, w,
                          epi=cabi.EPI_QKV_LINEAR, rms_in=1, what="to_qkv " + p, kmax_out=kmax)
         nchunks = max(1, min(32, n // 256))       # >= 64 pixels per wave, enough workgroups at small n
-        ctxn = torch.empty(B, cfg.attn_heads, 32, 32, dtype=torch.float32, device=self.dev)
         ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, cfg.attn_heads, 32, nchunks)),
                           dtype=torch.float32, device=self.dev)
         wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)
         wout = f[p + ".to_out.0.weight"].reshape(c, hid).contiguous()
-        self.keep += [kmax, ctx, ctxn, wfold, wout, qkv]
+        self.keep += [kmax, ctx, wfold, wout, qkv]
         dt, heads = self.dt, cfg.attn_heads
         es = self.esize
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), ctx.data_ptr(),
                                                                 B, n, heads, 32, nchunks, dt, st), "linattn_ctx"),
                   "linattn_ctx", nbytes=2 * B * n * hid * es, flops=2 * B * n * hid * 32)
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, heads,
-                                                                       32, st), "linattn_ctx_reduce"), "linattn_ctx_reduce")
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(),
-                                                                 wfold.data_ptr(), B, c, heads, 32, 0, dt, st), "linattn_fold"),
-                  "linattn_fold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctxfold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold.data_ptr(),
+                                                                    B, c, heads, 32, 0, dt, st), "linattn_ctxfold"),
+                  "linattn_ctxfold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
         q = self.src(qkv, hid, stride=3 * hid)
         return self.conv1(ops, [q], wfold, c, h, w, bias=f[p + ".to_out.0.bias"], epi=cabi.EPI_RMS_RES,
                           bstride=c * hid * self.esize, g2=self.P["g2"][p + ".to_out.1.g"], residual=x,

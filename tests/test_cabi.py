@@ -57,7 +57,7 @@ def test_argument_validation_needs_no_gpu():
     a.nsrc, a.dtype, a.Cout = 1, 7, 32
     assert lib.ld_conv3x3(C.byref(a), None) == -1 and b"dtype" in lib.ld_last_error()
     assert lib.ld_attention(None, None, 1, 4, 4, 32, 0, None) == -1
-    assert lib.ld_linattn_kvctx(None, None, None, 1, 4, 32, 4, 32, 1, 1, None) == -1
+    assert lib.ld_linattn_kvctx(None, None, None, None, 1, 4, 32, 4, 32, 1, 1, None) == -1
     assert int(lib.ld_linattn_ctx_part_floats(2, 4, 32, 3)) == 2 * 4 * 3 * (1024 + 64)
     with pytest.raises(RuntimeError):
         cabi.check(-1, "demo")

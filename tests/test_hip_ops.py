@@ -234,6 +234,9 @@ def test_linear_attention_block(dtype, c, H, W):
     cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), ctx.data_ptr(), B, n, 4, 32, nchunks, dt, hh.st()), "ctx")
     cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, 4, 32, hh.st()), "reduce")
     cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(), wfold.data_ptr(), B, c, 4, 32, 0, dt, hh.st()), "fold")
+    wfold2 = torch.zeros_like(wfold)                  # reduce + fold in one launch: same packed weights
+    cabi.check(lib.ld_linattn_ctxfold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold2.data_ptr(), B, c, 4, 32, 0, dt, hh.st()), "ctxfold")
+    assert hh.rel_err(wfold2.float().cpu(), wfold.float().cpu()) < (1e-5 if dtype == "fp32" else 1e-2)
     # intermediate check: normalised context = softmax_n(k) . v^T
     q_, k_, v_ = [t.reshape(B, 4, 32, n) for t in F.conv2d(unet_ref.rms_norm(x, sd["a.norm.g"]), sd["a.to_qkv.weight"]).chunk(3, dim=1)]
     cref = torch.einsum("bhdn,bhen->bhde", k_.softmax(dim=-1), v_)
@@ -365,9 +368,11 @@ def test_final_conv(dtype):
     assert hh.rel_err(out.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("single_sweep", [False, True])
 @pytest.mark.parametrize("c,H,W", [(32, 28, 28), (64, 14, 14), (32, 64, 96), (128, 32, 32)])
-def test_linear_attention_fused_bf16(c, H, W):
-    """The fused bf16 path (q/k/v recomputed from x, never stored) against the oracle block."""
+def test_linear_attention_fused_bf16(c, H, W, single_sweep):
+    """The fused bf16 path (q/k/v recomputed from x, never stored) against the oracle block; with the exact
+    two-sweep k maximum and with the single-sweep Cauchy-Schwarz shift + the fused reduce/fold launch."""
     dtype = "bf16"
     B, hid, n = 2, 128, H * W
     x = _q(hh.rand((B, c, H, W), 170, -2, 2), dtype)
@@ -389,12 +394,25 @@ def test_linear_attention_fused_bf16(c, H, W):
     ctxn = torch.empty(B, 4, 32, 32, device=hh.DEV)
     wfold = torch.empty(B, c * hid, dtype=hh.TDT[dtype], device=hh.DEV)
     wout = sd["a.to_out.0.weight"].reshape(c, hid).contiguous().to(hh.DEV)
-    cabi.check(lib.ld_linattn_kvctx(xd.data_ptr(), wkv.data_ptr(), ctx.data_ptr(), B, n, c, 4, 32, nchunks, dt, hh.st()), "kvctx")
+    kshift = None
+    if single_sweep:   # |k_d| <= ||W_k[d] * g * sqrt(C)||_2 because the RMS-normalised pixel has unit 2-norm
+        kshift = (w[hid:2 * hid, :, 0, 0] * scale[None, :]).norm(dim=1).contiguous().to(hh.DEV)
+        nchunks = max(1, min(128, n // 512))
+        ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, 4, 32, nchunks)), device=hh.DEV)
+    cabi.check(lib.ld_linattn_kvctx(xd.data_ptr(), wkv.data_ptr(), None if kshift is None else kshift.data_ptr(), ctx.data_ptr(),
+                                    B, n, c, 4, 32, nchunks, dt, hh.st()), "kvctx")
     cabi.check(lib.ld_linattn_ctx_reduce(ctx.data_ptr(), nchunks, ctxn.data_ptr(), B, 4, 32, hh.st()), "reduce")
     q_, k_, v_ = [t.reshape(B, 4, 32, n) for t in F.conv2d(unet_ref.rms_norm(x, sd["a.norm.g"]), w).chunk(3, dim=1)]
+    if single_sweep:
+        assert float((k_.reshape(B, hid, n).amax(-1) - kshift.cpu()[None]).max()) <= 1e-3      # the bound holds
     cref = torch.einsum("bhdn,bhen->bhde", k_.softmax(dim=-1), v_)
     assert hh.rel_err(ctxn.cpu(), cref) < 2e-2
     cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(), wfold.data_ptr(), B, c, 4, 32, 1, dt, hh.st()), "fold")
+    if single_sweep:   # one launch for reduce + fold: identical packed M_b
+        wfold2 = torch.zeros_like(wfold)
+        cabi.check(lib.ld_linattn_ctxfold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold2.data_ptr(), B, c, 4, 32, 1, dt, hh.st()), "ctxfold")
+        assert hh.rel_err(wfold2.float().cpu(), wfold.float().cpu()) < 1e-2
+        wfold = wfold2
     out = torch.empty(B, H, W, c, dtype=hh.TDT[dtype], device=hh.DEV)
     bias, g2 = sd["a.to_out.0.bias"].to(hh.DEV), (sd["a.to_out.1.g"].flatten() * math.sqrt(c)).to(hh.DEV)
     cabi.check(lib.ld_linattn_out(xd.data_ptr(), wq.data_ptr(), wfold.data_ptr(), bias.data_ptr(), g2.data_ptr(),
