@@ -212,12 +212,14 @@ int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const float* w_out /*
  *        host passes that norm, and passes NULL (exact two-sweep maximum) when it exceeds 40, where
  *        exp(k - m_d) could underflow.
  *   ld_linattn_out:   x -> out = RMSNorm(to_out(ctx^T softmax_d(q)*scale)) + x  (:242,245,249,251,425);
- *        wq_packed = the 128 q rows packed the same way, mfold from ld_linattn_fold(perm=1). */
+ *        wq_packed = the 128 q rows packed the same way, mfold from ld_linattn_fold / _ctxfold (perm=1);
+ *        qshift (optional, [4] fp32): per head an upper bound of q over its 32 channels (max_d of the same
+ *        Cauchy-Schwarz norm, <= 40), used as the softmax_d shift instead of the per-pixel maximum. */
 int ld_linattn_kvctx(const void* x, const void* wkv_packed, const float* kshift, float* ctx_part, int B,
                      int n, int C, int heads, int dim_head, int nchunks, int dtype, void* stream);
-int ld_linattn_out(const void* x, const void* wq_packed, const void* mfold, const float* bias,
-                   const float* g2, void* out, int B, int n, int C, float q_scale, int dtype,
-                   void* stream);
+int ld_linattn_out(const void* x, const void* wq_packed, const float* qshift, const void* mfold,
+                   const float* bias, const float* g2, void* out, int B, int n, int C, float q_scale,
+                   int dtype, void* stream);
 size_t ld_linattn_ctx_part_floats(int B, int heads, int dim_head, int nchunks);
 
 /* Full softmax attention (attend.py:84-113) on qkv [B, n, 3*hidden] with q pre-scaled;

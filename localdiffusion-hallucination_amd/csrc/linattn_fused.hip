@@ -261,6 +261,12 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) mloc[m][r] = a.kshift[h * 32 + 16 * m + 4 * kq + r];
   }
+  constexpr float LOG2E = 1.4426950408889634f;
+  float m2[2][4];                                        // shift * log2(e): P = exp2(k*log2e - m2), one FMA + v_exp
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m2[m][r] = mloc[m][r] * LOG2E;
   for (int pass = first_pass; pass < 2; ++pass) {
     for (int p0 = lo; p0 < hi; p0 += KTN) {
       __syncthreads();                                   // every wave is done with the previous x tile
@@ -325,14 +331,14 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
               for (int m = 0; m < 4; ++m) mma16<bf16>(acc[m], A[m][c], Bf);
             }
-            const float rinv = s_rinv[qq];
+            const float rinv = s_rinv[qq], rinv2 = rinv * LOG2E;
             const int row = half * 16 + li;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
               float pv[4], vv[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                pv[r] = valid ? __expf(acc[m][r] * rinv - mloc[m][r]) : 0.f;
+                pv[r] = valid ? __builtin_amdgcn_exp2f(fmaf(acc[m][r], rinv2, -m2[m][r])) : 0.f;
                 vv[r] = valid ? acc[2 + m][r] * rinv : 0.f;
                 zs[m][r] += pv[r];
               }
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mloc[m][r] = wave16_max(cmax[m][r]);
+        for (int r = 0; r < 4; ++r) { mloc[m][r] = wave16_max(cmax[m][r]); m2[m][r] = mloc[m][r] * LOG2E; }
     }
   }
   float* dst = a.ctx_part + (((size_t)b * a.heads + h) * a.nchunks + ck) * CTX_STRIDE;
@@ -400,6 +406,7 @@ struct LinOutArgs {
   bf16* out;
   int n, C;
   float q_scale;
+  const float* qshift;   // optional [4]: per head an upper bound of q (softmax_d shift): skips the max reduction
 };
 
 template <int NCH>
@@ -418,6 +425,11 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
   for (int u = tid; u < NCH * 8 * 64; u += 256) *reinterpret_cast<uint4*>(s_wq + u * 16) = a.wq[u];
   const uint4* mf = a.mfold + (size_t)b * 4 * MT2 * 64;
   for (int u = tid; u < 4 * MT2 * 64; u += 256) *reinterpret_cast<uint4*>(s_mf + u * 16) = mf[u];
+  float qs2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.qshift) {
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) qs2[hh] = a.qshift[hh] * 1.4426950408889634f;
+  }
   for (int tl = 0; tl < LINOUT_TPB; ++tl) {
   const int p0 = (blockIdx.x * LINOUT_TPB + tl) * NPT;
   if (p0 >= n) break;
@@ -462,22 +474,29 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
       for (int m = 0; m < 8; ++m)
         mma16<bf16>(q[m], *reinterpret_cast<const uint4*>(s_wq + (c * 8 + m) * 1024 + lane * 16), Bf);
     }
-    const float rinv = s_rinv[qq];
+    const float rinv2 = s_rinv[qq] * 1.4426950408889634f;  // softmax_d(q) = exp2(q*log2e - shift*log2e) / sum
     uint4 B2[4];
 #pragma unroll
     for (int hh = 0; hh < 4; ++hh) {                    // one head = channel tiles 2hh, 2hh+1
       float v0[4], v1[4];
-      float mx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v0[r] = q[2 * hh][r] * rinv; v1[r] = q[2 * hh + 1][r] * rinv;
-        mx = fmaxf(mx, fmaxf(v0[r], v1[r]));
+      for (int r = 0; r < 4; ++r) { v0[r] = q[2 * hh][r] * rinv2; v1[r] = q[2 * hh + 1][r] * rinv2; }
+      float mx;
+      if (a.qshift) {
+        mx = qs2[hh];                                   // data-independent bound (see ld_linattn_out)
+      } else {
+        mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fmaxf(v0[r], v1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
       float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { v0[r] = __expf(v0[r] - mx); v1[r] = __expf(v1[r] - mx); sum += v0[r] + v1[r]; }
+      for (int r = 0; r < 4; ++r) {
+        v0[r] = __builtin_amdgcn_exp2f(v0[r] - mx); v1[r] = __builtin_amdgcn_exp2f(v1[r] - mx);
+        sum += v0[r] + v1[r];
+      }
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
       const float sc = a.q_scale / sum;
@@ -562,13 +581,13 @@ extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const flo
   return LD_OK;
 }
 
-extern "C" int ld_linattn_out(const void* x, const void* wq_packed, const void* mfold, const float* bias,
-                              const float* g2, void* out, int B, int n, int C, float q_scale, int dtype,
-                              void* stream) {
+extern "C" int ld_linattn_out(const void* x, const void* wq_packed, const float* qshift, const void* mfold,
+                              const float* bias, const float* g2, void* out, int B, int n, int C, float q_scale,
+                              int dtype, void* stream) {
   LD_REQUIRE(x && wq_packed && mfold && bias && g2 && out && B > 0 && n > 0, "ld_linattn_out: bad args");
   LD_REQUIRE(dtype == LD_BF16, "ld_linattn_out: bf16 storage only (fp32 uses the unfused path)");
   LD_REQUIRE(C == 32 || C == 64 || C == 128, "ld_linattn_out: C in {32,64,128}");
-  LinOutArgs a{(const bf16*)x, (const uint4*)wq_packed, (const uint4*)mfold, bias, g2, (bf16*)out, n, C, q_scale};
+  LinOutArgs a{(const bf16*)x, (const uint4*)wq_packed, (const uint4*)mfold, bias, g2, (bf16*)out, n, C, q_scale, qshift};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((n + 128 * LINOUT_TPB - 1) / (128 * LINOUT_TPB), B);
   const int nch = C / 32;

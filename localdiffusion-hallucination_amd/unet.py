@@ -164,7 +164,7 @@ class Unet(nn.Module):
                 continue                                  # folded per batch with ctx (ld_linattn_fold)
             else:
                 pack(name, k)
-        P["wq"], P["wkv"], P["kshift"] = {}, {}, {}
+        P["wq"], P["wkv"], P["kshift"], P["qshift"] = {}, {}, {}, {}
         if self.compute_dtype == "bf16":
             hid, heads = self.cfg.hidden, self.cfg.attn_heads
             for name, w in sd.items():
@@ -196,6 +196,9 @@ class Unet(nn.Module):
                 wk = (w[hid:2 * hid, :, 0, 0].float() * scale[None, :]).to(tdt).float()
                 bound = wk.norm(dim=1) * 1.01
                 P["kshift"][base] = bound.contiguous() if float(bound.max()) <= 40.0 else None
+                wqn = (w[:hid, :, 0, 0].float() * scale[None, :]).to(tdt).float().norm(dim=1) * 1.01
+                qb = wqn.reshape(heads, 32).amax(dim=1)          # softmax_d(q) shift per head (same bound, max over d)
+                P["qshift"][base] = qb.contiguous() if float(qb.max()) <= 40.0 else None
                 P["keep"].append(scale)
         for name, w in sd.items():
             if name.endswith(".to_out.1.g"):
@@ -451,9 +454,11 @@ class _Plan:
         wq, wkv = self.P["wq"][p], self.P["wkv"][p]
         kshift = self.P["kshift"].get(p) if heads == 4 else None
         ksp = kshift.data_ptr() if kshift is not None else None
+        qshift = self.P["qshift"].get(p) if heads == 4 else None
+        qsp = qshift.data_ptr() if qshift is not None else None
         bias, g2 = f[p + ".to_out.0.bias"], self.P["g2"][p + ".to_out.1.g"]
         out = self.buf(h, w, c)
-        self.keep += [ctx, wfold, wout, wq, wkv, kshift, bias, g2, out, x]
+        self.keep += [ctx, wfold, wout, wq, wkv, kshift, qshift, bias, g2, out, x]
         npx = B * n
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_kvctx(x.data_ptr(), wkv.data_ptr(), ksp, ctx.data_ptr(), B, n, c,
                                                                   heads, 32, nchunks, dt, st), "linattn_kvctx"),
@@ -462,7 +467,7 @@ class _Plan:
                                                                     heads, 32, 1, dt, st), "linattn_ctxfold"),
                   "linattn_ctxfold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
         scale = cfg.attn_dim_head ** -0.5
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_out(x.data_ptr(), wq.data_ptr(), wfold.data_ptr(), bias.data_ptr(),
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_out(x.data_ptr(), wq.data_ptr(), qsp, wfold.data_ptr(), bias.data_ptr(),
                                                                 g2.data_ptr(), out.data_ptr(), B, n, c, scale, dt, st),
                                              "linattn_out"),
                   "linattn_out", nbytes=2 * npx * c * es, flops=2 * npx * hid * c * 2)

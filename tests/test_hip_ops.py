@@ -415,8 +415,11 @@ def test_linear_attention_fused_bf16(c, H, W, single_sweep):
         wfold = wfold2
     out = torch.empty(B, H, W, c, dtype=hh.TDT[dtype], device=hh.DEV)
     bias, g2 = sd["a.to_out.0.bias"].to(hh.DEV), (sd["a.to_out.1.g"].flatten() * math.sqrt(c)).to(hh.DEV)
-    cabi.check(lib.ld_linattn_out(xd.data_ptr(), wq.data_ptr(), wfold.data_ptr(), bias.data_ptr(), g2.data_ptr(),
-                                  out.data_ptr(), B, n, c, 32 ** -0.5, dt, hh.st()), "linattn_out")
+    qshift = None
+    if single_sweep:
+        qshift = (w[:hid, :, 0, 0] * scale[None, :]).norm(dim=1).reshape(4, 32).amax(dim=1).contiguous().to(hh.DEV)
+    cabi.check(lib.ld_linattn_out(xd.data_ptr(), wq.data_ptr(), None if qshift is None else qshift.data_ptr(), wfold.data_ptr(),
+                                  bias.data_ptr(), g2.data_ptr(), out.data_ptr(), B, n, c, 32 ** -0.5, dt, hh.st()), "linattn_out")
     assert hh.rel_err(hh.nchw(out), ref) < 6e-2
 
 
