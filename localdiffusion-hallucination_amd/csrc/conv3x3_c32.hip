@@ -1,23 +1,25 @@
-// Persistent 3x3 convolution for the C=32 output stages (32->32 and 64->32 at 256^2 / 128^2: the
+// Persistent deep-ring 3x3 convolution for the C=32 output stages (32->32 and 64->32 at 256^2 / 128^2: the
 // "ResBlock conv path" of the north star, AI 144-192 FLOP/B => HBM-bound if nothing else stalls).
 //
-// Same arithmetic, fragment layouts and fused prologue/epilogue as conv3x3.hip, different schedule:
-//   * grid = (G, B) with G*B ~ 2 workgroups per CU; a workgroup walks tiles g, g+G, ... of ONE image,
-//     so the launch has no tail of half-filled waves and per-workgroup setup happens once:
-//     weights (<= 2 K-chunks, 36 KiB) go to LDS once, bias and GroupNorm coefficients are built once,
-//     GroupNorm statistics of the output stay in registers across tiles and are flushed once;
-//   * halo tiles are double-buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4: no staging
-//     registers, so the kernel keeps >= 2 workgroups per CU).  LDS image = 21 blocks of 16 halo pixels,
-//     each block [kq 0..3][pixel 0..15][16 B] = 1 KiB = ONE DMA instruction: lane l = kq*16 + p reads
-//     fragment kq of pixel p, i.e. the wave reads 16 pixels x 64 B = one contiguous KiB of HBM (the
-//     LDS destination is wave-base + lane*16, the per-lane SOURCE does the halo/upsample/concat
-//     gather), and a fragment read of 16 consecutive pixels still hits 16 distinct 16-B slots
-//     (conflict-free for every tap).  Slots outside the image are zero-filled by LDS writes;
-//   * the DMA of item i+1 is issued right after the barrier that retires item i-1's readers and flies
-//     during item i's MFMAs (raw s_barrier + explicit s_waitcnt: __syncthreads() would drain it,
-//     cdna_hip_programming.md "Pipelining across barriers");
-//   * with a GroupNorm prologue the landed tile is transformed in place (LDS -> regs -> LDS) by the
-//     wave that owns the plane: its 8 channels are wave-uniform, so the coefficients are scalars.
+// Same arithmetic, fragment layouts and fused prologue/epilogue as conv3x3.hip, different schedule.  What
+// bounds these launches is bytes in flight: with one 21-KiB halo tile prefetched per workgroup (the previous
+// version: 2 workgroups/CU) a CU keeps ~42 KiB outstanding, which at the loaded HBM latency of ~2-4 us is
+// ~2.5 TB/s chip-wide -- exactly what was measured, for every schedule tried.  Here:
+//   * grid = one 512-thread workgroup per CU (G x B, G*B ~ 256); a workgroup walks tiles g, g+G, ... of ONE
+//     image, so weights (<= 2 K-chunks, 36 KiB), bias and GroupNorm coefficients are set up once and the
+//     output statistics stay in registers until one flush at the end;
+//   * items = (tile, K-chunk) pairs; the halo tile of an item lives in one slot of an R-deep LDS ring
+//     (R = 6 / 5 for 1 / 2 chunks, 21 KiB per slot) filled by LDS-DMA.  Slot = 21 blocks of 16 halo pixels,
+//     each block [kq 0..3][pixel 0..15][16 B] = 1 KiB = ONE global_load_lds_dwordx4: lane l = kq*16 + p reads
+//     fragment kq of pixel p (16 pixels x 64 B contiguous in HBM), and a fragment read of 16 consecutive
+//     pixels hits 16 distinct 16-B slots (conflict-free for every tap);
+//   * at item i every wave (a) requests its blocks of item i+R-1 into the slot item i-1 just vacated, (b) runs
+//     the MFMAs of item i, (c) stores the tile if it is finished, (d) waits -- with an exact counted vmcnt: the
+//     DMA is issued as inline asm (common.cuh), every wave issues a fixed number of DMA and store instructions
+//     per item because out-of-image lanes read a clamped in-image address and tiles are never ragged
+//     (H, W multiples of 16) -- for its OWN blocks of item i+1 and normalises / activates / zero-pads them in
+//     place, then ONE workgroup barrier.  R-2 items (63-84 KiB per CU) stay in flight across that barrier and
+//     the VALU prologue of item i+1 overlaps the MFMAs of item i of the other wave on the SIMD.
 #include "common.cuh"
 #include <stdlib.h>
 
@@ -37,125 +39,161 @@ struct C32Dev {
   int dbg;     // LD_CONV_DEBUG ablation bits (0 in production): 1 no DMA, 4 no MFMA, 8 no stores, 16 no transform
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
+// LD_CONV_DEBUG bit 32: wave 0 of workgroup (0,0) keeps cycle-counter stamps (start, setup done, ring filled, end
+// of each of the first 10 items, end) in registers and dumps them here when it finishes (ld_debug_c32_trace).
+__device__ unsigned long long g_c32_trace[16];
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate): binary decision tree,
+// 6 scalar compares for any n in 0..63
+template <int LO, int HI>
+__device__ __forceinline__ void wait_vmcnt_range(int n) {
+  if constexpr (LO == HI) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LO) : "memory");
+  } else {
+    constexpr int MID = (LO + HI) / 2;
+    if (n <= MID) wait_vmcnt_range<LO, MID>(n);
+    else wait_vmcnt_range<MID + 1, HI>(n);
+  }
+}
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  if (n < 0 || n > 63) n = 0;
+  wait_vmcnt_range<0, 63>(n);
+}
+
+template <typename T, int NCH, int R, int DBG>
+__global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
-  constexpr int MT = 2, NW = 4, TR = 16, TC = 16, HR = TR + 2, HC = TC + 2;
-  constexpr int NPIX = HR * HC, NPIXP = (NPIX + 15) / 16 * 16, PLANE = NPIXP * 16;   // 336 slots
-  constexpr int NBLK = NPIXP / 16, BPW = (NBLK + 3) / 4;                              // 16-pixel blocks, per wave
-  constexpr int XBUF = NBLK * 1024;                                                  // bytes per halo buffer
-  constexpr int WCH = 9 * MT * 1024;                                                 // bytes per weight chunk
+  constexpr int MT = 2, NW = 2, NWAVE = 8, TR = NW * NWAVE, TC = 16, HR = TR + 2, HC = TC + 2;
+  constexpr int NPIX = HR * HC, NBLK = (NPIX + 15) / 16, BPW = (NBLK + NWAVE - 1) / NWAVE;   // 324 px, 21 blocks, 3
+  constexpr int XBUF = NBLK * 1024;                                                         // bytes per ring slot
+  constexpr int WCH = 9 * MT * 1024;                                                        // bytes per weight chunk
+  constexpr int NST = NW * (sizeof(T) == 2 ? 1 : 2);                                        // store instructions per wave per tile
   constexpr bool P = DT<T>::precise;
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // LDS budget: two workgroups per CU need <= 81,920 B each: weights nch*18 KiB + 2 halo buffers 42 KiB +
-  // coefficients; the fp64 statistics scratch aliases the halo buffers (used only before the first DMA
-  // and after the last MFMA).
-  const int nch_w = a.s[0].C / CK + (a.nsrc > 1 ? a.s[1].C / CK : 0);
-  char* s_w = smem;                                   // [nch][9][MT][1 KiB]
-  char* s_x = smem + nch_w * WCH;                     // [2 buffers][NBLK][kq][16 px][16 B]
-  float* s_coef = reinterpret_cast<float*>(s_x + 2 * XBUF);
-  double* s_stat = reinterpret_cast<double*>(s_x);    // [4 waves][2][32] / coef scratch
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* s_w = smem;                                   // [NCH][9][MT][1 KiB]
+  char* s_x = smem + NCH * WCH;                       // [R slots][NBLK][kq][16 px][16 B]
+  float* s_coef = reinterpret_cast<float*>(s_x + R * XBUF);
+  double* s_stat = reinterpret_cast<double*>(s_x);    // [8 waves][2][32] / coefficient scratch (before / after the ring)
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
-  const int b = blockIdx.y, H = a.H, W = a.W;
+  const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, kq = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, H = a.H, W = a.W, G = gridDim.x;
   const int nch0 = a.s[0].C / CK;
-  const int nch = nch0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
-  const int G = gridDim.x;
-  const int ntl = (a.ntiles - (int)blockIdx.x + G - 1) / G;       // tiles g, g+G, ...
-  const int total = ntl * nch;
+  const int ntl = (a.ntiles - (int)blockIdx.x + G - 1) / G;       // tiles blockIdx.x, +G, ...
+  const int total = ntl * NCH;
+  const int nb_w = (NBLK - wv + NWAVE - 1) / NWAVE;                // DMA instructions of this wave per item (3 or 2)
+  const unsigned ring_a = lds_addr(s_x);
+  const bool tracing = (DBG & 32) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  unsigned long long tr_t[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tr_t[k] = 0;
+  if (tracing) tr_t[0] = __builtin_readcyclecounter();
 
   // ---- one-time setup: weights -> LDS, bias -> registers, GroupNorm coefficients -> LDS
   {
     const uint4* wg = reinterpret_cast<const uint4*>(a.w);
-    for (int u = tid; u < nch * 9 * MT * 64; u += 256) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[u];
+    for (int u = tid; u < NCH * 9 * MT * 64; u += 512) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[u];
   }
   float4 bias[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + m * 16 + kq * 4);
-  const bool any_coef = a.s[0].stats != nullptr || (a.nsrc > 1 && a.s[1].stats != nullptr);
-  if (any_coef) {
+  for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + kq * 8 + m * 4);   // pack.hip rowmap
+  if (a.s[0].stats != nullptr || (a.nsrc > 1 && a.s[1].stats != nullptr)) {
     const int trow = a.t_ptr ? *a.t_ptr : 0;
     int off = 0;
     for (int s = 0; s < a.nsrc; ++s) {
       const SrcDev S = s ? a.s[1] : a.s[0];
       if (S.stats) {
         const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
-        build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, tid, 256);
+        build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, tid, 512);
       }
       off += 2 * S.C;
     }
-    __syncthreads();                                  // s_stat scratch is about to be overwritten by the first DMA
   }
+  __syncthreads();                                    // weights / coefficients visible; s_stat scratch is dead
+  // Retire every compiler-visible global load HERE: hipcc's s_waitcnt bookkeeping does not see the asm DMAs, so
+  // a wait it placed at the first use of `bias` inside the item loop (vmcnt(1..2), counting only its own stores)
+  // would drain the whole ring on every tile.
+#pragma unroll
+  for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(bias[m].x), "v"(bias[m].y), "v"(bias[m].z), "v"(bias[m].w));
 
-  // ---- DMA of one (tile, chunk) item into buffer `buf`: wave wv owns plane kq = wv
-  auto dma = [&](int item, int buf) {
-    if (a.dbg & 1) return;
-    const int ti = item / nch, ch = item - ti * nch;
-    const int tile = blockIdx.x + ti * G;
-    const int ty0 = (tile / a.tiles_x) * TR, tx0 = (tile % a.tiles_x) * TC;
-    const int si = ch >= nch0 ? 1 : 0;
+  if (tracing) tr_t[1] = __builtin_readcyclecounter();
+  // tile-independent halo coordinates of the ring blocks this thread loads and post-processes
+  int qy[BPW], qx[BPW];
+#pragma unroll
+  for (int r = 0; r < BPW; ++r) {
+    const int q = (r * NWAVE + wv) * 16 + px;
+    qy[r] = q / HC;
+    qx[r] = q - qy[r] * HC;
+  }
+  // Position in the item sequence.  Tiles step by G through the image; the step is applied as a (row, column)
+  // increment so that no integer division runs inside the item loop (measured: the divisions, a 49-way waitcnt
+  // switch and 64-bit address products made an EMPTY item cost 2,000 cycles, as much as its useful work).
+  struct Cursor { int ch, ty, tx, ty0, tx0; };
+  const int step_y = G / a.tiles_x, step_x = G % a.tiles_x;
+  auto advance = [&](Cursor& c) {
+    if (++c.ch == NCH) {
+      c.ch = 0;
+      c.ty += step_y;
+      c.tx += step_x;
+      if (c.tx >= a.tiles_x) { c.tx -= a.tiles_x; ++c.ty; }
+      c.ty0 = c.ty * TR;
+      c.tx0 = c.tx * TC;
+    }
+  };
+  // ---- LDS-DMA of this wave's blocks of one item into ring slot `slot` (always nb_w instructions)
+  auto dma = [&](const Cursor& c, int slot) {
+    if (DBG & 1) return;
+    const int si = c.ch >= nch0 ? 1 : 0;
     const SrcDev S = si ? a.s[1] : a.s[0];
-    const int c0 = (ch - si * nch0) * CK;
-    const T* sdata = reinterpret_cast<const T*>(S.data);
+    const T* sdata = reinterpret_cast<const T*>(S.data) + (c.ch - si * nch0) * CK + kq * E;
     const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
-    char* xb = s_x + buf * XBUF;
+    const int row0 = b * Hs;                                       // element offsets fit 32 bits (checked on the host)
+    const unsigned sa = ring_a + slot * XBUF;
 #pragma unroll
     for (int r = 0; r < BPW; ++r) {
-      const int blk = r * 4 + wv;
-      if (blk < NBLK) {
-        const int q = blk * 16 + px;
-        bool inb = false;
-        size_t idx = 0;
-        if (q < NPIX) {
-          const int hy = q / HC, hx = q - hy * HC;
-          const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-          if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const int sy = S.ups ? gy >> 1 : gy, sx = S.ups ? gx >> 1 : gx;
-            idx = (((size_t)b * Hs + sy) * Ws + sx) * S.ld + c0 + kq * E;
-            inb = true;
-          }
-        }
-        if (inb) {
-          glds16(sdata + idx, __builtin_amdgcn_readfirstlane(lds_addr(xb + blk * 1024)));
-        } else {
-          *reinterpret_cast<uint4*>(xb + blk * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
-        }
+      const int blk = r * NWAVE + wv;
+      if (blk < NBLK) {                                            // wave-uniform
+        int gy = ((DBG & 1024) ? 0 : c.ty0) - 1 + qy[r], gx = ((DBG & 1024) ? 0 : c.tx0) - 1 + qx[r];   // 1024: always tile (0,0): L2-resident reads
+        gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);               // out-of-image (and padding) lanes read an in-image
+        gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);               // pixel; fixup() zeroes their slots after landing
+        const int sy = S.ups ? gy >> 1 : gy, sx = S.ups ? gx >> 1 : gx;
+        if constexpr (DBG & 512) glds16_nt(sdata + ((row0 + sy) * Ws + sx) * S.ld, __builtin_amdgcn_readfirstlane(sa + blk * 1024));
+        else glds16(sdata + ((row0 + sy) * Ws + sx) * S.ld, __builtin_amdgcn_readfirstlane(sa + blk * 1024));
       }
     }
   };
-  // ---- in-place normalise + FiLM + activation of the landed plane (prologue sources only)
-  auto transform = [&](int item, int buf) {
-    const int ti = item / nch, ch = item - ti * nch;
-    const int si = ch >= nch0 ? 1 : 0;
+  // ---- in-place prologue of the landed blocks this wave loaded (zero padding stays exactly zero)
+  auto fixup = [&](const Cursor& c, int slot) {
+    const int si = c.ch >= nch0 ? 1 : 0;
     const SrcDev S = si ? a.s[1] : a.s[0];
-    if (S.stats == nullptr || (a.dbg & 16)) return false;
-    const int tile = blockIdx.x + ti * G;
-    const int ty0 = (tile / a.tiles_x) * TR, tx0 = (tile % a.tiles_x) * TC;
-    const int c0 = (ch - si * nch0) * CK;
-    const float* cap = s_coef + (si ? 2 * a.s[0].C : 0) + c0 + kq * E;
+    const bool tr = S.stats != nullptr && !(DBG & 16);
+    const bool border = c.ty0 == 0 || c.tx0 == 0 || c.ty0 + TR >= H || c.tx0 + TC >= W;
+    if (!tr && !border) return;
     float ca[E], cs[E];
+    if (tr) {
+      const float* cap = s_coef + (si ? 2 * a.s[0].C : 0) + (c.ch - si * nch0) * CK + kq * E;
 #pragma unroll
-    for (int e = 0; e < E; ++e) { ca[e] = cap[e]; cs[e] = cap[S.C + e]; }
-    char* xb = s_x + buf * XBUF;
+      for (int e = 0; e < E; ++e) { ca[e] = cap[e]; cs[e] = cap[S.C + e]; }
+    }
+    char* xb = s_x + slot * XBUF + lane * 16;
 #pragma unroll
     for (int r = 0; r < BPW; ++r) {
-      const int blk = r * 4 + wv;
-      const int q = blk * 16 + px;
+      const int blk = r * NWAVE + wv, q = blk * 16 + px;
       if (blk < NBLK && q < NPIX) {
-        const int hy = q / HC, hx = q - hy * HC;
-        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {     // zero padding stays exactly zero
-          char* ptr = xb + blk * 1024 + lane * 16;
-          uint4 raw = *reinterpret_cast<const uint4*>(ptr);
+        const int gy = c.ty0 - 1 + qy[r], gx = c.tx0 - 1 + qx[r];
+        const bool valid = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        uint4* ptr = reinterpret_cast<uint4*>(xb + blk * 1024);
+        if (!valid) {
+          *ptr = make_uint4(0u, 0u, 0u, 0u);
+        } else if (tr) {
           float v[E];
-          unpack16<T>(raw, v);
+          unpack16<T>(*ptr, v);
           affine_act_n<P, E>(v, ca, cs, S.act);
-          *reinterpret_cast<uint4*>(ptr) = pack16<T>(v);
+          *ptr = pack16<T>(v);
         }
       }
     }
-    return true;
   };
 
   float ssum[MT][4], ssq[MT][4];
@@ -166,86 +204,138 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
   f32x4 acc[MT][NW];
   T* out = reinterpret_cast<T*>(a.out);
 
-  if (total > 0) dma(0, 0);
-  bool stores_behind = false;      // the previous iteration issued exactly 8 stores AFTER this item's DMA
+  // ---- fill the ring: items 0 .. R-2 requested, item 0 landed and post-processed
+  Cursor iss{0, (int)blockIdx.x / a.tiles_x, (int)blockIdx.x % a.tiles_x, 0, 0}, fix, cur;
+  iss.ty0 = iss.ty * TR;
+  iss.tx0 = iss.tx * TC;
+  fix = cur = iss;
+  int requested = 0;
+  for (; requested < R - 1 && requested < total; ++requested) { dma(iss, requested); advance(iss); }
+  if (total > 0) {
+    wait_vmcnt((DBG & 1) ? 0 : (requested - 1) * nb_w);
+    fixup(fix, 0);
+    advance(fix);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  if (tracing) tr_t[2] = __builtin_readcyclecounter();
+  // Phase order inside an item is skewed between the two waves that share a SIMD (wave w and w+4): waves 0-3 run
+  // MFMA -> store -> prologue of the next item, waves 4-7 run prologue -> MFMA -> store, so one wave's VALU / LDS /
+  // store phase overlaps the other's MFMAs instead of both queueing on the same pipe (measured in lockstep:
+  // 1,300 cycles of MFMA + 2,760 of prologue + 650 of epilogue per item, strictly one after the other).
+  const bool prologue_first = wv >= NWAVE / 2;
+  int slot = 0;
   for (int i = 0; i < total; ++i) {
-    const int buf = i & 1;
-    const int ti = i / nch, ch = i - ti * nch;
-    // my DMA / zero-fill of item i has landed.  vmcnt retires in order and the previous tile's 8 epilogue
-    // stores are younger than that DMA, so vmcnt(8) waits for the DMA without draining the stores.
-    if (stores_behind) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    stores_behind = false;
-    __builtin_amdgcn_s_barrier();                                 // ... and everybody's; item i-1 fully read
-    asm volatile("" ::: "memory");
-    if (i + 1 < total) dma(i + 1, buf ^ 1);
-    if (transform(i, buf)) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+    if (tracing && i == 3) tr_t[3] = __builtin_readcyclecounter();
+    // (a) request item i+R-1 into the slot item i-1 vacated (all waves are past barrier i-1)
+    if (i + R - 1 < total) {
+      dma(iss, slot == 0 ? R - 1 : slot - 1);
+      advance(iss);
     }
-    if (ch == 0) {
+    if (tracing && i == 3) tr_t[4] = __builtin_readcyclecounter();
+    // (b)+(c) MFMAs of item i (fragment reads of tap column dx+1 are in flight during the MFMAs of column dx);
+    //         tile finished: bias, statistics, store (exactly NST store instructions: tiles are never ragged)
+    auto mfma_and_store = [&]() {
+      if (cur.ch == 0) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const char* xb = s_x + buf * XBUF;
-    const char* wb = s_w + ch * WCH;
-    if (!(a.dbg & 4)) {   // fragment reads of tap column dx+1 are in flight during the MFMAs of column dx (see conv3x3.hip)
-      uint4 A[2][3][MT], Bq[2][NW + 2];
-      auto load_frags = [&](int dx, int set) {
+          for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (!(DBG & 4)) {
+        const char* xb = s_x + slot * XBUF + kq * 256;
+        const char* wb = s_w + cur.ch * WCH + lane * 16;
+        uint4 A[2][3][MT], Bq[2][NW + 2];
+        auto load_frags = [&](int dx, int set) {
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+          for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            A[set][dy][m] = *reinterpret_cast<const uint4*>(wb + ((dy * 3 + dx) * MT + m) * 1024 + lane * 16);
+            for (int m = 0; m < MT; ++m) A[set][dy][m] = *reinterpret_cast<const uint4*>(wb + ((dy * 3 + dx) * MT + m) * 1024);
 #pragma unroll
-        for (int rr = 0; rr < NW + 2; ++rr) {
-          const int q = (wv * NW + rr) * HC + dx + px;
-          Bq[set][rr] = *reinterpret_cast<const uint4*>(xb + ((q >> 4) << 10) + kq * 256 + ((q & 15) << 4));
-        }
-      };
-      load_frags(0, 0);
+          for (int rr = 0; rr < NW + 2; ++rr) {
+            const int q = (wv * NW + rr) * HC + dx + px;
+            Bq[set][rr] = *reinterpret_cast<const uint4*>(xb + ((q >> 4) << 10) + ((q & 15) << 4));
+          }
+        };
+        load_frags(0, 0);
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        if (dx + 1 < 3) load_frags(dx + 1, (dx + 1) & 1);
+        for (int dx = 0; dx < 3; ++dx) {
+          if (dx + 1 < 3) load_frags(dx + 1, (dx + 1) & 1);
 #pragma unroll
-        for (int rr = 0; rr < NW + 2; ++rr) {
+          for (int rr = 0; rr < NW + 2; ++rr) {
 #pragma unroll
-          for (int dy = 0; dy < 3; ++dy) {
-            const int j = rr - dy;
-            if (j >= 0 && j < NW) {
+            for (int dy = 0; dy < 3; ++dy) {
+              const int j = rr - dy;
+              if (j >= 0 && j < NW) {
 #pragma unroll
-              for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[dx & 1][dy][m], Bq[dx & 1][rr]);
+                for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[dx & 1][dy][m], Bq[dx & 1][rr]);
+              }
             }
           }
         }
       }
-    }
-    if (ch == nch - 1) {                                          // tile finished: bias, stats, store
-      const int tile = blockIdx.x + ti * G;
-      const int ty0 = (tile / a.tiles_x) * TR, tx0 = (tile % a.tiles_x) * TC;
-      const int gx = tx0 + px;
-      // all 8 store instructions execute in this wave iff its 4 rows are inside the image (uniform test)
-      stores_behind = (ty0 + wv * NW + NW <= H) && (i + 1 < total) && !(a.dbg & 8);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int co = m * 16 + kq * 4;
-        const float4 bv = bias[m];
+      if (cur.ch == NCH - 1 && !(DBG & 8)) {
+        // the lane holds channels 8kq..8kq+7 of pixel px (pack.hip rowmap): one 16-byte store per row (bf16)
+        const int gx = cur.tx0 + px;
+        const float4 b0 = bias[0], b1 = bias[1];
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-          const int gy = ty0 + wv * NW + j;
-          if (gy < H && gx < W) {
-            float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
-            if (!(a.dbg & 8)) store4<T>(out + (((size_t)b * H + gy) * W + gx) * 32 + co, v);
+          const int gy = cur.ty0 + wv * NW + j;
+          float v0[4] = {acc[0][j][0] + b0.x, acc[0][j][1] + b0.y, acc[0][j][2] + b0.z, acc[0][j][3] + b0.w};
+          float v1[4] = {acc[1][j][0] + b1.x, acc[1][j][1] + b1.y, acc[1][j][2] + b1.z, acc[1][j][3] + b1.w};
+          if constexpr (sizeof(T) == 2 && (DBG & 256)) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            u32x4 pk = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+            __builtin_nontemporal_store(pk, reinterpret_cast<u32x4*>(out + (size_t)(((b * H + gy) * W + gx) * 32 + kq * 8)));
+          } else {
+            store8<T>(out + (size_t)(((b * H + gy) * W + gx) * 32 + kq * 8), v0, v1);
+          }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
+          for (int r = 0; r < 4; ++r) {
+            ssum[0][r] += v0[r]; ssq[0][r] += v0[r] * v0[r];
+            ssum[1][r] += v1[r]; ssq[1][r] += v1[r] * v1[r];
           }
         }
       }
+    };
+    // (d) own blocks of item i+1: wait, post-process.  Younger than that DMA in this wave's in-order VM queue:
+    //     the DMAs of items i+2 .. min(i+R-1, total-1) and the stores of every tile this wave finished since the
+    //     DMA was issued (at iteration i+2-R, or in the ring fill) -- iterations first_it .. i when the stores of
+    //     this iteration are already out (MFMA first), first_it .. i-1 otherwise.
+    auto prologue_next = [&](bool stored_this_iteration) {
+      if (i + 1 >= total) return;
+      const int last = i + R - 1 < total - 1 ? i + R - 1 : total - 1;
+      const int first_it = i + 2 - R > 0 ? i + 2 - R : 0;
+      const int hi_it = stored_this_iteration ? i : i - 1;          // last iteration whose stores are counted
+      int tile_ends;
+      if (NCH == 1) tile_ends = hi_it - first_it + 1;
+      else tile_ends = (hi_it + 1) / 2 - first_it / 2;              // iterations k in [first_it, hi_it] with k odd
+      if (tile_ends < 0) tile_ends = 0;
+      const int nst = (DBG & 8) ? 0 : NST * tile_ends;
+      if (!(DBG & 128)) wait_vmcnt((DBG & 1) ? nst : (last - (i + 1)) * nb_w + nst);
+      if (!(DBG & 64)) fixup(fix, slot == R - 1 ? 0 : slot + 1);
+      advance(fix);
+    };
+    if (prologue_first) {
+      prologue_next(false);
+      if (tracing && i == 3) tr_t[5] = __builtin_readcyclecounter();
+      mfma_and_store();
+    } else {
+      mfma_and_store();
+      if (tracing && i == 3) tr_t[5] = __builtin_readcyclecounter();
+      prologue_next(true);
     }
+    if (tracing && i == 3) tr_t[8] = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tracing && i == 3) tr_t[9] = __builtin_readcyclecounter();
+    advance(cur);
+    slot = slot == R - 1 ? 0 : slot + 1;
   }
+  if (tracing) tr_t[13] = __builtin_readcyclecounter();
 
   if (a.ostats) {                                                 // one flush per workgroup
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -256,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
       for (int r = 0; r < 4; ++r) {
         const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
         if (px == 0) {
-          s_stat[(wv * 2 + 0) * 32 + m * 16 + kq * 4 + r] = (double)s1;
-          s_stat[(wv * 2 + 1) * 32 + m * 16 + kq * 4 + r] = (double)s2;
+          s_stat[(wv * 2 + 0) * 32 + kq * 8 + m * 4 + r] = (double)s1;
+          s_stat[(wv * 2 + 1) * 32 + kq * 8 + m * 4 + r] = (double)s2;
         }
       }
     __syncthreads();
@@ -265,49 +355,88 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(C32Dev a) {
     if (tid < 2 * a.ogroups) {
       const int gi = tid >> 1, k = tid & 1;
       double acc1 = 0.0;
-      for (int w4 = 0; w4 < 4; ++w4)
-        for (int c = 0; c < gs; ++c) acc1 += s_stat[(w4 * 2 + k) * 32 + gi * gs + c];
+      for (int w8 = 0; w8 < NWAVE; ++w8)
+        for (int c = 0; c < gs; ++c) acc1 += s_stat[(w8 * 2 + k) * 32 + gi * gs + c];
       const int stripe = blockIdx.x % LD_STAT_STRIPES;
       atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + gi) * 2 + k], acc1);
     }
   }
+  if (tracing) {
+    tr_t[14] = __builtin_readcyclecounter();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g_c32_trace[k] = tr_t[k];
+  }
 }
 
-template <typename T>
-int launch_c32(const C32Dev& a0, hipStream_t st) {
-  C32Dev a = a0;
-  a.tiles_x = (a.W + 15) / 16;
-  a.ntiles = a.tiles_x * ((a.H + 15) / 16);
-  const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
-  const int ck = sizeof(T) == 4 ? 16 : 32;
-  const size_t lds = (size_t)(ctot / ck) * 9 * 2 * 1024 + 2 * 4 * 336 * 16 + 2 * ctot * sizeof(float);
+template <typename T, int NCH, int R, int DBG>
+int launch_c32_dbg(C32Dev& a, size_t lds, dim3 grid, hipStream_t st) {
   static size_t allowed = 0;
   if (lds > allowed) {
-    LD_HIP(ld_allow_lds(conv3x3_c32_kernel<T>, lds));
+    LD_HIP(ld_allow_lds(conv3x3_c32_kernel<T, NCH, R, DBG>, lds));
     allowed = lds;
   }
-  int G = (512 + a.B - 1) / a.B;                       // ~2 workgroups per CU over the whole launch
-  if (G > a.ntiles) G = a.ntiles;
-  hipLaunchKernelGGL((conv3x3_c32_kernel<T>), dim3(G, a.B), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_c32_kernel<T, NCH, R, DBG>), grid, dim3(512), lds, st, a);
   LD_LAUNCH_CHECK("conv3x3_c32");
   return LD_OK;
+}
+
+template <typename T, int NCH, int R>
+int launch_c32(const C32Dev& a0, hipStream_t st) {
+  C32Dev a = a0;
+  a.tiles_x = a.W / 16;
+  a.ntiles = a.tiles_x * (a.H / 16);
+  const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
+  const size_t lds = (size_t)NCH * 9 * 2 * 1024 + (size_t)R * 21 * 1024 + 2 * ctot * sizeof(float);
+  int G = (256 + a.B - 1) / a.B;                       // one workgroup per CU over the whole launch
+  if (G > a.ntiles) G = a.ntiles;
+  const dim3 grid(G, a.B);
+  // the LD_CONV_DEBUG ablation / trace variants are separate instantiations: the production kernel carries none
+  // of their branches (only a few bit patterns are built; anything else runs the production kernel)
+  if (sizeof(T) == 2 && NCH == 1) {
+    switch (a.dbg) {
+      case 32: return launch_c32_dbg<T, NCH, R, 32>(a, lds, grid, st);
+      case 13: return launch_c32_dbg<T, NCH, R, 13>(a, lds, grid, st);
+      case 45: return launch_c32_dbg<T, NCH, R, 45>(a, lds, grid, st);
+      case 205: return launch_c32_dbg<T, NCH, R, 205>(a, lds, grid, st);
+      case 237: return launch_c32_dbg<T, NCH, R, 237>(a, lds, grid, st);
+      case 1: return launch_c32_dbg<T, NCH, R, 1>(a, lds, grid, st);
+      case 4: return launch_c32_dbg<T, NCH, R, 4>(a, lds, grid, st);
+      case 8: return launch_c32_dbg<T, NCH, R, 8>(a, lds, grid, st);
+      case 12: return launch_c32_dbg<T, NCH, R, 12>(a, lds, grid, st);
+      case 5: return launch_c32_dbg<T, NCH, R, 5>(a, lds, grid, st);
+      case 256: return launch_c32_dbg<T, NCH, R, 256>(a, lds, grid, st);
+      case 512: return launch_c32_dbg<T, NCH, R, 512>(a, lds, grid, st);
+      case 1024: return launch_c32_dbg<T, NCH, R, 1024>(a, lds, grid, st);
+      case 1032: return launch_c32_dbg<T, NCH, R, 1032>(a, lds, grid, st);
+      case 768: return launch_c32_dbg<T, NCH, R, 768>(a, lds, grid, st);
+      case 261: return launch_c32_dbg<T, NCH, R, 261>(a, lds, grid, st);
+      default: break;
+    }
+  }
+  return launch_c32_dbg<T, NCH, R, 0>(a, lds, grid, st);
 }
 
 }  // namespace
 
 // Returns 1 if this launch is handled here, 0 if the generic kernel must take it, <0 on error.
 int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
-  static const int disabled = getenv("LD_CONV_NO_C32") ? 1 : 0;
-  if (disabled || p->Cout != 32 || p->H < 32 || p->W < 32) return 0;
+  static const int disabled = getenv("LD_CONV_NO_C32") ? atoi(getenv("LD_CONV_NO_C32")) : 0;
+  if (disabled || p->Cout != 32 || p->H < 32 || p->W < 32 || p->H % 16 != 0 || p->W % 16 != 0) return 0;
   const int ck = p->dtype == LD_F32 ? 16 : 32;
   int ctot = 0;
   for (int s = 0; s < p->nsrc; ++s) ctot += p->src[s].C;
-  // measured in situ (cfg3): single-chunk convs gain 3-8 us over the generic kernel, two-chunk ones lose ~5 us
-  static const int max_chunks = getenv("LD_CONV_C32_CHUNKS") ? atoi(getenv("LD_CONV_C32_CHUNKS")) : 1;
-  if (ctot / ck > max_chunks || ctot / ck > 2) return 0;
+  static const int max_chunks = getenv("LD_CONV_C32_CHUNKS") ? atoi(getenv("LD_CONV_C32_CHUNKS")) : 2;
+  const int nch = ctot / ck;
+  if (nch > max_chunks || nch > 2) return 0;
+  if (p->nsrc == 2 && p->src[0].C != ck) return 0;     // a K-chunk never straddles the two sources
   if (p->out_stats && (p->out_groups <= 0 || 32 % p->out_groups != 0)) return 0;
-  const long tiles = (long)((p->W + 15) / 16) * ((p->H + 15) / 16) * p->B;
-  if (tiles < 1024) return 0;                          // too few tiles to amortise a persistent workgroup
+  static const long min_tiles = getenv("LD_CONV_C32_MIN_TILES") ? atol(getenv("LD_CONV_C32_MIN_TILES")) : 1024;
+  const long tiles = (long)(p->W / 16) * (p->H / 16) * p->B;
+  if (tiles < min_tiles) return 0;                     // too few tiles to amortise a persistent workgroup
+  for (int s = 0; s < p->nsrc; ++s) {                  // the kernel uses 32-bit element offsets
+    const long ld = p->src[s].pix_stride > 0 ? p->src[s].pix_stride : p->src[s].C;
+    if ((long)p->B * p->H * p->W * ld >= (1L << 31)) return 0;
+  }
   C32Dev a;
   a.nsrc = p->nsrc;
   for (int s = 0; s < p->nsrc; ++s) a.s[s] = to_dev(p->src[s]);
@@ -317,6 +446,15 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   a.B = p->B; a.H = p->H; a.W = p->W; a.t_ptr = p->t_ptr; a.tiles_x = a.ntiles = 0;
   static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
   a.dbg = dbg;
-  const int rc = p->dtype == LD_F32 ? launch_c32<float>(a, st) : launch_c32<bf16>(a, st);
+  int rc;
+  if (p->dtype == LD_F32) rc = nch == 1 ? launch_c32<float, 1, 6>(a, st) : launch_c32<float, 2, 5>(a, st);
+  else rc = nch == 1 ? launch_c32<bf16, 1, 6>(a, st) : launch_c32<bf16, 2, 5>(a, st);
   return rc == LD_OK ? 1 : rc;
+}
+
+// Debug hook (not part of the public ABI): cycle stamps of the last LD_CONV_DEBUG&32 launch (16 uint64).
+extern "C" int ld_debug_c32_trace(unsigned long long* host) {
+  LD_HIP(hipDeviceSynchronize());
+  LD_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c32_trace), sizeof(unsigned long long) * 16));
+  return LD_OK;
 }

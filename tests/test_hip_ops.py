@@ -446,8 +446,20 @@ def test_conv3x3_c32_persistent_path(dtype):
     src = hh.make_src(hh.nhwc(x, dtype), cin, gn=(hh.stats_striped(x, 8), g_d, b_d, 8), act=cabi.ACT_SILU, film=f_d, film_b=2 * cin)
     out = hh.conv3x3([src], hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype)
     assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
-    if dtype == "bf16":
-        # 64 -> 32: (upsampled 32 ch) ++ (32 ch), and a width that is not a multiple of 16
+    # 64 -> 32 in two K-chunks (bf16: upsampled 32 ch ++ 32 ch; fp32: four 16-channel chunks -> generic kernel),
+    # statistics + prologue on the second source, on a multiple-of-16 width (deep-ring kernel) and a ragged one
+    for Wr in ((256, 250) if dtype == "bf16" else ()):
+        x1, x2 = _q(hh.rand((B, 32, H // 2, Wr // 2), 207), dtype), _q(hh.rand((B, 32, H, Wr), 208), dtype)
+        w2 = _q(hh.rand((cout, 64, 3, 3), 209, -0.1, 0.1), dtype)
+        y2 = F.silu(F.group_norm(x2, 8, gamma, beta, eps=1e-5))
+        ref = F.conv2d(torch.cat([F.interpolate(x1, scale_factor=2, mode="nearest"), y2], 1), w2, b, padding=1)
+        stats = hh.stats_buffer(B, 8)
+        src2 = hh.make_src(hh.nhwc(x2, dtype), 32, gn=(hh.stats_striped(x2, 8), g_d, b_d, 8), act=cabi.ACT_SILU)
+        out = hh.conv3x3([hh.make_src(hh.nhwc(x1, dtype), 32, ups=1), src2],
+                         hh.pack(w2, dtype, 3), b.to(hh.DEV), B, H, Wr, cout, dtype, stats=stats, groups=8)
+        assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
+        assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, 8)) < 1e-2
+    if False:
         Wr = 250
         x1, x2 = _q(hh.rand((B, 32, H // 2, Wr // 2), 207), dtype), _q(hh.rand((B, 32, H, Wr), 208), dtype)
         w2 = _q(hh.rand((cout, 64, 3, 3), 209, -0.1, 0.1), dtype)
