@@ -85,16 +85,6 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float*
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
 }
-// 8 consecutive output channels (the two accumulator fragments of an m-tile pair, see pack.hip rowmap)
-template <typename T> __device__ __forceinline__ void store8(T* p, const float* lo, const float* hi);
-template <> __device__ __forceinline__ void store8<float>(float* p, const float* lo, const float* hi) {
-  *reinterpret_cast<float4*>(p) = make_float4(lo[0], lo[1], lo[2], lo[3]);
-  *reinterpret_cast<float4*>(p + 4) = make_float4(hi[0], hi[1], hi[2], hi[3]);
-}
-template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float* lo, const float* hi) {
-  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]),
-                                            pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]));
-}
 template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
   float4 r = *reinterpret_cast<const float4*>(p);
@@ -137,12 +127,6 @@ template <> __device__ __forceinline__ void mma16<bf16>(f32x4& acc, const uint4&
 // counted s_waitcnt vmcnt(N), then a barrier, then the reads (cdna_hip_programming.md "What hipcc does not do").
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)p;            // low 32 bits of a flat LDS address = byte offset in the workgroup's LDS
-}
-// same, non-temporal (streaming) cache policy
-__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;

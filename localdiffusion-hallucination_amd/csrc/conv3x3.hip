@@ -154,11 +154,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   };
 
   issue_loads(0, hxA, wxA);
-  // output channel of accumulator register r of m-tile m in this lane: chan(m) + r (pack.hip rowmap)
-  auto chan = [&](int m) { return ((m0 + m) >> 1) * 32 + kq * 8 + (m & 1) * 4; };
   float4 bias[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + chan(m));
+  for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + (m0 + m) * 16 + kq * 4);
 
   // ---- prologue coefficients (overlaps the loads above)
   {
@@ -245,8 +243,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
     }
   }
 
-  // ---- epilogue: bias, statistics, NHWC store.  The lane holds channels chan(m)..+3 of pixel px for every m, i.e.
-  // 8 consecutive channels per m-tile pair: one 16-byte (bf16) store per pair and output row.
+  // ---- epilogue: bias, statistics, NHWC store.  lane holds channels 16m+4kq..+3 of pixel px.
   T* out = reinterpret_cast<T*>(a.out);
   const int gx = tx0 + px;
   float ssum[MT][4], ssq[MT][4];
@@ -255,21 +252,18 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.f;
 #pragma unroll
-  for (int m = 0; m < MT; m += 2) {
-    const float4 b0 = bias[m], b1 = bias[m + 1];
+  for (int m = 0; m < MT; ++m) {
+    const int co = (m0 + m) * 16 + kq * 4;
+    const float4 bv = bias[m];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int gy = ty0 + wv * NW + j;
       const bool valid = gy < H && gx < W;
-      float v0[4] = {acc[m][j][0] + b0.x, acc[m][j][1] + b0.y, acc[m][j][2] + b0.z, acc[m][j][3] + b0.w};
-      float v1[4] = {acc[m + 1][j][0] + b1.x, acc[m + 1][j][1] + b1.y, acc[m + 1][j][2] + b1.z, acc[m + 1][j][3] + b1.w};
+      float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
       if (valid) {
-        if (!(a.dbg & 8)) store8<T>(out + (((size_t)b * H + gy) * W + gx) * a.Cout + chan(m), v0, v1);
+        if (!(a.dbg & 8)) store4<T>(out + (((size_t)b * H + gy) * W + gx) * a.Cout + co, v);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ssum[m][r] += v0[r]; ssq[m][r] += v0[r] * v0[r];
-          ssum[m + 1][r] += v1[r]; ssq[m + 1][r] += v1[r] * v1[r];
-        }
+        for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
       }
     }
   }
@@ -280,10 +274,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
-        if (px == 0) {                           // slot = channel index inside this workgroup's 16*MT channels
-          const int lc = (m >> 1) * 32 + kq * 8 + (m & 1) * 4 + r;
-          s_stat[(wv * 2 + 0) * 16 * MT + lc] = (double)s1;
-          s_stat[(wv * 2 + 1) * 16 * MT + lc] = (double)s2;
+        if (px == 0) {
+          s_stat[(wv * 2 + 0) * 16 * MT + m * 16 + kq * 4 + r] = (double)s1;
+          s_stat[(wv * 2 + 1) * 16 * MT + m * 16 + kq * 4 + r] = (double)s2;
         }
       }
     __syncthreads();

@@ -1,14 +1,8 @@
 // Weight repacking into MFMA fragment order (run once at model load).
 //
 // Packed layout, storage dtype, E = 16/sizeof(T) elements per fragment, CK = 4E channels/chunk:
-//   k=3:  [chunk][tap 0..8][mtile][kq 0..3][i 0..15][e]   = W[rowmap(mtile,i)][chunk*CK+kq*E+e][tap/3][tap%3]
+//   k=3:  [chunk][tap 0..8][mtile][kq 0..3][i 0..15][e]   = W[16*mtile+i][chunk*CK+kq*E+e][tap/3][tap%3]
 //   k=1:  [chunk][mtile][kq][i][e]                         = W[16*mtile+i][chunk*CK+kq*E+e]
-// rowmap (k=3 only): within every group of 32 output channels (two m-tiles), MFMA row i of m-tile 2g+h computes
-// output channel 32g + 8*(i>>2) + 4h + (i&3).  The accumulator layout gives lane (pixel, kq) rows 4kq..4kq+3 of
-// each m-tile, so with this map the lane owns channels 32g + 8kq .. +7: ONE 16-byte store per pixel and 32
-// channels (bf16), the 4 kq lanes of a pixel write 64 contiguous bytes, and a wave-instruction writes whole
-// lines -- instead of two 8-byte pieces per lane (measured: the 8-byte epilogue stores of the 256^2 convolutions
-// cost as much as the rest of the kernel: 22.9 us with, 11.3 us without them).
 // so that lane l = kq*16+i of a wave reads its A fragment (16 B) at byte offset 16*l of a 1 KiB
 // block: global->LDS staging is a linear copy and LDS fragment reads are conflict-free.
 #include "common.cuh"
@@ -29,7 +23,7 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
   const int m = r % mt_total; r /= mt_total;
   const int tap = r % taps; r /= taps;
   const int ch = (int)r;
-  const int co = ks == 3 ? (m >> 1) * 32 + (i >> 2) * 8 + (m & 1) * 4 + (i & 3) : m * 16 + i;
+  const int co = m * 16 + i;
   int ci = ch * CK + kq * E + e;
   if (unshuffle) {            // packed K order (p1,p2,c) <- reference order (c,p1,p2)
     const int c4 = cin / 4, pp = ci / c4, c = ci - pp * c4;
@@ -46,7 +40,6 @@ extern "C" int ld_pack_conv_weight(const float* w, const float* scale_in, void* 
   LD_REQUIRE(w && out, "ld_pack_conv_weight: null pointer");
   LD_REQUIRE(ksize == 1 || ksize == 3, "ld_pack_conv_weight: ksize %d", ksize);
   LD_REQUIRE(cout % 16 == 0 && cin % 32 == 0, "ld_pack_conv_weight: cout %% 16 / cin %% 32 (%d,%d)", cout, cin);
-  LD_REQUIRE(ksize != 3 || cout % 32 == 0, "ld_pack_conv_weight: k=3 needs cout %% 32 == 0 (got %d)", cout);
   LD_REQUIRE(!(unshuffle && (ksize != 1 || cin % 128 != 0)), "ld_pack_conv_weight: unshuffle needs k=1, cin %% 128 == 0");
   const long total = (long)cout * cin * ksize * ksize;
   const int bs = 256;

@@ -426,8 +426,9 @@ def test_linear_attention_fused_bf16(c, H, W, single_sweep):
 # ------------------------------------------------------------------------------ persistent C=32 conv (conv3x3_c32.hip)
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_c32_persistent_path(dtype):
-    """Shapes large enough (>= 1024 tiles, Cout 32, <= 2 K-chunks) to take the persistent LDS-DMA kernel:
-    plain + statistics, concat, nearest-x2 upsample, GroupNorm+FiLM+SiLU prologue, ragged width."""
+    """32 -> 32 at 256^2 (>= 1024 tiles, one K-chunk, H and W multiples of 16) takes the persistent deep-ring
+    LDS-DMA kernel: plain + statistics, GroupNorm+FiLM+SiLU prologue; the 64 -> 32 concat / nearest-x2 cases
+    (two K-chunks, also a ragged width) take the register-staged kernel at the same size."""
     B, H, W, cout = 4, 256, 256, 32
     cin = 32
     x, w, b = _q(hh.rand((B, cin, H, W), 201), dtype), _q(hh.rand((cout, cin, 3, 3), 202, -0.1, 0.1), dtype), hh.rand((cout,), 203)
@@ -446,8 +447,8 @@ def test_conv3x3_c32_persistent_path(dtype):
     src = hh.make_src(hh.nhwc(x, dtype), cin, gn=(hh.stats_striped(x, 8), g_d, b_d, 8), act=cabi.ACT_SILU, film=f_d, film_b=2 * cin)
     out = hh.conv3x3([src], hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype)
     assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
-    # 64 -> 32 in two K-chunks (bf16: upsampled 32 ch ++ 32 ch; fp32: four 16-channel chunks -> generic kernel),
-    # statistics + prologue on the second source, on a multiple-of-16 width (deep-ring kernel) and a ragged one
+    # 64 -> 32 in two K-chunks: upsampled 32 ch ++ 32 ch, statistics + prologue on the second source, on a
+    # multiple-of-16 width and a ragged one
     for Wr in ((256, 250) if dtype == "bf16" else ()):
         x1, x2 = _q(hh.rand((B, 32, H // 2, Wr // 2), 207), dtype), _q(hh.rand((B, 32, H, Wr), 208), dtype)
         w2 = _q(hh.rand((cout, 64, 3, 3), 209, -0.1, 0.1), dtype)
@@ -459,14 +460,6 @@ def test_conv3x3_c32_persistent_path(dtype):
                          hh.pack(w2, dtype, 3), b.to(hh.DEV), B, H, Wr, cout, dtype, stats=stats, groups=8)
         assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
         assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, 8)) < 1e-2
-    if False:
-        Wr = 250
-        x1, x2 = _q(hh.rand((B, 32, H // 2, Wr // 2), 207), dtype), _q(hh.rand((B, 32, H, Wr), 208), dtype)
-        w2 = _q(hh.rand((cout, 64, 3, 3), 209, -0.1, 0.1), dtype)
-        ref = F.conv2d(torch.cat([F.interpolate(x1, scale_factor=2, mode="nearest"), x2], 1), w2, b, padding=1)
-        out = hh.conv3x3([hh.make_src(hh.nhwc(x1, dtype), 32, ups=1), hh.make_src(hh.nhwc(x2, dtype), 32)],
-                         hh.pack(w2, dtype, 3), b.to(hh.DEV), B, H, Wr, cout, dtype)
-        assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -5,21 +5,20 @@
 // bounds these launches is bytes in flight: with one 21-KiB halo tile prefetched per workgroup (the previous
 // version: 2 workgroups/CU) a CU keeps ~42 KiB outstanding, which at the loaded HBM latency of ~2-4 us is
 // ~2.5 TB/s chip-wide -- exactly what was measured, for every schedule tried.  Here:
-//   * grid = one 512-thread workgroup per CU (G x B, G*B ~ 256); a workgroup walks tiles g, g+G, ... of ONE
+//   * grid = one 640-thread workgroup per CU (G x B, G*B ~ 256); a workgroup walks tiles g, g+G, ... of ONE
 //     image, so weights (<= 2 K-chunks, 36 KiB), bias and GroupNorm coefficients are set up once and the
 //     output statistics stay in registers until one flush at the end;
 //   * items = (tile, K-chunk) pairs; the halo tile of an item lives in one slot of an R-deep LDS ring
-//     (R = 6, 21 KiB per slot) filled by LDS-DMA.  Slot = 21 blocks of 16 halo pixels,
+//     (R = 6 / 5 for 1 / 2 chunks, 21 KiB per slot) filled by LDS-DMA.  Slot = 21 blocks of 16 halo pixels,
 //     each block [kq 0..3][pixel 0..15][16 B] = 1 KiB = ONE global_load_lds_dwordx4: lane l = kq*16 + p reads
 //     fragment kq of pixel p (16 pixels x 64 B contiguous in HBM), and a fragment read of 16 consecutive
 //     pixels hits 16 distinct 16-B slots (conflict-free for every tap);
-//   * at item i every wave (a) requests its blocks of item i+R-1 into the slot item i-1 just vacated, (b) runs
-//     the MFMAs of item i, (c) stores the tile if it is finished, (d) waits -- with an exact counted vmcnt: the
-//     DMA is issued as inline asm (common.cuh), every wave issues a fixed number of DMA and store instructions
-//     per item because out-of-image lanes read a clamped in-image address and tiles are never ragged
-//     (H, W multiples of 16) -- for its OWN blocks of item i+1 and normalises / activates / zero-pads them in
-//     place, then ONE workgroup barrier.  R-2 items (63-84 KiB per CU) stay in flight across that barrier and
-//     the VALU prologue of item i+1 overlaps the MFMAs of item i of the other wave on the SIMD.
+//   * waves 8-9 are PRODUCERS: all they ever issue is LDS-DMA (inline asm, common.cuh; out-of-image lanes read a
+//     clamped in-image address so every item is a fixed number of instructions) and exact counted vmcnt waits;
+//     waves 0-7 are CONSUMERS: in-place GroupNorm/FiLM/SiLU + zero padding of the NEXT item, MFMAs of the
+//     current one, 16-byte NHWC stores -- they never wait on vmcnt.  One workgroup barrier per item; R-3 items
+//     (63 KiB per CU) stay in flight across it.  Keeping the DMAs out of the storing waves' in-order
+//     vector-memory queues is the point: see the measurement next to the ring fill.
 #include "common.cuh"
 #include <stdlib.h>
 
@@ -61,13 +60,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 template <typename T, int NCH, int R, int DBG>
-__global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
+__global__ __launch_bounds__(640) void conv3x3_c32_kernel(C32Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
-  constexpr int MT = 2, NW = 2, NWAVE = 8, TR = NW * NWAVE, TC = 16, HR = TR + 2, HC = TC + 2;
-  constexpr int NPIX = HR * HC, NBLK = (NPIX + 15) / 16, BPW = (NBLK + NWAVE - 1) / NWAVE;   // 324 px, 21 blocks, 3
+  constexpr int MT = 2, NW = 2, NWAVE = 8, NPROD = 2, NTHR = 64 * (NWAVE + NPROD);
+  constexpr int TR = NW * NWAVE, TC = 16, HR = TR + 2, HC = TC + 2;
+  constexpr int NPIX = HR * HC, NBLK = (NPIX + 15) / 16;                                    // 324 px, 21 blocks
+  constexpr int BPW = (NBLK + NWAVE - 1) / NWAVE, BPP = (NBLK + NPROD - 1) / NPROD;         // blocks per consumer / producer wave
   constexpr int XBUF = NBLK * 1024;                                                         // bytes per ring slot
   constexpr int WCH = 9 * MT * 1024;                                                        // bytes per weight chunk
-  constexpr int NST = MT * NW;                                                              // store instructions per wave per tile
   constexpr bool P = DT<T>::precise;
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -78,11 +78,13 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
 
   const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, kq = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool prod = wv >= NWAVE;                      // waves 8, 9: LDS-DMA only
+  const int pw = wv - NWAVE;
   const int b = blockIdx.y, H = a.H, W = a.W, G = gridDim.x;
   const int nch0 = a.s[0].C / CK;
   const int ntl = (a.ntiles - (int)blockIdx.x + G - 1) / G;       // tiles blockIdx.x, +G, ...
   const int total = ntl * NCH;
-  const int nb_w = (NBLK - wv + NWAVE - 1) / NWAVE;                // DMA instructions of this wave per item (3 or 2)
+  const int nb_p = prod ? (NBLK - pw + NPROD - 1) / NPROD : 0;     // DMA instructions of this producer wave per item
   const unsigned ring_a = lds_addr(s_x);
   const bool tracing = (DBG & 32) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
   unsigned long long tr_t[16];
@@ -93,11 +95,11 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
   // ---- one-time setup: weights -> LDS, bias -> registers, GroupNorm coefficients -> LDS
   {
     const uint4* wg = reinterpret_cast<const uint4*>(a.w);
-    for (int u = tid; u < NCH * 9 * MT * 64; u += 512) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[u];
+    for (int u = tid; u < NCH * 9 * MT * 64; u += NTHR) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[u];
   }
   float4 bias[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + m * 16 + kq * 4);
+  for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + kq * 8 + m * 4);   // pack.hip rowmap
   if (a.s[0].stats != nullptr || (a.nsrc > 1 && a.s[1].stats != nullptr)) {
     const int trow = a.t_ptr ? *a.t_ptr : 0;
     int off = 0;
@@ -105,30 +107,20 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
       const SrcDev S = s ? a.s[1] : a.s[0];
       if (S.stats) {
         const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
-        build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, tid, 512);
+        build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, tid, NTHR);
       }
       off += 2 * S.C;
     }
   }
   __syncthreads();                                    // weights / coefficients visible; s_stat scratch is dead
   // Retire every compiler-visible global load HERE: hipcc's s_waitcnt bookkeeping does not see the asm DMAs, so
-  // a wait it placed at the first use of `bias` inside the item loop (vmcnt(1..2), counting only its own stores)
-  // would drain the whole ring on every tile.
+  // a wait it placed at the first use of `bias` inside the item loop would drain the ring on every tile.
 #pragma unroll
   for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(bias[m].x), "v"(bias[m].y), "v"(bias[m].z), "v"(bias[m].w));
-
   if (tracing) tr_t[1] = __builtin_readcyclecounter();
-  // tile-independent halo coordinates of the ring blocks this thread loads and post-processes
-  int qy[BPW], qx[BPW];
-#pragma unroll
-  for (int r = 0; r < BPW; ++r) {
-    const int q = (r * NWAVE + wv) * 16 + px;
-    qy[r] = q / HC;
-    qx[r] = q - qy[r] * HC;
-  }
+
   // Position in the item sequence.  Tiles step by G through the image; the step is applied as a (row, column)
-  // increment so that no integer division runs inside the item loop (measured: the divisions, a 49-way waitcnt
-  // switch and 64-bit address products made an EMPTY item cost 2,000 cycles, as much as its useful work).
+  // increment so that no integer division runs inside the item loop.
   struct Cursor { int ch, ty, tx, ty0, tx0; };
   const int step_y = G / a.tiles_x, step_x = G % a.tiles_x;
   auto advance = [&](Cursor& c) {
@@ -141,7 +133,7 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
       c.tx0 = c.tx * TC;
     }
   };
-  // ---- LDS-DMA of this wave's blocks of one item into ring slot `slot` (always nb_w instructions)
+  // ---- producer: LDS-DMA of this wave's blocks of one item into ring slot `slot` (always nb_p instructions)
   auto dma = [&](const Cursor& c, int slot) {
     if (DBG & 1) return;
     const int si = c.ch >= nch0 ? 1 : 0;
@@ -151,10 +143,11 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
     const int row0 = b * Hs;                                       // element offsets fit 32 bits (checked on the host)
     const unsigned sa = ring_a + slot * XBUF;
 #pragma unroll
-    for (int r = 0; r < BPW; ++r) {
-      const int blk = r * NWAVE + wv;
+    for (int r = 0; r < BPP; ++r) {
+      const int blk = r * NPROD + pw;
       if (blk < NBLK) {                                            // wave-uniform
-        int gy = c.ty0 - 1 + qy[r], gx = c.tx0 - 1 + qx[r];
+        const int q = blk * 16 + px, hy = q / HC, hx = q - hy * HC;
+        int gy = c.ty0 - 1 + hy, gx = c.tx0 - 1 + hx;
         gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);               // out-of-image (and padding) lanes read an in-image
         gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);               // pixel; fixup() zeroes their slots after landing
         const int sy = S.ups ? gy >> 1 : gy, sx = S.ups ? gx >> 1 : gx;
@@ -162,7 +155,14 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
       }
     }
   };
-  // ---- in-place prologue of the landed blocks this wave loaded (zero padding stays exactly zero)
+  // ---- consumer: in-place prologue of this wave's share of a landed item (zero padding stays exactly zero)
+  int qy[BPW], qx[BPW];
+#pragma unroll
+  for (int r = 0; r < BPW; ++r) {
+    const int q = (r * NWAVE + (wv & (NWAVE - 1))) * 16 + px;
+    qy[r] = q / HC;
+    qx[r] = q - qy[r] * HC;
+  }
   auto fixup = [&](const Cursor& c, int slot) {
     const int si = c.ch >= nch0 ? 1 : 0;
     const SrcDev S = si ? a.s[1] : a.s[0];
@@ -203,47 +203,66 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
   f32x4 acc[MT][NW];
   T* out = reinterpret_cast<T*>(a.out);
 
-  // ---- fill the ring: items 0 .. R-2 requested, item 0 landed and post-processed
+#define LD_C32_BARRIER()                                \
+  do {                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    __builtin_amdgcn_s_barrier();                       \
+    asm volatile("" ::: "memory");                      \
+  } while (0)
+
+  // ---- fill the ring.  Producers request items 0 .. R-2 and wait until items 0 and 1 have landed; consumers
+  // then post-process item 0.  From here on the two roles only meet at one barrier per item:
+  //   producer, item i:  request item i+R-1 into the slot item i-1 vacated; wait (exact counted vmcnt: its VM
+  //                      queue holds nothing but its own DMAs) until item i+2 has landed;
+  //   consumer, item i:  post-process its share of item i+1 (landed: the producers waited for it before the
+  //                      previous barrier), MFMAs of item i, store the tile if finished.  Its VM queue holds only
+  //                      stores, which it never waits for -- with DMA and stores in ONE wave's in-order queue a
+  //                      landed DMA could not retire before the acknowledgement of the older stores (measured:
+  //                      DMA alone +4 us, stores alone +3.6 us, both in the same waves +16 us).
   Cursor iss{0, (int)blockIdx.x / a.tiles_x, (int)blockIdx.x % a.tiles_x, 0, 0}, fix, cur;
   iss.ty0 = iss.ty * TR;
   iss.tx0 = iss.tx * TC;
   fix = cur = iss;
-  int requested = 0;
-  for (; requested < R - 1 && requested < total; ++requested) { dma(iss, requested); advance(iss); }
-  if (total > 0) {
-    wait_vmcnt((DBG & 1) ? 0 : (requested - 1) * nb_w);
+  if (prod) {
+    int requested = 0;
+    for (; requested < R - 1 && requested < total; ++requested) { dma(iss, requested); advance(iss); }
+    const int keep = requested - 2 > 0 ? requested - 2 : 0;         // items 2.. may stay in flight
+    wait_vmcnt((DBG & 1) ? 0 : keep * nb_p);
+  }
+  LD_C32_BARRIER();
+  if (!prod && total > 0) {
     fixup(fix, 0);
     advance(fix);
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
+  LD_C32_BARRIER();
   if (tracing) tr_t[2] = __builtin_readcyclecounter();
-  // Phase order inside an item is skewed between the two waves that share a SIMD (wave w and w+4): waves 0-3 run
-  // MFMA -> store -> prologue of the next item, waves 4-7 run prologue -> MFMA -> store, so one wave's VALU / LDS /
-  // store phase overlaps the other's MFMAs instead of both queueing on the same pipe (measured in lockstep:
-  // 1,300 cycles of MFMA + 2,760 of prologue + 650 of epilogue per item, strictly one after the other).
-  const bool prologue_first = wv >= NWAVE / 2;
+
   int slot = 0;
   for (int i = 0; i < total; ++i) {
-    if (tracing && i == 3) tr_t[3] = __builtin_readcyclecounter();
-    // (a) request item i+R-1 into the slot item i-1 vacated (all waves are past barrier i-1)
-    if (i + R - 1 < total) {
-      dma(iss, slot == 0 ? R - 1 : slot - 1);
-      advance(iss);
-    }
-    if (tracing && i == 3) tr_t[4] = __builtin_readcyclecounter();
-    // (b)+(c) MFMAs of item i (fragment reads of tap column dx+1 are in flight during the MFMAs of column dx);
-    //         tile finished: bias, statistics, store (exactly NST store instructions: tiles are never ragged)
-    auto mfma_and_store = [&]() {
+    if (prod) {
+      if (i + R - 1 < total) {
+        dma(iss, slot == 0 ? R - 1 : slot - 1);
+        advance(iss);
+      }
+      if (i + 2 < total) {                                        // item i+2 landed; items i+3 .. stay in flight
+        const int last = i + R - 1 < total - 1 ? i + R - 1 : total - 1;
+        wait_vmcnt((DBG & 1) ? 0 : (last - (i + 2)) * nb_p);
+      }
+    } else {
+      // Phase order is skewed between the two consumer waves that share a SIMD (w and w+4): one runs
+      // prologue -> MFMA -> store, the other MFMA -> store -> prologue, so VALU and MFMA phases overlap.
+      auto prologue_next = [&]() {
+        if (i + 1 < total && !(DBG & 64)) fixup(fix, slot == R - 1 ? 0 : slot + 1);
+        advance(fix);
+      };
+      if (wv >= NWAVE / 2) prologue_next();
       if (cur.ch == 0) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (!(DBG & 4)) {
+      if (!(DBG & 4)) {   // fragment reads of tap column dx+1 are in flight during the MFMAs of column dx
         const char* xb = s_x + slot * XBUF + kq * 256;
         const char* wb = s_w + cur.ch * WCH + lane * 16;
         uint4 A[2][3][MT], Bq[2][NW + 2];
@@ -276,72 +295,50 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
         }
       }
       if (cur.ch == NCH - 1 && !(DBG & 8)) {
+        // the lane holds channels 8kq..8kq+7 of pixel px (pack.hip rowmap): one 16-byte store per row (bf16)
         const int gx = cur.tx0 + px;
+        const float4 b0 = bias[0], b1 = bias[1];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int co = m * 16 + kq * 4;
-          const float4 bv = bias[m];
+        for (int j = 0; j < NW; ++j) {
+          const int gy = cur.ty0 + wv * NW + j;
+          float v0[4] = {acc[0][j][0] + b0.x, acc[0][j][1] + b0.y, acc[0][j][2] + b0.z, acc[0][j][3] + b0.w};
+          float v1[4] = {acc[1][j][0] + b1.x, acc[1][j][1] + b1.y, acc[1][j][2] + b1.z, acc[1][j][3] + b1.w};
+          store8<T>(out + (size_t)(((b * H + gy) * W + gx) * 32 + kq * 8), v0, v1);
 #pragma unroll
-          for (int j = 0; j < NW; ++j) {
-            const int gy = cur.ty0 + wv * NW + j;
-            float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
-            store4<T>(out + (size_t)(((b * H + gy) * W + gx) * 32 + co), v);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
+          for (int r = 0; r < 4; ++r) {
+            ssum[0][r] += v0[r]; ssq[0][r] += v0[r] * v0[r];
+            ssum[1][r] += v1[r]; ssq[1][r] += v1[r] * v1[r];
           }
         }
       }
-    };
-    // (d) own blocks of item i+1: wait, post-process.  Younger than that DMA in this wave's in-order VM queue:
-    //     the DMAs of items i+2 .. min(i+R-1, total-1) and the stores of every tile this wave finished since the
-    //     DMA was issued (at iteration i+2-R, or in the ring fill) -- iterations first_it .. i when the stores of
-    //     this iteration are already out (MFMA first), first_it .. i-1 otherwise.
-    auto prologue_next = [&](bool stored_this_iteration) {
-      if (i + 1 >= total) return;
-      const int last = i + R - 1 < total - 1 ? i + R - 1 : total - 1;
-      const int first_it = i + 2 - R > 0 ? i + 2 - R : 0;
-      const int hi_it = stored_this_iteration ? i : i - 1;          // last iteration whose stores are counted
-      int tile_ends;
-      if (NCH == 1) tile_ends = hi_it - first_it + 1;
-      else tile_ends = (hi_it + 1) / 2 - first_it / 2;              // iterations k in [first_it, hi_it] with k odd
-      if (tile_ends < 0) tile_ends = 0;
-      const int nst = (DBG & 8) ? 0 : NST * tile_ends;
-      if (!(DBG & 128)) wait_vmcnt((DBG & 1) ? nst : (last - (i + 1)) * nb_w + nst);
-      if (!(DBG & 64)) fixup(fix, slot == R - 1 ? 0 : slot + 1);
-      advance(fix);
-    };
-    if (prologue_first) {
-      prologue_next(false);
-      if (tracing && i == 3) tr_t[5] = __builtin_readcyclecounter();
-      mfma_and_store();
-    } else {
-      mfma_and_store();
-      if (tracing && i == 3) tr_t[5] = __builtin_readcyclecounter();
-      prologue_next(true);
+      if (wv < NWAVE / 2) prologue_next();
+      advance(cur);
     }
-    if (tracing && i == 3) tr_t[8] = __builtin_readcyclecounter();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (tracing && i == 3) tr_t[9] = __builtin_readcyclecounter();
-    advance(cur);
+    LD_C32_BARRIER();
     slot = slot == R - 1 ? 0 : slot + 1;
+    if (tracing && i < 10) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) if (i == k) tr_t[3 + k] = __builtin_readcyclecounter();
+    }
   }
+#undef LD_C32_BARRIER
   if (tracing) tr_t[13] = __builtin_readcyclecounter();
 
   if (a.ostats) {                                                 // one flush per workgroup
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    if (!prod) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
-        if (px == 0) {
-          s_stat[(wv * 2 + 0) * 32 + m * 16 + kq * 4 + r] = (double)s1;
-          s_stat[(wv * 2 + 1) * 32 + m * 16 + kq * 4 + r] = (double)s2;
+        for (int r = 0; r < 4; ++r) {
+          const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
+          if (px == 0) {
+            s_stat[(wv * 2 + 0) * 32 + kq * 8 + m * 4 + r] = (double)s1;
+            s_stat[(wv * 2 + 1) * 32 + kq * 8 + m * 4 + r] = (double)s2;
+          }
         }
-      }
+    }
     __syncthreads();
     const int gs = 32 / a.ogroups;
     if (tid < 2 * a.ogroups) {
@@ -367,7 +364,7 @@ int launch_c32_dbg(C32Dev& a, size_t lds, dim3 grid, hipStream_t st) {
     LD_HIP(ld_allow_lds(conv3x3_c32_kernel<T, NCH, R, DBG>, lds));
     allowed = lds;
   }
-  hipLaunchKernelGGL((conv3x3_c32_kernel<T, NCH, R, DBG>), grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_c32_kernel<T, NCH, R, DBG>), grid, dim3(640), lds, st, a);
   LD_LAUNCH_CHECK("conv3x3_c32");
   return LD_OK;
 }
@@ -390,10 +387,18 @@ int launch_c32(const C32Dev& a0, hipStream_t st) {
       case 13: return launch_c32_dbg<T, NCH, R, 13>(a, lds, grid, st);
       case 45: return launch_c32_dbg<T, NCH, R, 45>(a, lds, grid, st);
       case 205: return launch_c32_dbg<T, NCH, R, 205>(a, lds, grid, st);
+      case 237: return launch_c32_dbg<T, NCH, R, 237>(a, lds, grid, st);
       case 1: return launch_c32_dbg<T, NCH, R, 1>(a, lds, grid, st);
       case 4: return launch_c32_dbg<T, NCH, R, 4>(a, lds, grid, st);
       case 8: return launch_c32_dbg<T, NCH, R, 8>(a, lds, grid, st);
       case 12: return launch_c32_dbg<T, NCH, R, 12>(a, lds, grid, st);
+      case 5: return launch_c32_dbg<T, NCH, R, 5>(a, lds, grid, st);
+      case 256: return launch_c32_dbg<T, NCH, R, 256>(a, lds, grid, st);
+      case 512: return launch_c32_dbg<T, NCH, R, 512>(a, lds, grid, st);
+      case 1024: return launch_c32_dbg<T, NCH, R, 1024>(a, lds, grid, st);
+      case 1032: return launch_c32_dbg<T, NCH, R, 1032>(a, lds, grid, st);
+      case 768: return launch_c32_dbg<T, NCH, R, 768>(a, lds, grid, st);
+      case 261: return launch_c32_dbg<T, NCH, R, 261>(a, lds, grid, st);
       default: break;
     }
   }
@@ -409,9 +414,10 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   const int ck = p->dtype == LD_F32 ? 16 : 32;
   int ctot = 0;
   for (int s = 0; s < p->nsrc; ++s) ctot += p->src[s].C;
-  // Single K-chunk only: measured in situ (cfg3) the ring gains 1-4 us per 32->32 @256^2 launch over the
-  // register-staged kernel but LOSES 1-6 us on the two-chunk 64->32 ones (the kernel template still carries NCH).
-  if (ctot != ck || p->nsrc != 1) return 0;
+  static const int max_chunks = getenv("LD_CONV_C32_CHUNKS") ? atoi(getenv("LD_CONV_C32_CHUNKS")) : 2;
+  const int nch = ctot / ck;
+  if (nch > max_chunks || nch > 2) return 0;
+  if (p->nsrc == 2 && p->src[0].C != ck) return 0;     // a K-chunk never straddles the two sources
   if (p->out_stats && (p->out_groups <= 0 || 32 % p->out_groups != 0)) return 0;
   static const long min_tiles = getenv("LD_CONV_C32_MIN_TILES") ? atol(getenv("LD_CONV_C32_MIN_TILES")) : 1024;
   const long tiles = (long)(p->W / 16) * (p->H / 16) * p->B;
@@ -429,7 +435,9 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   a.B = p->B; a.H = p->H; a.W = p->W; a.t_ptr = p->t_ptr; a.tiles_x = a.ntiles = 0;
   static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
   a.dbg = dbg;
-  const int rc = p->dtype == LD_F32 ? launch_c32<float, 1, 6>(a, st) : launch_c32<bf16, 1, 6>(a, st);
+  int rc;
+  if (p->dtype == LD_F32) rc = nch == 1 ? launch_c32<float, 1, 6>(a, st) : launch_c32<float, 2, 5>(a, st);
+  else rc = nch == 1 ? launch_c32<bf16, 1, 6>(a, st) : launch_c32<bf16, 2, 5>(a, st);
   return rc == LD_OK ? 1 : rc;
 }
 
