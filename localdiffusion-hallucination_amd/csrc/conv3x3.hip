@@ -40,7 +40,7 @@ struct Conv3Dev {
   int dbg;     // ablation switches (LD_CONV_DEBUG env, 0 in production): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
 
-template <typename T, int MT, int NW, bool DEEP>
+template <typename T, int MT, int NW, bool DEEP, int DBG>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int TR = 4 * NW, TC = 16, HR = TR + 2, HC = TC + 2;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
       if (q < NPIX) {
         const int hy = q / HC, hx_ = q - hy * HC;
         const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W && !(a.dbg & 1)) {
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W && !(DBG & 1)) {
           hvalid |= 1u << it;
           hoff0[it] = ((b * Hs0 + (S0.ups ? gy >> 1 : gy)) * Ws0 + (S0.ups ? gx >> 1 : gx)) * S0.ld + kq * E;
           hoff1[it] = ((b * Hs1 + (S1.ups ? gy >> 1 : gy)) * Ws1 + (S1.ups ? gx >> 1 : gx)) * S1.ld + kq * E;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   for (int k = 0; k < WU; ++k) {
     const int u = k * 256 + tid;
     const int tap = u / (MT * 64), r = u - tap * (MT * 64);
-    woff[k] = (u < UNITS && !(a.dbg & 2)) ? (tap * mt_total + m0) * 64 + r : -1;
+    woff[k] = (u < UNITS && !(DBG & 2)) ? (tap * mt_total + m0) * 64 + r : -1;
   }
   const int wstride = 9 * mt_total * 64;                // uint4 units per chunk
   auto issue_loads = [&](int ch, uint4 (&hx)[ITER], uint4 (&wx)[WU]) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   // ds_read latency is paid once per chunk instead of once per activation fragment (PMC on 256->256@32^2:
   // 38 % of wave cycles were s_waitcnt stalls with the read-then-use order).
   auto compute = [&]() {
-    if (a.dbg & 4) return;
+    if (DBG & 4) return;
     uint4 A[2][3][MT], Bq[2][NW + 2];
     auto load_frags = [&](int dx, int set) {
 #pragma unroll
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
       const bool valid = gy < H && gx < W;
       float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
       if (valid) {
-        if (!(a.dbg & 8)) store4<T>(out + (((size_t)b * H + gy) * W + gx) * a.Cout + co, v);
+        if (!(DBG & 8)) store4<T>(out + (((size_t)b * H + gy) * W + gx) * a.Cout + co, v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
       }
@@ -294,24 +294,44 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
   }
 }
 
-template <typename T, int MT, int NW, bool DEEP>
-int launch(const Conv3Dev& a, hipStream_t st) {
+template <typename T, int MT, int NW, bool DEEP, int DBG>
+int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   constexpr int TR = 4 * NW, HR = TR + 2, HC = 18;
   constexpr int NPIXP = (HR * HC + 15) / 16 * 16;
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
   const size_t lds = 4 * NPIXP * 16 + 9 * MT * 1024 + 2 * ctot * sizeof(float) + 4 * 2 * 16 * MT * sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
-    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP>, lds));
+    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG>, lds));
     allowed = lds;
   }
   Conv3Dev d = a;
   d.tiles_x = (a.W + 15) / 16;
   const int tiles_y = (a.H + TR - 1) / TR;
   dim3 grid(d.tiles_x * tiles_y, a.Cout / (16 * MT), a.B);
-  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NW, DEEP>), grid, dim3(256), lds, st, d);
+  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NW, DEEP, DBG>), grid, dim3(256), lds, st, d);
   LD_LAUNCH_CHECK("conv3x3");
   return LD_OK;
+}
+
+// The LD_CONV_DEBUG ablation variants are separate instantiations (bf16, non-DEEP only): the production kernel
+// carries none of their branches.
+template <typename T, int MT, int NW, bool DEEP>
+int launch(const Conv3Dev& a, hipStream_t st) {
+  if constexpr (sizeof(T) == 2 && !DEEP) {
+    switch (a.dbg) {
+      case 1: return launch_dbg<T, MT, NW, DEEP, 1>(a, st);
+      case 2: return launch_dbg<T, MT, NW, DEEP, 2>(a, st);
+      case 3: return launch_dbg<T, MT, NW, DEEP, 3>(a, st);
+      case 4: return launch_dbg<T, MT, NW, DEEP, 4>(a, st);
+      case 7: return launch_dbg<T, MT, NW, DEEP, 7>(a, st);
+      case 8: return launch_dbg<T, MT, NW, DEEP, 8>(a, st);
+      case 12: return launch_dbg<T, MT, NW, DEEP, 12>(a, st);
+      case 15: return launch_dbg<T, MT, NW, DEEP, 15>(a, st);
+      default: break;
+    }
+  }
+  return launch_dbg<T, MT, NW, DEEP, 0>(a, st);
 }
 
 template <typename T>
