@@ -20,12 +20,12 @@ def load(d, counter):
 
 def family(name):
     import re
-    m = re.search(r"conv3x3_c32_kernelI(f|DF16b)E", name)      # persistent variant of the <.,2,4> family
+    bf = "DF16b" in name or "bf16" in name or "_Accum" in name     # rocprofv3's demangler prints __bf16 as "bool _Accum"
+    if "conv3x3_c32_kernel" in name:                           # persistent variant of the <.,2,4> family
+        return f"conv3x3<{'bf16' if bf else 'f32'},2,4>"
+    m = re.search(r"conv3x3_kernelI(?:f|DF16b)Li(\d)ELi(\d)E", name) or re.search(r"conv3x3_kernel<[^,]+, (\d), (\d)", name)
     if m:
-        return f"conv3x3<{'f32' if m.group(1) == 'f' else 'bf16'},2,4>"
-    m = re.search(r"conv3x3_kernelI(f|DF16b)Li(\d)ELi(\d)E", name)
-    if m:
-        return f"conv3x3<{'f32' if m.group(1) == 'f' else 'bf16'},{m.group(2)},{m.group(3)}>"
+        return f"conv3x3<{'bf16' if bf else 'f32'},{m.group(1)},{m.group(2)}>"
     for key, fam in [("conv1x1", "conv1x1"), ("gn_apply", "gn_apply"), ("kvctx", "linattn_kvctx"), ("linout", "linattn_out"),
                      ("attention", "attention"), ("conv_image", "conv_image7x7")]:
         if key in name:
