@@ -159,6 +159,16 @@ int ld_conv_image(const float* x_nchw, const float* w_oihw, const float* bias, v
                   double* out_stats, int out_groups, int B, int Cin, int H, int W, int ksize,
                   int dtype, void* stream);
 
+/* init_conv 7x7 (ddpm.py:319,413) for bf16 storage as an implicit GEMM on MFMA: x NCHW fp32 [B,Cin<=3,H,W] ->
+ * out NHWC bf16 [B,H,W,32].  Image and weights are split into bf16 hi+lo parts (three MFMA products, fp32
+ * accumulate), so the result equals the fp32-FMA kernel of ld_conv_image up to the rounding of the stored bf16.
+ * w_packed: ld_stem_packed_bytes() bytes written once per model by ld_pack_stem_weight from the OIHW fp32 weight. */
+size_t ld_stem_packed_bytes(void);
+int ld_pack_stem_weight(const float* w_oihw /*[32,Cin,7,7]*/, void* out_packed, int Cin, void* stream);
+int ld_conv_stem(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H, int W,
+                 void* stream);
+
+
 /* ---- GroupNorm apply (+FiLM) + activation + residual, optional second normalised input ----- */
 /* ResnetBlock tail  h = SiLU(GN(conv2)) + res(x)  (ddpm.py:210-212) and BasicBlock tail
  * ReLU(GN(conv2) + GN(conv_id)) followed by MaxPool2d(2) (unet_model.py:38-51,120,123,129). */

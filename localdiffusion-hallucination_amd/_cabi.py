@@ -64,6 +64,9 @@ _SIGS = {
     "ld_pack_conv_weight": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_conv_image": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, vp]),
+    "ld_stem_packed_bytes": (C.c_size_t, []),
+    "ld_pack_stem_weight": (C.c_int, [vp, vp, C.c_int, vp]),
+    "ld_conv_stem": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_gn_apply": (C.c_int, [C.POINTER(GnApplyArgs), vp]),
     "ld_linattn_kmax": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_linattn_ctx": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -89,6 +89,132 @@ __global__ __launch_bounds__(256) void conv_image_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// init_conv 7x7 for bf16 storage on MFMA (ld_conv_stem).  The direct kernel above runs at the fp32 VALU roofline
+// (147 x 32 MACs per pixel: 72-84 us at 256^2, B=8); as an implicit GEMM the same convolution is
+// K = 21 kernel rows x 8 (kx padded from 7, zero weight) = 168 -> 6 K-chunks x 32 output channels.
+//   * K order k = (c*7 + ky)*8 + kx: the im2col B fragment of a lane (pixel px, k-quad kq) is ONE kernel row,
+//     8 consecutive words of the halo tile at a per-lane base (row 4*chunk + kq) + compile-time offsets;
+//   * precision: the fp32 image and the fp32 weights are each split into bf16 hi + lo parts and three MFMAs
+//     (w_hi x_hi + w_hi x_lo + w_lo x_hi) recover the product to ~2^-16 relative, fp32 accumulate -- the result
+//     matches the fp32-FMA kernel far below the bf16 rounding of the stored output.  The image is split once per
+//     halo pixel while it is staged (LDS word = hi | lo << 16; one v_perm_b32 per pair assembles a fragment), the
+//     weights once per model by ld_pack_stem_weight;
+//   * persistent workgroups (~2 per CU) keep the 24 weight fragments in registers and register-prefetch the next
+//     tile's halo before the MFMAs of the current one.
+constexpr int STEM_NCHK = 6;
+constexpr int STEM_PACKED_U16 = 2 * STEM_NCHK * 2 * 64 * 8;      // [hi|lo][chunk][m-tile][lane][8 bf16]
+
+__global__ void stem_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cin) {
+  constexpr int KS = 7;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 32 * STEM_NCHK * 32) return;
+  const int co = i / (STEM_NCHK * 32), k = i - co * (STEM_NCHK * 32);
+  const int kr = k >> 3, kx = k & 7, c = kr / KS, ky = kr - c * KS;
+  const float v = (c < Cin && kx < KS) ? w[(((size_t)co * Cin + c) * KS + ky) * KS + kx] : 0.f;
+  const bf16 hi = (bf16)v;
+  const bf16 lo = (bf16)(v - (float)hi);
+  const int ch = k >> 5, l = ((k >> 3) & 3) * 16 + (co & 15), e = k & 7, m = co >> 4;
+  const int slot = ((ch * 2 + m) * 64 + l) * 8 + e;
+  out[slot] = __builtin_bit_cast(unsigned short, hi);
+  out[STEM_NCHK * 2 * 64 * 8 + slot] = __builtin_bit_cast(unsigned short, lo);
+}
+
+__global__ __launch_bounds__(256) void conv_stem_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
+                                                             const float* __restrict__ bias, bf16* out, int B, int Cin,
+                                                             int H, int W, int tiles_x, int ntiles) {
+  constexpr int KS = 7, PAD = 3, TSX = 16, TSY = 32, HSX = TSX + KS - 1 + 1, HSY = TSY + KS - 1, NCHK = STEM_NCHK;
+  constexpr int NIN = 3 * HSY * HSX, NLD = (NIN + 255) / 256;
+  __shared__ unsigned s_in[NIN + 8];                     // per input pixel: bf16 hi part | bf16 lo part << 16
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.y;
+  uint4 Ahi[NCHK][2], Alo[NCHK][2];                      // this lane's weight fragments, straight from the packed image
+#pragma unroll
+  for (int ch = 0; ch < NCHK; ++ch)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      Ahi[ch][m] = wp[(ch * 2 + m) * 64 + lane];
+      Alo[ch][m] = wp[(NCHK * 2 + ch * 2 + m) * 64 + lane];
+    }
+  int offb[NCHK];                                        // halo offset of this lane's kernel row per chunk
+#pragma unroll
+  for (int ch = 0; ch < NCHK; ++ch) {
+    const int kr = ch * 4 + kq, c = kr / KS, ky = kr - c * KS;
+    offb[ch] = c < 3 ? (c * HSY + ky) * HSX : 0;         // rows past the last channel carry zero weights
+  }
+  float4 bv[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) bv[m] = *reinterpret_cast<const float4*>(bias + m * 16 + kq * 4);
+  if (tid < 8) s_in[NIN + tid] = 0u;
+  // halo staging is register-prefetched: tile t+1's pixels are requested before tile t's MFMAs
+  float stage[NLD];
+  auto request = [&](int t) {
+    const int y0 = (t / tiles_x) * TSY, x0 = (t % tiles_x) * TSX;
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+      const int i = r * 256 + tid;
+      float v = 0.f;
+      if (i < NIN) {
+        const int c = i / (HSY * HSX), q = i - c * HSY * HSX, hy = q / HSX, hx = q - hy * HSX;
+        const int gy = y0 - PAD + hy, gx = x0 - PAD + hx;
+        if (c < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[(((size_t)b * Cin + c) * H + gy) * W + gx];
+      }
+      stage[r] = v;
+    }
+  };
+  if ((int)blockIdx.x < ntiles) request(blockIdx.x);
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int y0 = (t / tiles_x) * TSY, x0 = (t % tiles_x) * TSX;
+    __syncthreads();                                     // previous tile's gathers are done
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+      const int i = r * 256 + tid;
+      if (i < NIN) {
+        const float v = stage[r];
+        const bf16 hi = (bf16)v;                         // split ONCE per halo pixel, not once per im2col use
+        const bf16 lo = (bf16)(v - (float)hi);
+        s_in[i] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+      }
+    }
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);
+    const int gx = x0 + px;
+#pragma unroll 2
+    for (int j = 0; j < TSY / 4; ++j) {
+      const int row = wv * (TSY / 4) + j;
+      const unsigned* pin = s_in + row * HSX + px;
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ch = 0; ch < NCHK; ++ch) {
+        const unsigned* pr = pin + offb[ch];
+        unsigned v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = pr[e];
+        // one byte-permute per pair assembles the packed hi (low halves) and lo (high halves) fragments
+        const uint4 Bhi = make_uint4(__builtin_amdgcn_perm(v[1], v[0], 0x05040100u), __builtin_amdgcn_perm(v[3], v[2], 0x05040100u),
+                                     __builtin_amdgcn_perm(v[5], v[4], 0x05040100u), __builtin_amdgcn_perm(v[7], v[6], 0x05040100u));
+        const uint4 Blo = make_uint4(__builtin_amdgcn_perm(v[1], v[0], 0x07060302u), __builtin_amdgcn_perm(v[3], v[2], 0x07060302u),
+                                     __builtin_amdgcn_perm(v[5], v[4], 0x07060302u), __builtin_amdgcn_perm(v[7], v[6], 0x07060302u));
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          mma16<bf16>(acc[m], Ahi[ch][m], Bhi);
+          mma16<bf16>(acc[m], Ahi[ch][m], Blo);
+          mma16<bf16>(acc[m], Alo[ch][m], Bhi);
+        }
+      }
+      const int gy = y0 + row;
+      if (gy < H && gx < W) {
+        bf16* op = out + (((size_t)b * H + gy) * W + gx) * CO;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          float r4[4] = {acc[m][0] + bv[m].x, acc[m][1] + bv[m].y, acc[m][2] + bv[m].z, acc[m][3] + bv[m].w};
+          store4<bf16>(op + m * 16 + kq * 4, r4);
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 int run(const float* x, const float* w, const float* bias, void* out, double* ostats, int ogroups, int B,
         int Cin, int H, int W, int ks, hipStream_t st) {
@@ -113,4 +239,28 @@ extern "C" int ld_conv_image(const float* x, const float* w, const float* bias, 
   if (dtype == LD_F32) return run<float>(x, w, bias, out, out_stats, out_groups, B, Cin, H, W, ksize, st);
   if (dtype == LD_BF16) return run<bf16>(x, w, bias, out, out_stats, out_groups, B, Cin, H, W, ksize, st);
   return ld_fail(LD_EINVAL, "ld_conv_image: bad dtype %d", dtype);
+}
+
+extern "C" size_t ld_stem_packed_bytes(void) { return (size_t)STEM_PACKED_U16 * sizeof(unsigned short); }
+
+extern "C" int ld_pack_stem_weight(const float* w_oihw, void* out_packed, int Cin, void* stream) {
+  LD_REQUIRE(w_oihw && out_packed, "ld_pack_stem_weight: null pointer");
+  LD_REQUIRE(Cin >= 1 && Cin <= 3, "ld_pack_stem_weight: Cin %d (1..3)", Cin);
+  hipLaunchKernelGGL(stem_pack_kernel, dim3((32 * STEM_NCHK * 32 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     w_oihw, (unsigned short*)out_packed, Cin);
+  LD_LAUNCH_CHECK("pack_stem_weight");
+  return LD_OK;
+}
+
+extern "C" int ld_conv_stem(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H,
+                            int W, void* stream) {
+  LD_REQUIRE(x && w_packed && bias && out, "ld_conv_stem: null pointer");
+  LD_REQUIRE(Cin >= 1 && Cin <= 3 && B > 0 && H > 0 && W > 0, "ld_conv_stem: bad shape (Cin %d)", Cin);
+  const int tiles_x = (W + 15) / 16, tiles_y = (H + 31) / 32, ntiles = tiles_x * tiles_y;
+  int G = (512 + B - 1) / B;                             // ~2 persistent workgroups per CU
+  if (G > ntiles) G = ntiles;
+  hipLaunchKernelGGL(conv_stem_mfma_kernel, dim3(G, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     (const uint4*)w_packed, bias, (bf16*)out, B, Cin, H, W, tiles_x, ntiles);
+  LD_LAUNCH_CHECK("conv_stem");
+  return LD_OK;
 }

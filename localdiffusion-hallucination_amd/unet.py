@@ -200,6 +200,12 @@ class Unet(nn.Module):
                 qb = wqn.reshape(heads, 32).amax(dim=1)          # softmax_d(q) shift per head (same bound, max over d)
                 P["qshift"][base] = qb.contiguous() if float(qb.max()) <= 40.0 else None
                 P["keep"].append(scale)
+        if self.compute_dtype == "bf16" and self.cfg.init_dim == 32:
+            wi = sd["init_conv.weight"].contiguous()
+            stem = torch.empty(int(lib.ld_stem_packed_bytes()), dtype=torch.uint8, device=dev)
+            cabi.check(lib.ld_pack_stem_weight(wi.data_ptr(), stem.data_ptr(), wi.shape[1], st), "pack init_conv")
+            P["stem"] = stem
+            P.setdefault("keep", []).append(wi)
         for name, w in sd.items():
             if name.endswith(".to_out.1.g"):
                 g = w.flatten()
@@ -568,10 +574,18 @@ class _Plan:
         H, W = self.H, self.W
         r = self.buf(H, W, cfg.init_dim)
         wi, bi = f["init_conv.weight"], f["init_conv.bias"]
-        self._raw(ops, lambda st: cabi.check(lib.ld_conv_image(
-            self.x_in.data_ptr(), wi.data_ptr(), bi.data_ptr(), r.data_ptr(), None, 1, B, cfg.channels, H, W, 7,
-            self.dt, st), "init_conv"), "conv_image7x7",
-            nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W)
+        if self.dt == cabi.LD_BF16 and cfg.init_dim == 32:       # implicit GEMM on MFMA (hi/lo split: fp32-accurate)
+            wstem = self.P["stem"]
+            self.keep.append(wstem)
+            self._raw(ops, lambda st: cabi.check(lib.ld_conv_stem(
+                self.x_in.data_ptr(), wstem.data_ptr(), bi.data_ptr(), r.data_ptr(), B, cfg.channels, H, W, st),
+                "init_conv"), "conv_image7x7",
+                nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W)
+        else:
+            self._raw(ops, lambda st: cabi.check(lib.ld_conv_image(
+                self.x_in.data_ptr(), wi.data_ptr(), bi.data_ptr(), r.data_ptr(), None, 1, B, cfg.channels, H, W, 7,
+                self.dt, st), "init_conv"), "conv_image7x7",
+                nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W)
         self.named["init_conv"] = r
         x, c, h, w = r, cfg.init_dim, H, W
         skips = []

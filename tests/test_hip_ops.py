@@ -158,6 +158,29 @@ def test_conv_image(dtype, cin, ks, H, W):
     assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, 16)) < 1e-5
 
 
+@pytest.mark.parametrize("cin,H,W", [(3, 64, 48), (1, 28, 28), (3, 40, 33), (3, 256, 256)])
+def test_conv_stem_mfma_bf16(cin, H, W):
+    """init_conv 7x7 for bf16 storage as an im2col MFMA GEMM (hi/lo split of image and weights): equal to the fp32
+    reference up to the bf16 rounding of the stored output, and to the fp32-FMA kernel's bf16 output within one ulp."""
+    B = 2
+    x, w, b = hh.rand((B, cin, H, W), 43, -1.5, 1.5), hh.rand((32, cin, 7, 7), 44, -0.2, 0.2), hh.rand((32,), 45)
+    ref = F.conv2d(x, w, b, padding=3)
+    lib = cabi.lib()
+    xd, wd, bd = x.to(hh.DEV), w.to(hh.DEV).contiguous(), b.to(hh.DEV)
+    wp = torch.empty(int(lib.ld_stem_packed_bytes()), dtype=torch.uint8, device=hh.DEV)
+    cabi.check(lib.ld_pack_stem_weight(wd.data_ptr(), wp.data_ptr(), cin, hh.st()), "pack_stem")
+    out = torch.empty(B, H, W, 32, dtype=torch.bfloat16, device=hh.DEV)
+    cabi.check(lib.ld_conv_stem(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), B, cin, H, W, hh.st()), "conv_stem")
+    got = hh.nchw(out)
+    assert hh.rel_err(got, ref) < hh.RTOL["bf16"]
+    # the split products keep fp32-level accuracy: the only error left is the final bf16 rounding (half an ulp <= 2^-8)
+    assert float(((got - ref).abs() / ref.abs().clamp_min(0.25)).max()) < 2.0 ** -8 * 1.02
+    out2 = torch.empty_like(out)
+    cabi.check(lib.ld_conv_image(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out2.data_ptr(), None, 0, B, cin, H, W, 7,
+                                 cabi.LD_BF16, hh.st()), "conv_image")
+    assert float((got - hh.nchw(out2)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
 # ------------------------------------------------------------------------------ gn_apply
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gn_apply_resblock_tail_and_basicblock_tail(dtype):
