@@ -33,7 +33,9 @@ struct Conv1Dev {
   int B, H, W, Cout;
 };
 
-template <typename T, int MT, int NW>
+// EPI (the epilogue kind) is a template parameter: as a runtime switch inside the store loop it kept every
+// epilogue's registers and branches alive in every launch.
+template <typename T, int MT, int NW, int EPI>
 __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int NPT = 64 * NW, PLANE = NPT * 16;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   const int HW = a.H * a.W, p0 = blockIdx.x * NPT;
   const int mt_total = a.Cout / 16;
 
-  if (a.epi == LD_EPI_GN_TAIL)
+  if (EPI == LD_EPI_GN_TAIL)
     build_gn_coef(a.tail, b, 0, (long)HW, s_tcoef, reinterpret_cast<double*>(s_tcoef + 2 * a.Cout), tid, 256);
 
   f32x4 acc[MT][NW];
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[m][r] = acc[m][j][r] * rinv + (a.bias ? a.bias[co + r] : 0.f);
     }
-    if (a.epi == LD_EPI_QKV_LINEAR && q_part) {
+    if (EPI == LD_EPI_QKV_LINEAR && q_part) {
       // softmax over the 32 channels of each head = 2 channel tiles x 4 regs x 4 kq lanes
 #pragma unroll
       for (int m = 0; m < MT; m += 2) {   // MT is even; (m, m+1) = one head
@@ -179,12 +181,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[m][r] *= sc; v[m + 1][r] *= sc; }
       }
-    } else if (a.epi == LD_EPI_QKV_FULL && q_part) {
+    } else if (EPI == LD_EPI_QKV_FULL && q_part) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[m][r] *= a.q_scale;
-    } else if (a.epi == LD_EPI_RMS_RES) {
+    } else if (EPI == LD_EPI_RMS_RES) {
       float ss = 0.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -211,12 +213,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
       for (int m = 0; m < MT; ++m) {
         const int co = (m0 + m) * 16 + kq * 4;
         const size_t o = ((size_t)b * HW + p) * a.Cout + co;
-        if (a.epi == LD_EPI_RMS_RES || a.epi == LD_EPI_RES) {
+        if (EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES) {
           float rv[4];
           load4<T>(res + o, rv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
-        } else if (a.epi == LD_EPI_GN_TAIL) {
+        } else if (EPI == LD_EPI_GN_TAIL) {
           float rv[4];
           load4<T>(reinterpret_cast<const T*>(a.tail.data) + o, rv);
           affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
@@ -250,15 +252,27 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   }
 }
 
-template <typename T, int MT, int NW>
-int launch(const Conv1Dev& a, hipStream_t st) {
+template <typename T, int MT, int NW, int EPI>
+int launch_epi(const Conv1Dev& a, hipStream_t st) {
   constexpr int NPT = 64 * NW;
-  const size_t lds = 4 * NPT * 16 + MT * 1024 + NPT * sizeof(float) + (a.epi == LD_EPI_GN_TAIL ? 2 * a.Cout * sizeof(float) + 64 * sizeof(double) : 0);
+  const size_t lds = 4 * NPT * 16 + MT * 1024 + NPT * sizeof(float) + (EPI == LD_EPI_GN_TAIL ? 2 * a.Cout * sizeof(float) + 64 * sizeof(double) : 0);
   const int HW = a.H * a.W;
   dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
-  hipLaunchKernelGGL((conv1x1_kernel<T, MT, NW>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv1x1_kernel<T, MT, NW, EPI>), grid, dim3(256), lds, st, a);
   LD_LAUNCH_CHECK("conv1x1");
   return LD_OK;
+}
+
+template <typename T, int MT, int NW>
+int launch(const Conv1Dev& a, hipStream_t st) {
+  switch (a.epi) {
+    case LD_EPI_PLAIN: return launch_epi<T, MT, NW, LD_EPI_PLAIN>(a, st);
+    case LD_EPI_QKV_LINEAR: return launch_epi<T, MT, NW, LD_EPI_QKV_LINEAR>(a, st);
+    case LD_EPI_QKV_FULL: return launch_epi<T, MT, NW, LD_EPI_QKV_FULL>(a, st);
+    case LD_EPI_RMS_RES: return launch_epi<T, MT, NW, LD_EPI_RMS_RES>(a, st);
+    case LD_EPI_RES: return launch_epi<T, MT, NW, LD_EPI_RES>(a, st);
+    default: return launch_epi<T, MT, NW, LD_EPI_GN_TAIL>(a, st);
+  }
 }
 
 template <typename T>
