@@ -191,12 +191,27 @@ __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, 
                                               double* red, int tid, int nthreads) {
   const int C = S.C, G = S.groups, gs = C / G;
   float* gstat = reinterpret_cast<float*>(red);          // after the stripe sum: [G] mean, [G] rstd (floats)
+  // Request order matters (vector loads issue in order): first the 2*stripes statistics words of this thread's
+  // group, then gamma / beta / FiLM of its first channel -- which do not depend on the statistics and whose
+  // address needs the (long since loaded) step index -- and only then the arithmetic: one global round trip
+  // instead of two in front of every consumer launch.
+  double st1[LD_STAT_STRIPES], st2[LD_STAT_STRIPES];
+  if (tid < G) {
+    const double* p = S.stats + (size_t)b * LD_STAT_STRIPES * G * 2 + 2 * tid;
+#pragma unroll
+    for (int s = 0; s < LD_STAT_STRIPES; ++s) { st1[s] = p[(size_t)s * G * 2]; st2[s] = p[(size_t)s * G * 2 + 1]; }
+  }
+  const float* film = S.film ? S.film + (long)trow * S.film_tstride + (long)b * S.film_bstride : nullptr;
+  float g0 = 0.f, b0 = 0.f, f0 = 0.f, f1 = 0.f;
+  if (tid < C) {
+    g0 = S.gamma[tid]; b0 = S.beta[tid];
+    if (film) { f0 = film[tid]; f1 = film[C + tid]; }
+  }
   if (tid < G) {
     // sum the stripes in fp64, then ONE double divide/sqrt per group (not per channel)
-    const double* p = S.stats + (size_t)b * LD_STAT_STRIPES * G * 2 + 2 * tid;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int s = 0; s < LD_STAT_STRIPES; ++s) { s1 += p[(size_t)s * G * 2]; s2 += p[(size_t)s * G * 2 + 1]; }
+    for (int s = 0; s < LD_STAT_STRIPES; ++s) { s1 += st1[s]; s2 += st2[s]; }
     const double inv_n = 1.0 / ((double)npix * gs);
     const double mean = s1 * inv_n;
     double var = s2 * inv_n - mean * mean;
@@ -206,13 +221,13 @@ __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, 
     gstat[G + tid] = rstd;
   }
   __syncthreads();
-  const float* film = S.film ? S.film + (long)trow * S.film_tstride + (long)b * S.film_bstride : nullptr;
   for (int c = tid; c < C; c += nthreads) {
     const int g = c / gs;
-    float a = gstat[G + g] * S.gamma[c];
-    float s = S.beta[c] - gstat[g] * a;
+    const bool first = c == tid;
+    float a = gstat[G + g] * (first ? g0 : S.gamma[c]);
+    float s = (first ? b0 : S.beta[c]) - gstat[g] * a;
     if (film) {
-      const float sc = film[c] + 1.0f, sh = film[C + c];
+      const float sc = (first ? f0 : film[c]) + 1.0f, sh = first ? f1 : film[C + c];
       a *= sc;
       s = s * sc + sh;
     }
