@@ -425,6 +425,13 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
   for (int u = tid; u < NCH * 8 * 64; u += 256) *reinterpret_cast<uint4*>(s_wq + u * 16) = a.wq[u];
   const uint4* mf = a.mfold + (size_t)b * 4 * MT2 * 64;
   for (int u = tid; u < 4 * MT2 * 64; u += 256) *reinterpret_cast<uint4*>(s_mf + u * 16) = mf[u];
+  // bias and the RMSNorm gain of this lane's output channels: loaded once, not inside the per-pixel epilogue
+  float4 bvr[MT2], gvr[MT2];
+#pragma unroll
+  for (int m2 = 0; m2 < MT2; ++m2) {
+    bvr[m2] = *reinterpret_cast<const float4*>(a.bias + m2 * 16 + kq * 4);
+    gvr[m2] = *reinterpret_cast<const float4*>(a.g2 + m2 * 16 + kq * 4);
+  }
   float qs2[4] = {0.f, 0.f, 0.f, 0.f};
   if (a.qshift) {
 #pragma unroll
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
     float y[MT2][4];
 #pragma unroll
     for (int m2 = 0; m2 < MT2; ++m2) {
-      const float4 bv = *reinterpret_cast<const float4*>(a.bias + m2 * 16 + kq * 4);
+      const float4 bv = bvr[m2];
       y[m2][0] = o[m2][0] + bv.x; y[m2][1] = o[m2][1] + bv.y; y[m2][2] = o[m2][2] + bv.z; y[m2][3] = o[m2][3] + bv.w;
 #pragma unroll
       for (int r = 0; r < 4; ++r) ss = fmaf(y[m2][r], y[m2][r], ss);
@@ -527,9 +534,10 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
 #pragma unroll
       for (int m2 = 0; m2 < MT2; ++m2) {
         const int co = m2 * 16 + kq * 4;
-        const float4 gv = *reinterpret_cast<const float4*>(a.g2 + co);
+        const float4 gv = gvr[m2];
+        // the residual x is already in the staging tile: channels co..co+3 = chunk m2/2, fragment 2*(m2&1) + kq/2
         float xr[4];
-        load4<bf16>(xb + (size_t)p * C + co, xr);
+        load4<bf16>(reinterpret_cast<const bf16*>(s_x + ((m2 >> 1) * 4 + (m2 & 1) * 2 + (kq >> 1)) * PLANE + qq * 16 + (kq & 1) * 8), xr);
         float r4[4] = {y[m2][0] * inv * gv.x + xr[0], y[m2][1] * inv * gv.y + xr[1],
                        y[m2][2] * inv * gv.z + xr[2], y[m2][3] * inv * gv.w + xr[3]};
         store4<bf16>(a.out + ((size_t)b * n + p) * C + co, r4);
