@@ -27,7 +27,8 @@ def family(name):
     if m:
         return f"conv3x3<{'bf16' if bf else 'f32'},{m.group(1)},{m.group(2)}>"
     for key, fam in [("conv1x1", "conv1x1"), ("gn_apply", "gn_apply"), ("kvctx", "linattn_kvctx"), ("linout", "linattn_out"),
-                     ("attention", "attention"), ("conv_image", "conv_image7x7")]:
+                     ("attention", "attention"), ("conv_image", "conv_image7x7"), ("conv_stem", "conv_image7x7"),
+                     ("ctxfold", "linattn_ctxfold")]:
         if key in name:
             return fam
     return None
