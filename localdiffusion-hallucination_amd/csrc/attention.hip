@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 // LDS: K as [kgrp][key][16 B] planes (conflict-free b128 reads), V as 96-byte rows (64 B data +
 // 32 B pad: the 8 rows a half-wave's transposed read touches land on 8 disjoint bank octets).
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-constexpr int TKV = 64;
+constexpr int TKV = 128;                // keys per tile: one barrier pair, one max/sum shuffle pair per 128 keys
 constexpr int VROW = 96;
 
 __device__ __forceinline__ uint2 tr_read(const char* p) {
@@ -135,7 +135,8 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
 
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                              int n, int heads) {
-  __shared__ __attribute__((aligned(16))) uint4 s_k[4][TKV];
+  constexpr int NKT = TKV / 16, NST = TKV / 64;          // 16-key MFMA tiles per tile; staging rows per thread
+  __shared__ __attribute__((aligned(16))) uint4 s_k[4][TKV + 1];   // +1: the 4 chunk lanes of a key write 4 distinct bank quads
   __shared__ __attribute__((aligned(16))) char s_v[TKV * VROW];
   const int hidden = heads * D;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
@@ -147,33 +148,47 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restr
   if (qi < n) qf = *reinterpret_cast<const uint4*>(base + (size_t)qi * rowstride + h * D + kg * 8);
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
   float m = -1e30f, l = 0.f;
-  const int skey = tid & 63, schunk = tid >> 6;          // staging role: one 16-B chunk of one key
+  // staging role: 4 consecutive lanes fetch the 64 contiguous bytes of one key's head slice (one line request per
+  // key; with one lane per key every lane touched its own 128-B line for 16 bytes: 8x the L2->L1 traffic)
+  const int skey = tid >> 2, schunk = tid & 3;
   const int tq = (lane >> 2) & 3, tp = lane & 3;         // transposed-read role inside the 16-lane group
-  for (int j0 = 0; j0 < n; j0 += TKV) {
-    __syncthreads();
-    {
-      const int j = j0 + skey;
-      uint4 kk = make_uint4(0u, 0u, 0u, 0u), vv = kk;
+  // register-staged prefetch (T14): the K/V rows of tile j+1 are requested before tile j's MFMAs, so the
+  // tiles of a 1024-key sequence cost one exposed global round trip instead of one each
+  uint4 kk[NST], vv[NST];
+  auto request = [&](int j0) {
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int j = j0 + u * 64 + skey;
+      kk[u] = make_uint4(0u, 0u, 0u, 0u);
+      vv[u] = kk[u];
       if (j < n) {
         const bf16* rp = base + (size_t)j * rowstride + h * D + schunk * 8;
-        kk = *reinterpret_cast<const uint4*>(rp + hidden);
-        vv = *reinterpret_cast<const uint4*>(rp + 2 * hidden);
+        kk[u] = *reinterpret_cast<const uint4*>(rp + hidden);
+        vv[u] = *reinterpret_cast<const uint4*>(rp + 2 * hidden);
       }
-      s_k[schunk][skey] = kk;
-      *reinterpret_cast<uint4*>(s_v + skey * VROW + schunk * 16) = vv;
+    }
+  };
+  request(0);
+  for (int j0 = 0; j0 < n; j0 += TKV) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      s_k[schunk][u * 64 + skey] = kk[u];
+      *reinterpret_cast<uint4*>(s_v + (u * 64 + skey) * VROW + schunk * 16) = vv[u];
     }
     __syncthreads();
-    f32x4 s[4];
+    if (j0 + TKV < n) request(j0 + TKV);
+    f32x4 s[NKT];
     float mx = -1e30f;
+    const bool full = j0 + TKV <= n;                     // no key of this tile is past the end
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
       const uint4 kf = s_k[kg][kt * 16 + li];
       s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       mma16<bf16>(s[kt], kf, qf);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool ok = (j0 + kt * 16 + kg * 4 + r) < n;
-        s[kt][r] = ok ? s[kt][r] : -1e30f;
+        if (!full && (j0 + kt * 16 + kg * 4 + r) >= n) s[kt][r] = -1e30f;
         mx = fmaxf(mx, s[kt][r]);
       }
     }
@@ -185,21 +200,21 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restr
     l *= alpha;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-    unsigned pk[4][2];
+    unsigned pk[NKT][2];
+    const float mn2 = mn * 1.4426950408889634f;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < NKT; ++kt) {
       float pv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool ok = (j0 + kt * 16 + kg * 4 + r) < n;
-        pv[r] = ok ? __expf(s[kt][r] - mn) : 0.f;
+        pv[r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], 1.4426950408889634f, -mn2));   // masked keys: exp2(-huge) = 0
         l += pv[r];
       }
       pk[kt][0] = pack_bf16x2(pv[0], pv[1]);
       pk[kt][1] = pack_bf16x2(pv[2], pv[3]);
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < NKT / 2; ++ks) {
       const uint4 pf = make_uint4(pk[2 * ks][0], pk[2 * ks][1], pk[2 * ks + 1][0], pk[2 * ks + 1][1]);
       const char* vrow = s_v + (ks * 32 + kg * 4 + tq) * VROW + tp * 8;
 #pragma unroll
