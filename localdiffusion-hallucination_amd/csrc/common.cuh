@@ -63,10 +63,12 @@ template <> __device__ __forceinline__ void unpack16<bf16>(const uint4& r, float
   v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
 }
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved)
-  bf16 a = (bf16)lo, b = (bf16)hi;
-  unsigned short ua = __builtin_bit_cast(unsigned short, a), ub = __builtin_bit_cast(unsigned short, b);
-  return (unsigned)ua | ((unsigned)ub << 16);
+  // ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved) for the pair: converting the two values
+  // separately costs a cvt each plus shift/or to merge them (4 VALU instructions per pair in every epilogue)
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* v);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* v) {

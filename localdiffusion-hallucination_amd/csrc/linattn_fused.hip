@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
 // in-wave DPP reduction.  Emits the same partials as kvctx_kernel.
 constexpr int SROW = 32;                  // pixels per wave-private P/V strip (= one MFMA K-step)
 
-template <int NCH>
+// SINGLE (caller-supplied shift): the max sweep, its registers and its code are compiled out.
+template <int NCH, bool SINGLE>
 __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
   constexpr int PLANE = KTN * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -254,8 +255,8 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
   // softmax over n is shift-invariant: with a caller-supplied bound m_d >= max_n k_d (the Cauchy-Schwarz bound
   // ||W_k[d] g sqrt(C)||_2 of the RMS-normalised input, computed once at weight-packing time) the max sweep
   // (pass 0) is skipped and every chunk's partial is already on the same scale.
-  const int first_pass = a.kshift ? 1 : 0;
-  if (a.kshift) {
+  constexpr int first_pass = SINGLE ? 1 : 0;
+  if (SINGLE) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -294,10 +295,10 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
       {
         const int nxt = p0 + KTN;
         if (nxt < hi) issue(nxt);
-        else if (pass == 0) issue(lo);
+        else if (!SINGLE && pass == 0) issue(lo);
       }
       const int ngrp = min(KTN, hi - p0 + 15) / 16;      // 16-pixel groups that contain valid pixels
-      if (pass == 0) {
+      if (!SINGLE && pass == 0) {
         for (int g = 0; g < ngrp; ++g) {
           const int qq = g * 16 + li;
           f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
         }
       }
     }
-    if (pass == 0) {
+    if (!SINGLE && pass == 0) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -563,12 +564,19 @@ extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const flo
     static bool ok2[5] = {false, false, false, false, false};
     dim3 grid2(nchunks, B);
     if (nch == 1) {
-      hipLaunchKernelGGL(kvctx_wph_kernel<1>, grid2, dim3(256), lds2, st, a);
+      if (kshift) hipLaunchKernelGGL((kvctx_wph_kernel<1, true>), grid2, dim3(256), lds2, st, a);
+      else hipLaunchKernelGGL((kvctx_wph_kernel<1, false>), grid2, dim3(256), lds2, st, a);
     } else if (nch == 2) {
-      hipLaunchKernelGGL(kvctx_wph_kernel<2>, grid2, dim3(256), lds2, st, a);
+      if (kshift) hipLaunchKernelGGL((kvctx_wph_kernel<2, true>), grid2, dim3(256), lds2, st, a);
+      else hipLaunchKernelGGL((kvctx_wph_kernel<2, false>), grid2, dim3(256), lds2, st, a);
     } else {
-      if (!ok2[4]) { LD_HIP(ld_allow_lds(kvctx_wph_kernel<4>, lds2)); ok2[4] = true; }
-      hipLaunchKernelGGL(kvctx_wph_kernel<4>, grid2, dim3(256), lds2, st, a);
+      if (!ok2[4]) {
+        LD_HIP(ld_allow_lds((kvctx_wph_kernel<4, true>), lds2));
+        LD_HIP(ld_allow_lds((kvctx_wph_kernel<4, false>), lds2));
+        ok2[4] = true;
+      }
+      if (kshift) hipLaunchKernelGGL((kvctx_wph_kernel<4, true>), grid2, dim3(256), lds2, st, a);
+      else hipLaunchKernelGGL((kvctx_wph_kernel<4, false>), grid2, dim3(256), lds2, st, a);
     }
     LD_LAUNCH_CHECK("linattn_kvctx(wave-per-head)");
     return LD_OK;
