@@ -319,36 +319,43 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
         }
       } else {
         for (int g2 = 0; g2 < (ngrp + 1) / 2; ++g2) {     // 32 pixels = one context K-step
+          // groups that lie entirely inside the chunk (all of them at the model's sizes) skip the per-element
+          // validity selects (24 v_cndmask of ~200 VALU instructions per group)
+          auto softmax_part = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const int qq = (g2 * 2 + half) * 16 + li;
-            const bool valid = (p0 + qq) < hi;
-            f32x4 acc[4];
+            for (int half = 0; half < 2; ++half) {
+              const int qq = (g2 * 2 + half) * 16 + li;
+              const bool valid = FULL || (p0 + qq) < hi;
+              f32x4 acc[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+              for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-              const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
+              for (int c = 0; c < NCH; ++c) {
+                const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
 #pragma unroll
-              for (int m = 0; m < 4; ++m) mma16<bf16>(acc[m], A[m][c], Bf);
-            }
-            const float rinv = s_rinv[qq], rinv2 = rinv * LOG2E;
-            const int row = half * 16 + li;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              float pv[4], vv[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                pv[r] = valid ? __builtin_amdgcn_exp2f(fmaf(acc[m][r], rinv2, -m2[m][r])) : 0.f;
-                vv[r] = valid ? acc[2 + m][r] * rinv : 0.f;
-                zs[m][r] += pv[r];
+                for (int m = 0; m < 4; ++m) mma16<bf16>(acc[m], A[m][c], Bf);
               }
-              *reinterpret_cast<uint2*>(my_p + row * PROW + (16 * m + 4 * kq) * 2) =
-                  make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
-              *reinterpret_cast<uint2*>(my_v + row * PROW + (16 * m + 4 * kq) * 2) =
-                  make_uint2(pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3]));
+              const float rinv = s_rinv[qq], rinv2 = rinv * LOG2E;
+              const int row = half * 16 + li;
+#pragma unroll
+              for (int m = 0; m < 2; ++m) {
+                float pv[4], vv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  pv[r] = valid ? __builtin_amdgcn_exp2f(fmaf(acc[m][r], rinv2, -m2[m][r])) : 0.f;
+                  vv[r] = valid ? acc[2 + m][r] * rinv : 0.f;
+                  zs[m][r] += pv[r];
+                }
+                *reinterpret_cast<uint2*>(my_p + row * PROW + (16 * m + 4 * kq) * 2) =
+                    make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+                *reinterpret_cast<uint2*>(my_v + row * PROW + (16 * m + 4 * kq) * 2) =
+                    make_uint2(pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3]));
+              }
             }
-          }
+          };
+          if (p0 + (g2 * 2 + 2) * 16 <= hi) softmax_part(std::true_type{});
+          else softmax_part(std::false_type{});
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: own writes visible to own reads
           const int row = kq * 4 + tq;
           uint4 Af[2], Bf2[2];
