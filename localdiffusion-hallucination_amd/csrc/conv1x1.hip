@@ -63,6 +63,23 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 #pragma unroll
   for (int i = 0; i < NW; ++i) rs[i] = 0.f;
 
+  // The epilogue's second operand (residual / GroupNorm-tail input) does not depend on the GEMM: request it now,
+  // so its global round trip overlaps the K loop instead of following it.
+  constexpr bool HAS_OP2 = EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES || EPI == LD_EPI_GN_TAIL;
+  float op2[HAS_OP2 ? MT : 1][HAS_OP2 ? NW : 1][4];
+  if constexpr (HAS_OP2) {
+    const T* src2 = reinterpret_cast<const T*>(EPI == LD_EPI_GN_TAIL ? a.tail.data : a.res);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int p = p0 + (wv * NW + j) * 16 + px;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (p < HW) load4<T>(src2 + ((size_t)b * HW + p) * a.Cout + (m0 + m) * 16 + kq * 4, op2[m][j]);
+        else op2[m][j][0] = op2[m][j][1] = op2[m][j][2] = op2[m][j][3] = 0.f;
+      }
+    }
+  }
+
   // K-chunk bookkeeping: plain = chunks of src0 then src1; unshuffle = 4 sub-pixels x chunks of src0
   const int nc0 = a.s[0].C / CK;
   const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
@@ -138,7 +155,6 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 
   // ---- epilogue: lane holds channels (m0+m)*16 + 4kq + r of pixel p0 + (wv*NW+j)*16 + px
   T* out = reinterpret_cast<T*>(a.out);
-  const T* res = reinterpret_cast<const T*>(a.res);
   const bool q_part = (m0 * 16) < a.hidden;
   const bool k_part = a.kmax != nullptr && (m0 * 16) >= a.hidden && (m0 * 16) < 2 * a.hidden;
   float cmax[MT][4];
@@ -213,14 +229,11 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
       for (int m = 0; m < MT; ++m) {
         const int co = (m0 + m) * 16 + kq * 4;
         const size_t o = ((size_t)b * HW + p) * a.Cout + co;
-        if (EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES) {
-          float rv[4];
-          load4<T>(res + o, rv);
+        if constexpr (EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
-        } else if (EPI == LD_EPI_GN_TAIL) {
-          float rv[4];
-          load4<T>(reinterpret_cast<const T*>(a.tail.data) + o, rv);
+          for (int r = 0; r < 4; ++r) v[m][r] += op2[m][j][r];
+        } else if constexpr (EPI == LD_EPI_GN_TAIL) {
+          float rv[4] = {op2[m][j][0], op2[m][j][1], op2[m][j][2], op2[m][j][3]};
           affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
