@@ -41,7 +41,7 @@ struct Conv3Dev {
 };
 
 template <typename T, int MT, int NW, bool DEEP, int DBG>
-__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Dev a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3 : 1, MT == 2 ? 3 : 2))) void conv3x3_kernel(Conv3Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int TR = 4 * NW, TC = 16, HR = TR + 2, HC = TC + 2;
   constexpr int NPIX = HR * HC, NPIXP = (NPIX + 15) / 16 * 16, PLANE = NPIXP * 16;
