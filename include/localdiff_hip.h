@@ -250,6 +250,14 @@ int ld_film(const float* temb, int n, int time_dim, const float* w, const float*
 int ld_final_conv(const void* x, const float* w /*[Cout,Cin]*/, const float* b, float* out_nchw,
                   int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 
+/* ld_final_conv + ld_ddpm_step (+ ld_randn for the step's noise, stream index `noise_stream`) of the same pixels
+ * in ONE launch: model_out = final_conv(x) is still written (fp32 NCHW), x_t is updated in place to x_{t-1}
+ * (ddpm.py:451, 775-776, 659-666, 853-858).  Bitwise the same result as the three separate calls. */
+int ld_final_step(const void* x, const float* w, const float* b, float* model_out, float* x_t, float* x0_out,
+                  const float* sched, const int32_t* t_ptr, float lo, float hi, int objective, uint64_t seed,
+                  int64_t noise_stream, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
+
 /* ---- reverse-process pointwise kernels (NCHW fp32) ---------------------------------------- */
 #define LD_OBJ_X0 0
 #define LD_OBJ_NOISE 1

@@ -138,22 +138,87 @@ __global__ void recompose_kernel(const float* patches, const float* masks, float
 }
 
 // ---------------------------------------------------------------- final 1x1 conv -> NCHW fp32
+// One thread per pixel.  The pixel's Cin channels are fetched with 16-byte loads (a 64-byte bf16 row in 4
+// requests instead of 8) before any arithmetic; the weights sit in LDS (same address in every lane: broadcast).
+// The accumulation order (groups of 4 channels, fmaf chain inside a group) is fixed, so the stand-alone kernel and
+// the fused final step below give bitwise the same model output.
+template <typename T>
+__device__ __forceinline__ void final_conv_pixel(const T* xp, const float* s_w, int Cin, int Cout, float* acc) {
+  constexpr int E = 16 / sizeof(T);
+  acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += 4 * E) {             // 4 x 16 B in flight per pass
+    uint4 raw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      raw[q] = (c0 + q * E < Cin) ? *reinterpret_cast<const uint4*>(xp + c0 + q * E) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (c0 + q * E >= Cin) break;
+      float v[E];
+      if constexpr (sizeof(T) == 2) unpack16<bf16>(raw[q], v);
+      else unpack16<float>(raw[q], v);
+#pragma unroll
+      for (int g = 0; g < E; g += 4) {
+        const int c = c0 + q * E + g;
+        for (int o = 0; o < Cout; ++o) {
+          const float* wr = s_w + o * Cin + c;
+          acc[o] = fmaf(v[g], wr[0], fmaf(v[g + 1], wr[1], fmaf(v[g + 2], wr[2], fmaf(v[g + 3], wr[3], acc[o]))));
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void final_conv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                   float* __restrict__ out, int HW, int Cin, int Cout, long npix) {
+  extern __shared__ float s_fw[];
+  for (int i = threadIdx.x; i < Cin * Cout; i += BS) s_fw[i] = w[i];
+  __syncthreads();
   GRID_STRIDE(i, npix) {                    // i over [B, HW]
     const long b = i / HW, p = i - b * HW;
-    const T* xp = x + (size_t)i * Cin;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < Cin; c += 4) {
-      float v[4];
-      load4<T>(xp + c, v);
-      for (int o = 0; o < Cout; ++o) {
-        const float* wr = w + (size_t)o * Cin + c;
-        acc[o] = fmaf(v[0], wr[0], fmaf(v[1], wr[1], fmaf(v[2], wr[2], fmaf(v[3], wr[3], acc[o]))));
-      }
-    }
+    float acc[4];
+    final_conv_pixel<T>(x + (size_t)i * Cin, s_fw, Cin, Cout, acc);
     for (int o = 0; o < Cout; ++o) out[((size_t)b * Cout + o) * HW + p] = acc[o] + bias[o];
+  }
+}
+
+// final 1x1 conv + the whole ancestral update of the same pixel (ld_ddpm_step's arithmetic, ddpm.py:817-858) with
+// the noise of ld_randn generated in place (same counter -> same integers): one launch and one pass over the
+// feature map instead of three launches.
+template <typename T>
+__global__ void final_step_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float* __restrict__ model_out, float* __restrict__ x_t, float* __restrict__ x0o,
+                                  const float* __restrict__ sched, const int* __restrict__ t_ptr, float lo, float hi,
+                                  int obj, unsigned long long seed, long stream, int HW, int Cin, int Cout, long npix) {
+  extern __shared__ float s_fw[];
+  for (int i = threadIdx.x; i < Cin * Cout; i += BS) s_fw[i] = w[i];
+  const int t = t_ptr ? *t_ptr : 0;
+  const float* row = sched + (size_t)t * LD_SCHED_COLS;
+  const float c1 = row[LD_SCHED_COEF1], c2 = row[LD_SCHED_COEF2], sg = row[LD_SCHED_SIGMA];
+  const unsigned long long base = mix64(seed ^ ((unsigned long long)stream * 0xD1B54A32D192ED03ull));
+  __syncthreads();
+  GRID_STRIDE(i, npix) {
+    const long b = i / HW, p = i - b * HW;
+    float acc[4];
+    final_conv_pixel<T>(x + (size_t)i * Cin, s_fw, Cin, Cout, acc);
+    for (int o = 0; o < Cout; ++o) {
+      const size_t idx = ((size_t)b * Cout + o) * HW + p;
+      const float mo = acc[o] + bias[o];
+      model_out[idx] = mo;
+      const float xi = x_t[idx];
+      const float x0 = clampf(to_x0(xi, mo, row, obj), lo, hi);
+      const float mean = c1 * x0 + c2 * xi;
+      float r = mean;
+      if (t > 0) {
+        const unsigned long long h = mix64(base + (unsigned long long)(idx + 1) * 0x9E3779B97F4A7C15ull);
+        const float u1 = ((float)(unsigned)(h >> 40) + 1.0f) * 5.9604644775390625e-8f;          // 2^-24
+        const float u2 = (float)(unsigned)((h >> 16) & 0xFFFFFFu) * 5.9604644775390625e-8f;
+        r = mean + sg * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
+      }
+      x_t[idx] = r;
+      if (x0o) x0o[idx] = x0;
+    }
   }
 }
 }  // namespace
@@ -255,14 +320,33 @@ extern "C" int ld_recompose(const float* patches, const float* masks, float* out
 extern "C" int ld_final_conv(const void* x, const float* w, const float* b, float* out_nchw, int B, int H, int W,
                              int Cin, int Cout, int dtype, void* stream) {
   LD_REQUIRE(x && w && b && out_nchw, "ld_final_conv: null pointer");
-  LD_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 4 == 0, "ld_final_conv: Cout %d (1..4), Cin %d", Cout, Cin);
+  LD_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 8 == 0, "ld_final_conv: Cout %d (1..4), Cin %d (multiple of 8)", Cout, Cin);
   const long npix = (long)B * H * W;
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(final_conv_kernel<float>, dim3(nblocks(npix)), dim3(BS), 0, ST(stream), (const float*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
+    hipLaunchKernelGGL(final_conv_kernel<float>, dim3(nblocks(npix)), dim3(BS), Cin * Cout * sizeof(float), ST(stream), (const float*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(final_conv_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), 0, ST(stream), (const bf16*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
+    hipLaunchKernelGGL(final_conv_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), Cin * Cout * sizeof(float), ST(stream), (const bf16*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
   else
     return ld_fail(LD_EINVAL, "ld_final_conv: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("final_conv");
+  return LD_OK;
+}
+
+extern "C" int ld_final_step(const void* x, const float* w, const float* b, float* model_out, float* x_t, float* x0_out,
+                             const float* sched, const int32_t* t_ptr, float lo, float hi, int objective, uint64_t seed,
+                             int64_t noise_stream, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+  LD_REQUIRE(x && w && b && model_out && x_t && sched, "ld_final_step: null pointer");
+  LD_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 8 == 0, "ld_final_step: Cout %d (1..4), Cin %d (multiple of 8)", Cout, Cin);
+  LD_REQUIRE(objective >= 0 && objective <= 2, "ld_final_step: objective %d", objective);
+  LD_REQUIRE(dtype == LD_F32 || dtype == LD_BF16, "ld_final_step: bad dtype %d", dtype);
+  const long npix = (long)B * H * W;
+  const size_t lds = (size_t)Cin * Cout * sizeof(float);
+  if (dtype == LD_F32)
+    hipLaunchKernelGGL(final_step_kernel<float>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const float*)x, w, b, model_out,
+                       x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_stream, H * W, Cin, Cout, npix);
+  else
+    hipLaunchKernelGGL(final_step_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const bf16*)x, w, b, model_out,
+                       x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_stream, H * W, Cin, Cout, npix);
+  LD_LAUNCH_CHECK("final_step");
   return LD_OK;
 }

@@ -18,6 +18,7 @@ Noise: ``noise_source='device'`` draws z_t with the counter-based generator on t
 (``ld_randn``); ``'host'`` uploads the same stream from ``rng.py`` (bit-identical to the golden
 fixtures); a callable ``f(shape, k) -> tensor`` may be supplied instead.
 """
+import os
 from functools import partial
 
 import numpy as np
@@ -64,6 +65,7 @@ class GaussianDiffusion(nn.Module):
         self.instance = 0
         # build-specific knobs (additive; defaults reproduce the reference's behaviour)
         self.noise_source = "device"
+        self.fuse_final_step = os.environ.get("LD_NO_FUSED_FINAL") is None
         self.noise_seed = 10                      # torch.manual_seed(10), ddpm.py:934
         self.use_graph = False
         self._sched = None
@@ -167,6 +169,27 @@ class GaussianDiffusion(nn.Module):
                 and timers is None and n_steps > 1):
             return self._run_joint_steps_graph(jp, t_start, n_steps, lo, hi, z, draw)
         t = t_start
+        # device noise: final_conv, the posterior update and the noise draw of a step are ONE launch (ld_final_step,
+        # bitwise the same result as the three calls below)
+        fused = (self.noise_source == "device" and timers is None and self.fuse_final_step
+                 and jp.x_in.shape[1] == jp.model_out.shape[1])
+        if fused:
+            xa, wf, bf = jp.final
+            B_, C_, H_, W_ = jp.model_out.shape
+            for _ in range(n_steps):
+                jp.set_step(t)
+                jp.run_main(st, skip_final=True)
+                k = draw if t > 0 else 0
+                cabi.check(lib.ld_final_step(xa.data_ptr(), wf.data_ptr(), bf.data_ptr(), jp.model_out.data_ptr(),
+                                             jp.x_in.data_ptr(), cabi.ptr(x0_buf), sched.data_ptr(), jp.t_dev.data_ptr(),
+                                             lo, hi, obj, self.noise_seed, k, B_, H_, W_, wf.shape[1], C_, jp.dt, st),
+                           "final_step")
+                if t > 0:
+                    draw += 1
+                if after is not None:
+                    after(t)
+                t -= 1
+            return draw
         for _ in range(n_steps):
             jp.set_step(t)
             if timers is None:

@@ -630,6 +630,7 @@ class _Plan:
         wf = f["final_conv.weight"].reshape(cfg.out_dim, cfg.dim).contiguous()
         bf = f["final_conv.bias"]
         self.keep += [wf, bf, x, r]
+        self.final = (x, wf, bf)              # operands of the last op (diffusion.py fuses it with the sampler update)
         self._raw(ops, lambda st, x=x: cabi.check(lib.ld_final_conv(
             x.data_ptr(), wf.data_ptr(), bf.data_ptr(), self.model_out.data_ptr(), B, H, W, cfg.dim, cfg.out_dim,
             self.dt, st), "final_conv"), "final_conv",
@@ -646,11 +647,13 @@ class _Plan:
         for op in self.ops_cond:
             op(st)
 
-    def run_main(self, st):
+    def run_main(self, st, skip_final=False):
+        """One denoiser evaluation.  ``skip_final``: stop before final_conv (the caller runs ld_final_step)."""
         s = self.stats[self.cond_slots:]
         cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
         cabi.check(self.lib.ld_memset_zero(self.kmax_arena.data_ptr(), self.kmax_arena.numel() * 4, st), "memset")
-        for op in self.ops_main:
+        ops = self.ops_main[:-1] if skip_final else self.ops_main
+        for op in ops:
             op(st)
 
     def run_main_timed(self, st, acc):

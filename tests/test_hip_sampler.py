@@ -110,6 +110,19 @@ def test_device_noise_runs_and_is_deterministic():
     assert float(np.abs(a - c).max()) < 1e-3      # device Box-Muller is fp32, host fp64
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_final_step_is_bitwise_the_three_launches(dtype):
+    """ld_final_step (final_conv + posterior update + in-place noise) vs ld_final_conv, ld_randn, ld_ddpm_step."""
+    cond = torch.from_numpy(rng.uniform((2, 1, 28, 28), 8, 1, 0.0, 2.0))
+    gd = make(MNIST, dict(data="mnist"), 28, 9, dtype=dtype)
+    gd.noise_source = "device"
+    gd.fuse_final_step = True
+    fused = run(gd, cond, None, 2)
+    gd.fuse_final_step = False
+    plain = run(gd, cond, None, 2)
+    assert np.isfinite(fused).all() and np.array_equal(fused, plain)
+
+
 def test_graph_replay_matches_eager():
     """HIP-graph replay of the reverse step gives the same image as the eager launch sequence."""
     cond = torch.from_numpy(rng.uniform((2, 1, 28, 28), 8, 1, 0.0, 2.0))
