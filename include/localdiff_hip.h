@@ -108,6 +108,9 @@ typedef struct ld_conv3x3_args {
   int32_t B, H, W, Cout;   /* Cout multiple of 32 */
   const int32_t* t_ptr;
   int32_t dtype;
+  const void* addend;      /* optional NHWC [B,H,W,Cout] tensor (storage dtype) added to conv + bias BEFORE the     */
+                           /* statistics: the step-invariant half of a convolution over a concatenation whose     */
+                           /* second operand does not change between reverse steps (conv_fusion, ddpm.py:434-436) */
 } ld_conv3x3_args;
 int ld_conv3x3(const ld_conv3x3_args* args, void* stream);
 
@@ -119,7 +122,8 @@ int ld_conv3x3(const ld_conv3x3_args* args, void* stream);
                             /* into q                                                           */
 #define LD_EPI_RMS_RES 3    /* to_out conv + RMSNorm + residual (ddpm.py:229-232,251,425,444)    */
 #define LD_EPI_RES 4        /* to_out conv + residual (ddpm.py:269,282,425,431)                  */
-#define LD_EPI_GN_TAIL 5    /* ResnetBlock tail fused into its res_conv (ddpm.py:198,210-212):    */
+#define LD_EPI_GN_TAIL 5    /* ResnetBlock tail fused into its res_conv (ddpm.py:198,210-212);    */
+                            /* `residual`, if given, is added too (step-invariant half of res_conv) */
                             /* out = res_conv(x) + act(GroupNorm(gn_tail))  -- gn_tail is block2's */
                             /* raw conv output with its statistics                               */
 typedef struct ld_conv1x1_args {

@@ -29,7 +29,7 @@ class Src(C.Structure):
 class Conv3x3Args(C.Structure):
     _fields_ = [("src", Src * 2), ("nsrc", i32), ("weight", vp), ("bias", vp), ("out", vp),
                 ("out_stats", vp), ("out_groups", i32), ("B", i32), ("H", i32), ("W", i32),
-                ("Cout", i32), ("t_ptr", vp), ("dtype", i32)]
+                ("Cout", i32), ("t_ptr", vp), ("dtype", i32), ("addend", vp)]
 
 
 class Conv1x1Args(C.Structure):

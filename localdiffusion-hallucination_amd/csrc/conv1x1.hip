@@ -237,6 +237,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
           affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
+          if (a.res) {                                   // step-invariant half of res_conv (conv_fusion)
+            float r2[4];
+            load4<T>(reinterpret_cast<const T*>(a.res) + o, r2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[m][r] += r2[r];
+          }
         }
         store4<T>(out + o, v[m]);
       }

@@ -36,6 +36,7 @@ struct Conv3Dev {
   int ogroups;
   int B, H, W, Cout;
   const int* t_ptr;
+  const void* addend;
   int tiles_x;
   int dbg;     // ablation switches (LD_CONV_DEBUG env, 0 in production): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
@@ -260,6 +261,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
       const int gy = ty0 + wv * NW + j;
       const bool valid = gy < H && gx < W;
       float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
+      if (valid && a.addend) {
+        float ad[4];
+        load4<T>(reinterpret_cast<const T*>(a.addend) + (((size_t)b * H + gy) * W + gx) * a.Cout + co, ad);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += ad[r];
+      }
       if (valid) {
         if (!(DBG & 8)) store4<T>(out + (((size_t)b * H + gy) * W + gx) * a.Cout + co, v);
 #pragma unroll
@@ -391,6 +398,7 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   a.w = p->weight; a.bias = p->bias; a.out = p->out; a.ostats = p->out_stats;
   a.ogroups = p->out_groups > 0 ? p->out_groups : 1;
   a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout; a.t_ptr = p->t_ptr; a.tiles_x = 0;
+  a.addend = p->addend;
   static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
   a.dbg = dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

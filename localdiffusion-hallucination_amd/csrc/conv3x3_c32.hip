@@ -405,7 +405,7 @@ int launch_c32(const C32Dev& a0, hipStream_t st) {
 // Returns 1 if this launch is handled here, 0 if the generic kernel must take it, <0 on error.
 int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   static const int disabled = getenv("LD_CONV_NO_C32") ? atoi(getenv("LD_CONV_NO_C32")) : 0;
-  if (disabled || p->Cout != 32 || p->H < 32 || p->W < 32 || p->H % 16 != 0 || p->W % 16 != 0) return 0;
+  if (disabled || p->addend || p->Cout != 32 || p->H < 32 || p->W < 32 || p->H % 16 != 0 || p->W % 16 != 0) return 0;
   const int ck = p->dtype == LD_F32 ? 16 : 32;
   int ctot = 0;
   for (int s = 0; s < p->nsrc; ++s) ctot += p->src[s].C;

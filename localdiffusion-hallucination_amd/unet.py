@@ -200,6 +200,20 @@ class Unet(nn.Module):
                 qb = wqn.reshape(heads, 32).amax(dim=1)          # softmax_d(q) shift per head (same bound, max over d)
                 P["qshift"][base] = qb.contiguous() if float(qb.max()) <= 40.0 else None
                 P["keep"].append(scale)
+        if self.compute_dtype == "bf16" and "conv_fusion.res_conv.weight" in sd:
+            # conv_fusion sees cat(trunk, conditioning features) (ddpm.py:434-436) and the second half does not change
+            # between reverse steps: its weights are packed per half so that the conditioning half of block1.proj and
+            # res_conv can be evaluated once per sample (bf16 storage only: fp32 keeps the reference's summation order)
+            for nm, k in (("conv_fusion.block1.proj.weight", 3), ("conv_fusion.res_conv.weight", 1)):
+                wfull = sd[nm]
+                half = wfull.shape[1] // 2
+                for tag, part in (("#x", wfull[:, :half]), ("#c", wfull[:, half:])):
+                    part = part.contiguous()
+                    out = torch.empty(part.numel(), dtype=tdt, device=dev)
+                    cabi.check(lib.ld_pack_conv_weight(part.data_ptr(), None, out.data_ptr(), part.shape[0], part.shape[1],
+                                                       k, 0, dt, st), "pack " + nm + tag)
+                    P["w"][nm + tag] = out
+                    P.setdefault("keep", []).append(part)
         if self.compute_dtype == "bf16" and self.cfg.init_dim == 32:
             wi = sd["init_conv.weight"].contiguous()
             stem = torch.empty(int(lib.ld_stem_packed_bytes()), dtype=torch.uint8, device=dev)
@@ -282,6 +296,16 @@ class _Plan:
         self._slot_cursor = 0
         self.cond_feat = self._build_cond()
         self.named["cond_model"] = self.cond_feat
+        self.fusion_const = None
+        if ("conv_fusion.block1.proj.weight#c" in self.P["w"] and not cfg.cond_early_exit
+                and not os.environ.get("LD_NO_FUSION_FOLD")):
+            c = self.cond_feat.shape[-1]
+            hh, ww = self.cond_feat.shape[1], self.cond_feat.shape[2]
+            p1 = self.conv3(self.ops_cond, [self.src(self.cond_feat, c)], "conv_fusion.block1.proj", c, hh, ww,
+                            weight=self.P["w"]["conv_fusion.block1.proj.weight#c"])
+            p2 = self.conv1(self.ops_cond, [self.src(self.cond_feat, c)], self.P["w"]["conv_fusion.res_conv.weight#c"],
+                            c, hh, ww, bias=self.f32["conv_fusion.res_conv.bias"], what="res_conv(cond) conv_fusion")
+            self.fusion_const = (p1, p2, torch.zeros(c, dtype=torch.float32, device=self.dev))
         self._slot_cursor = self.cond_slots
         self._build_main()
         if table_T:
@@ -329,13 +353,16 @@ class _Plan:
         if ops is self.ops_main:
             self.meta[len(ops) - 1] = dict(what=what, family=what, bytes=nbytes, flops=flops)
 
-    def conv3(self, ops, srcs, wname, cout, h, w, stats=None, groups=8):
+    def conv3(self, ops, srcs, wname, cout, h, w, stats=None, groups=8, weight=None, bias=None, addend=None):
         a = cabi.Conv3x3Args()
         for i, s in enumerate(srcs):
             a.src[i] = s
         a.nsrc = len(srcs)
-        a.weight = self.P["w"][wname + ".weight"].data_ptr()
-        a.bias = self.f32[wname + ".bias"].data_ptr()
+        weight = self.P["w"][wname + ".weight"] if weight is None else weight
+        bias = self.f32[wname + ".bias"] if bias is None else bias
+        a.weight, a.bias = weight.data_ptr(), bias.data_ptr()
+        a.addend = cabi.ptr(addend)
+        self.keep += [weight, bias, addend]
         out = self.buf(h, w, cout)
         a.out = out.data_ptr()
         if stats is not None:
@@ -426,7 +453,7 @@ class _Plan:
         film = self.films.get(p)
         n1 = self.src(raw1, cout, gn=(s1, f[p + ".block1.norm.weight"], f[p + ".block1.norm.bias"], G),
                       act=cabi.ACT_SILU, film=film)
-        if h * w <= 32 * 32 and cout >= 128:
+        if h * w <= 32 * 32 and cout >= 128 and not os.environ.get("LD_NO_SEPARATE_ACT"):
             # small, wide maps: the normalise+FiLM+SiLU prologue would be repeated by every cout-tile workgroup
             # (4x at 256 channels) on the critical path of one-workgroup-per-CU launches; a separate pass over
             # the (L2-resident) tensor measured cheaper (256->256@32^2: 45 -> 25 us + 9 us).  Everything else keeps
@@ -443,6 +470,26 @@ class _Plan:
         else:
             assert res_tensor is not None and cin_total == cout
             out = self.gn_apply(ops, n2, self.src(res_tensor, cout), h, w, cout)
+        self.named[p] = out
+        return out
+
+    def fusion_block_folded(self, ops, x, c, h, w):
+        """conv_fusion (a ResnetBlock over cat(trunk, conditioning features), ddpm.py:434-436) with the conditioning
+        halves of block1.proj and res_conv precomputed by run_cond: per step only the trunk halves are convolved,
+        the constants enter as a pre-statistics addend / an extra residual."""
+        f, G, p = self.f32, self.cfg.resnet_block_groups, "conv_fusion"
+        p1, p2, zero = self.fusion_const
+        s1, s2 = self.slot(), self.slot()
+        raw1 = self.conv3(ops, [self.src(x, c)], p + ".block1.proj", c, h, w, stats=s1, groups=G,
+                          weight=self.P["w"][p + ".block1.proj.weight#x"], bias=zero, addend=p1)
+        n1 = self.src(raw1, c, gn=(s1, f[p + ".block1.norm.weight"], f[p + ".block1.norm.bias"], G),
+                      act=cabi.ACT_SILU, film=self.films.get(p))
+        if h * w <= 32 * 32 and c >= 128 and not os.environ.get("LD_NO_SEPARATE_ACT"):
+            n1 = self.src(self.gn_apply(ops, n1, None, h, w, c), c)
+        raw2 = self.conv3(ops, [n1], p + ".block2.proj", c, h, w, stats=s2, groups=G)
+        n2 = self.src(raw2, c, gn=(s2, f[p + ".block2.norm.weight"], f[p + ".block2.norm.bias"], G), act=cabi.ACT_SILU)
+        out = self.conv1(ops, [self.src(x, c)], self.P["w"][p + ".res_conv.weight#x"], c, h, w, bias=None,
+                         epi=cabi.EPI_GN_TAIL, gn_tail=n2, residual=p2, what="res_conv+tail " + p)
         self.named[p] = out
         return out
 
@@ -609,7 +656,10 @@ class _Plan:
         x = self.attention(ops, "mid_attn", x, c, h, w, True)
         x = self.resnet_block(ops, "mid_block2", lambda x=x, c=c: [self.src(x, c)], c, c, h, w, res_tensor=x)
         feat = self.cond_feat
-        x = self.resnet_block(ops, "conv_fusion", lambda x=x, c=c: [self.src(x, c), self.src(feat, c)], 2 * c, c, h, w)
+        if self.fusion_const is not None:
+            x = self.fusion_block_folded(ops, x, c, h, w)
+        else:
+            x = self.resnet_block(ops, "conv_fusion", lambda x=x, c=c: [self.src(x, c), self.src(feat, c)], 2 * c, c, h, w)
         for j, ((cin, cout), full) in enumerate(zip(reversed(io), reversed(cfg.full_attn))):
             p = f"ups.{j}"
             for k in (0, 1):

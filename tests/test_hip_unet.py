@@ -80,6 +80,28 @@ def test_forward_bf16_within_tolerance(tag):
     assert rel < 5e-2
 
 
+def test_conv_fusion_fold_matches_the_concatenated_block(monkeypatch):
+    """bf16: conv_fusion with the conditioning halves of block1.proj / res_conv precomputed once per sample vs the
+    same block evaluated on cat(trunk, conditioning features) every step: same tap and output up to bf16 rounding."""
+    kw, B, H = CASES["mri64"]
+    cfg_x = torch.from_numpy(rng.randn((B, 1, H, H), 1, 100))
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 1, 101, 0.0, 2.0))
+    tv = torch.full((B,), 7, dtype=torch.long)
+    net, _ = build(kw, "bf16")
+    y_fold = net(cfg_x.cuda(), cond.cuda(), tv.cuda()).cpu()
+    plan = net.plan(B, H, H)
+    assert plan.fusion_const is not None
+    tap_fold = plan.named["conv_fusion"].float().cpu()
+    monkeypatch.setenv("LD_NO_FUSION_FOLD", "1")
+    net2, _ = build(kw, "bf16")
+    y_cat = net2(cfg_x.cuda(), cond.cuda(), tv.cuda()).cpu()
+    plan2 = net2.plan(B, H, H)
+    assert plan2.fusion_const is None
+    tap_cat = plan2.named["conv_fusion"].float().cpu()
+    assert float((tap_fold - tap_cat).abs().max()) <= 3e-2 * float(tap_cat.abs().max())
+    assert float((y_fold - y_cat).abs().max()) <= 2e-2 * float(y_cat.abs().max())
+
+
 def test_per_sample_timesteps_and_state_dict_names():
     kw, B, H = CASES["mnist28"]
     net, sd = build(kw, "fp32")
