@@ -372,7 +372,7 @@ class _Plan:
         a.dtype = self.dt
         cin = sum(s.C for s in srcs)
         npx = self.B * h * w
-        mt4 = cout % 64 == 0
+        mt4 = cout % 64 == 0 and ((w + 15) // 16) * ((h + 7) // 8) * (cout // 64) * self.B >= 256
         big = ((w + 15) // 16) * ((h + 15) // 16) * (cout // (64 if mt4 else 32)) * self.B >= 512 and h >= 16 and not mt4
         fam = f"conv3x3<{'f32' if self.dt == cabi.LD_F32 else 'bf16'},{4 if mt4 else 2},{4 if big else 2}>"
         in_el = sum(s.C * (npx // 4 if s.upsample else npx) for s in srcs)
