@@ -14,6 +14,7 @@
 // Tiling: 256 threads = 4 waves; tile = 64*NW consecutive pixels of one image x 16*MT output
 // channels; wave w owns pixel tiles [w*NW,(w+1)*NW) and all MT channel tiles.
 #include "common.cuh"
+#include <stdlib.h>
 
 namespace {
 
@@ -305,7 +306,11 @@ int dispatch(const Conv1Dev& a, hipStream_t st) {
       default: return ld_fail(LD_EINVAL, "ld_conv1x1: RMS_RES epilogue supports Cout 32/64/128 (got %d)", a.Cout);
     }
   }
-  const bool mt4 = (a.Cout % 64) == 0;
+  bool mt4 = (a.Cout % 64) == 0;
+  // small maps: prefer 32-channel tiles while the 64-channel grid (128-pixel tiles) would leave CUs with at most
+  // one workgroup -- the K loop is a chain of synchronous chunk loads and a second resident workgroup hides it
+  static const long small_min = getenv("LD_C1_SMALL_MIN") ? atol(getenv("LD_C1_SMALL_MIN")) : 512;
+  if (mt4 && (long)((HW + 127) / 128) * (a.Cout / 64) * a.B < small_min) mt4 = false;
   const long blocks4 = (long)((HW + 255) / 256) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
   const bool big = blocks4 >= 512;
   if (mt4) return big ? launch<T, 4, 4>(a, st) : launch<T, 4, 2>(a, st);
