@@ -63,6 +63,12 @@ class GaussianDiffusion(nn.Module):
         self.offset_noise_strength = offset_noise_strength
         self.cnt = -1
         self.instance = 0
+        # classifier gate state (ddpm.py:622-625, 883-916).  classifier_flag is never reset by the reference:
+        # once one fused prediction is accepted, later sample() calls on the same object skip the scoring.
+        self.classifier = None
+        self.classifier_flag = 0
+        self.pred_cls = 0.0
+        self.classifier_calls = 0
         # build-specific knobs (additive; defaults reproduce the reference's behaviour)
         self.noise_source = "device"
         self.fuse_final_step = os.environ.get("LD_NO_FUSED_FINAL") is None
@@ -73,9 +79,12 @@ class GaussianDiffusion(nn.Module):
 
     # ------------------------------------------------------------------ small API pieces
     def call_classifier(self):
-        if self.config.get("classifier", False):
-            raise NotImplementedError("the PatchCore x0 classifier gate (ddpm.py:883-916) needs anomalib "
-                                      "weights that the reference does not ship; it is off in config.yaml:34")
+        """ddpm.py:622-625 builds a PatchCore model from anomalib weights the reference does not ship.  Here the
+        gate takes any callable ``x0 (B,C,H,W float32 on the device) -> (score, _, _)`` assigned to ``.classifier``
+        before sampling; with config['classifier'] on and no callable the sampler refuses to run."""
+        if self.config.get("classifier", False) and self.classifier is None:
+            raise RuntimeError("config['classifier'] is on: assign a callable x0 -> (score, _, _) to "
+                               ".classifier before sampling (the reference's PatchCore weights are not shipped)")
 
     @property
     def device(self):
@@ -289,6 +298,10 @@ class GaussianDiffusion(nn.Module):
         draw = 1
         t = start_t
         xs = None
+        gate = bool(self.config.get("classifier", False)) and branch and fuse     # ddpm.py:883
+        if gate:
+            self.call_classifier()
+        x_branchout = None
         # ---------------- BRANCH phase
         if branch:
             assert self.objective == "pred_x0", "branch mode exists only for pred_x0 (ddpm.py:739-749)"
@@ -326,6 +339,9 @@ class GaussianDiffusion(nn.Module):
                 if fuse and t <= int(self.config["start_timestep"]):
                     jp = self.model.plan(B, H, W, table_T=self.num_timesteps_ori)
                     x0f = torch.empty(shape, dtype=torch.float32, device=dev)
+                    if gate:                               # self.x_branchout, ddpm.py:799
+                        m1 = (mask >= 1.0).float()
+                        x_branchout = [x_out_view * m1, x_in_view * (1.0 - m1)]
                     cabi.check(lib.ld_fuse_ddpm(x_out_view.data_ptr(), x_in_view.data_ptr(), mo_out.data_ptr(),
                                                 mo_in.data_ptr(), mask.data_ptr(), jp.x_in.data_ptr(),
                                                 x0f.data_ptr(), lo, hi, B, C, HW, st), "fuse_ddpm")
@@ -359,8 +375,14 @@ class GaussianDiffusion(nn.Module):
                     hist_x0.append(x0_buf.cpu())
                 if return_all_timesteps:
                     hist_x.append(jp.x_in.clone())
-            self.run_joint_steps(jp, t, t + 1, lo, hi, z, draw, x0_buf=x0_buf,
-                                 after=after if (return_all_outputs or return_all_timesteps) else None)
+            if gate and x_branchout is not None:
+                if x0_buf is None:
+                    x0_buf = torch.empty(shape, dtype=torch.float32, device=dev)
+                self._gated_joint_steps(jp, t, lo, hi, z, draw, x0_buf, x_branchout, cond, cond_out, cond_in,
+                                        mask, mask_x, after if (return_all_outputs or return_all_timesteps) else None)
+            else:
+                self.run_joint_steps(jp, t, t + 1, lo, hi, z, draw, x0_buf=x0_buf,
+                                     after=after if (return_all_outputs or return_all_timesteps) else None)
             ret = jp.x_in.clone()
         else:
             ret = xs
@@ -372,6 +394,73 @@ class GaussianDiffusion(nn.Module):
         if return_all_outputs:
             return ret, hist_x0, []
         return ret
+
+    def _gated_joint_steps(self, jp, t, lo, hi, z, draw, x0_buf, x_branchout, cond, cond_out, cond_in, mask,
+                           mask_x, after):
+        """Joint steps t..0 under the classifier gate (fusion(), ddpm.py:883-916).  Until one fused prediction
+        is accepted every joint step's x0 is scored; a rejected one (score <= 0 and t > 0) is discarded and
+        replaced by a fresh two-branch evaluation + fusion at the SAME t, started from the masked branch states
+        the fusion step kept (ddpm.py:799), with mask_x forced on (:906-908).  Noise draws stay in program
+        order: the rejected step's draw, then the redo's."""
+        lib, st = cabi.lib(), self._st()
+        sched = self._sched_table()
+        obj = cabi.OBJ[self.objective]
+        B, C, H, W = jp.x_in.shape
+        HW, n = H * W, jp.x_in.numel()
+        bp = None                                           # branch plan of the redo, built on first rejection
+        while t >= 0:
+            jp.set_step(t)
+            jp.run_main(st)
+            if t > 0:
+                self._noise(z, draw)
+                draw += 1
+            cabi.check(lib.ld_ddpm_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), z.data_ptr(),
+                                        jp.x_in.data_ptr(), x0_buf.data_ptr(), sched.data_ptr(),
+                                        jp.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+            if self.classifier_flag == 0:
+                self.pred_cls = float(self.classifier(x0_buf)[0])
+                self.classifier_calls += 1
+            if self.pred_cls > 0.0 or t == 0:
+                self.classifier_flag = 1
+            else:
+                mask_x = True
+                replaced = self._replaced_out(True)
+                if bp is None:
+                    bp = self.model.plan(B if replaced else 2 * B, H, W, table_T=self.num_timesteps_ori)
+                if replaced:
+                    bp.cond_in.copy_(cond_in)
+                else:
+                    bp.cond_in[:B].copy_(cond_out)
+                    bp.cond_in[B:].copy_(cond_in)
+                bp.run_cond(st)
+                x_in_view = bp.x_in if replaced else bp.x_in[B:]
+                x_out_view = x_branchout[0] if replaced else bp.x_in[:B]
+                if not replaced:
+                    x_out_view.copy_(x_branchout[0])
+                x_in_view.copy_(x_branchout[1])
+                mo_in = bp.model_out if replaced else bp.model_out[B:]
+                mo_out = cond_out if replaced else bp.model_out[:B]
+                bp.set_step(t)
+                bp.run_main(st)
+                if not replaced:
+                    cabi.check(lib.ld_mask_out(mo_out.data_ptr(), mask.data_ptr(), lo, B, C, HW, st), "mask_out")
+                self._noise(z, draw)                        # t > 0 here
+                draw += 1
+                # the masked states are idempotent under the fusion's own masking, so x_branchout stays as is
+                cabi.check(lib.ld_fuse_ddpm(x_out_view.data_ptr(), x_in_view.data_ptr(), mo_out.data_ptr(),
+                                            mo_in.data_ptr(), mask.data_ptr(), jp.x_in.data_ptr(),
+                                            x0_buf.data_ptr(), lo, hi, B, C, HW, st), "fuse_ddpm")
+                if bp is jp:                                # plans are cached per batch size: restore the joint one
+                    jp.cond_in.copy_(cond)
+                    jp.run_cond(st)
+                jp.set_step(t)
+                cabi.check(lib.ld_posterior_step(jp.x_in.data_ptr(), x0_buf.data_ptr(), z.data_ptr(),
+                                                 jp.x_in.data_ptr(), sched.data_ptr(), jp.t_dev.data_ptr(), n, st),
+                           "posterior_step")
+            if after is not None:
+                after(t)
+            t -= 1
+        return draw
 
     # ------------------------------------------------------------------ DDIM loop
     @torch.inference_mode()

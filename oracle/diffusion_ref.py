@@ -92,6 +92,7 @@ class SamplerOptions:
     mask_x: bool = False
     ood_AD: bool = False
     ood_confidence: bool = False
+    classifier: bool = False          # config['classifier']: gate the fused sample with a classifier (ddpm.py:883-916)
     seed: int = 10
 
 
@@ -107,6 +108,12 @@ class RefSampler:
         self.S = opts.sampling_timesteps or opts.timesteps
         self.buf = schedule_buffers(opts.beta_schedule, self.T, opts.objective)
         self.channels, self.image_size = channels, image_size
+        # classifier gate (ddpm.py:622-625 builds a PatchCore model; here any callable x0 -> (score, _, _)).  The
+        # flag lives on the object and is never reset (ddpm.py:522): once a sample was accepted, later calls of
+        # sample() on the same object skip the classifier.
+        self.classifier = None
+        self.classifier_flag = 0
+        self.pred_cls = None
 
     # --- pointwise conversions (ddpm.py:631-653) ---
     def _c(self, name, t):
@@ -178,34 +185,42 @@ class RefSampler:
         return (self.eps_from_x0(x_out, t, m_out), m_out), (self.eps_from_x0(x_in, t, m_in), m_in)
 
     # --- DDPM (ddpm.py:841-860, 930-977) ---
+    def _fuse_step(self, xs, cond, mask, t, lohi, mask_x, noise, sigma):
+        """Branch evaluation + fusion of one step (ddpm.py:769-810 + 853-858) -> (x_{t-1}, x0, [x_out*m, x_in*(1-m)])."""
+        (_, x0o), (_, x0i) = self.predict_branches(xs[0], xs[1], cond, mask, t, lohi, False, mask_x)
+        x0o = x0o.clamp(lohi[0], lohi[1])
+        x0i = x0i.clamp(lohi[0], lohi[1])
+        m = (mask >= 1.0).float()
+        x0 = (x0i * (1.0 - m) + x0o)
+        xo, xi = xs[0] * m, xs[1] * (1.0 - m)
+        assert bool((xo == 0).any()) and bool((xi == 0).any()), "x_out and x_in should be masked"
+        x = torch.where(xo == 0.0, xi, xo)
+        x0 = x0.clamp(lohi[0], lohi[1])
+        mean = self.posterior_mean(x0, x, t)
+        z = noise(x.shape) if t > 0 else 0.0
+        return mean + sigma * z, x0, [xo, xi]
+
     def p_sample_loop(self, cond, mask, lohi, shape, noise, branch, fuse, mask_x, record=None):
         """-> final tensor.  ``record(t, x)`` (optional) sees x_{t-1} after every step."""
         o = self.o
         x = noise(shape)
         joint = not branch
         xs = None
+        x_branchout = None            # masked branch states kept by the fusion step (ddpm.py:799)
         for t in range(self.T - 1, -1, -1):
             sigma = (0.5 * self._c("posterior_log_variance_clipped", t)).exp()
             if not joint:
                 if xs is None:
                     xs = [x, x]
-                (_, x0o), (_, x0i) = self.predict_branches(xs[0], xs[1], cond, mask, t, lohi, False, mask_x)
-                x0o = x0o.clamp(lohi[0], lohi[1])
-                x0i = x0i.clamp(lohi[0], lohi[1])
                 if fuse and t <= o.start_timestep:
-                    m = (mask >= 1.0).float()
-                    x0 = (x0i * (1.0 - m) + x0o)
-                    xo, xi = xs[0] * m, xs[1] * (1.0 - m)
-                    assert bool((xo == 0).any()) and bool((xi == 0).any()), "x_out and x_in should be masked"
-                    x = torch.where(xo == 0.0, xi, xo)
-                    x0 = x0.clamp(lohi[0], lohi[1])
-                    mean = self.posterior_mean(x0, x, t)
-                    z = noise(x.shape) if t > 0 else 0.0
-                    x = mean + sigma * z
-                    joint, xs = True, None
+                    x, _, x_branchout = self._fuse_step(xs, cond, mask, t, lohi, mask_x, noise, sigma)
+                    joint, xs = True, None          # (fusion() only does bookkeeping for this step: branch_cnt == 1, :877)
                     if record:
                         record(t, x)
                     continue
+                (_, x0o), (_, x0i) = self.predict_branches(xs[0], xs[1], cond, mask, t, lohi, False, mask_x)
+                x0o = x0o.clamp(lohi[0], lohi[1])
+                x0i = x0i.clamp(lohi[0], lohi[1])
                 z = noise(xs[0].shape) if t > 0 else 0.0
                 xs = [self.posterior_mean(x0o, xs[0], t) + sigma * z,
                       self.posterior_mean(x0i, xs[1], t) + sigma * z]
@@ -216,6 +231,19 @@ class RefSampler:
                 x0 = x0.clamp(lohi[0], lohi[1])
                 z = noise(x.shape) if t > 0 else 0.0
                 x = self.posterior_mean(x0, x, t) + sigma * z
+                # classifier-gated re-branching (fusion(), ddpm.py:883-916): until a fused prediction is accepted,
+                # every joint step is scored; a rejected one (score <= 0, t > 0) is thrown away and replaced by a
+                # fresh branch + fusion step at the SAME t from the masked branch states of the fusion time, with
+                # mask_x forced on (:906-908).  Noise draws happen in program order (rejected step, then the redo).
+                if o.classifier and fuse and o.branch_out and x_branchout is not None:
+                    if self.classifier_flag == 0:
+                        assert self.classifier is not None, "config['classifier'] needs a callable in .classifier"
+                        self.pred_cls = float(self.classifier(x0)[0])
+                    if self.pred_cls > 0.0 or t == 0:
+                        self.classifier_flag = 1
+                    else:
+                        mask_x = True
+                        x, _, x_branchout = self._fuse_step(x_branchout, cond, mask, t, lohi, mask_x, noise, sigma)
                 if record:
                     record(t, x)
         ret = xs if xs is not None else x

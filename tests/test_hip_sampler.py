@@ -99,6 +99,36 @@ def test_fallback_and_objectives(golden):
         check("G8 " + obj, run(make(MNIST, dict(data="mnist"), 28, 20, objective=obj), cond, None, 2), g[obj + "_final"])
 
 
+class StubClassifier:
+    """Same stand-in as tools/make_goldens.py: score -1 for the first ``reject`` calls, +1 afterwards."""
+    def __init__(self, reject):
+        self.reject, self.calls = reject, 0
+
+    def __call__(self, x0):
+        assert x0.is_cuda and x0.dtype == torch.float32
+        self.calls += 1
+        return (torch.tensor(-1.0 if self.calls <= self.reject else 1.0), None, None)
+
+
+@pytest.mark.parametrize("tag,kw,H,data,key", [("mnist28_reject2", MNIST, 28, "mnist", "28"),
+                                               ("mri32_reject3", dict(mode="mri"), 32, "mri", "32"),
+                                               ("mri32_reject_all", dict(mode="mri"), 32, "mri", "32")])
+def test_classifier_gated_rebranching(golden, tag, kw, H, data, key):
+    """fusion() (ddpm.py:883-916) with a pluggable classifier: rejected joint steps are redone as branch +
+    fusion steps from the masked branch states, t == 0 always accepts.  Golden = the real reference run
+    with the same stub classifier (tools/make_goldens.py g9)."""
+    g = golden("g9_classifier_gate")
+    cond, mask = torch.from_numpy(g["cond" + key]), torch.from_numpy(g["mask" + key])
+    calls, reject = (int(v) for v in g[tag + "_calls"])
+    gd = make(kw, dict(data=data, branch_out=True, start_intermediate=True, start_timestep=7, mask_x=True,
+                       classifier=True), H, 12)
+    with pytest.raises(RuntimeError):                    # gate on, no callable: refuse instead of skipping it
+        run(gd, cond, mask, 2)
+    gd.classifier = StubClassifier(reject)
+    check("G9 " + tag, run(gd, cond, mask, 2), g[tag + "_final"])
+    assert gd.classifier.calls == calls
+
+
 def test_device_noise_runs_and_is_deterministic():
     gd = make(MNIST, dict(data="mnist"), 28, 10)
     gd.noise_source = "device"

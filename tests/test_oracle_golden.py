@@ -133,3 +133,32 @@ def test_fallback_and_objectives(golden):
     for obj in ("pred_noise", "pred_v"):
         out = _run(CFG_MNIST, 28, 2, 20, None, cond, None, data="mnist", objective=obj)
         np.testing.assert_allclose(out, g[obj + "_final"], atol=1e-4, rtol=0)
+
+
+class StubClassifier:
+    """Same stand-in as tools/make_goldens.py: score -1 for the first ``reject`` calls, +1 afterwards."""
+    def __init__(self, reject):
+        self.reject, self.calls = reject, 0
+
+    def __call__(self, x0):
+        self.calls += 1
+        return (torch.tensor(-1.0 if self.calls <= self.reject else 1.0), None, None)
+
+
+@pytest.mark.parametrize("tag,cfg,H,data,key", [("mnist28_reject2", CFG_MNIST, 28, "mnist", "28"),
+                                                ("mri32_reject3", CFG_MRI, 32, "mri", "32"),
+                                                ("mri32_reject_all", CFG_MRI, 32, "mri", "32")])
+def test_classifier_gated_rebranching(golden, tag, cfg, H, data, key):
+    """fusion() (ddpm.py:883-916): rejected joint steps are redone as branch + fusion steps from the masked
+    branch states; t == 0 always accepts.  Golden = the real reference with the same stub classifier."""
+    g = golden("g9_classifier_gate")
+    cond, mask = torch.from_numpy(g["cond" + key]), torch.from_numpy(g["mask" + key])
+    calls, reject = (int(v) for v in g[tag + "_calls"])
+    o = diffusion_ref.SamplerOptions(timesteps=12, branch_out=True, start_intermediate=True, start_timestep=7,
+                                     data=data, mask_x=True, classifier=True)
+    smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(cfg), cfg), o, cfg.channels, H)
+    smp.classifier = StubClassifier(reject)
+    with torch.no_grad():
+        out = smp.sample(cond, mask, (0.0, 2.0), 2, Noise())
+    assert smp.classifier.calls == calls
+    assert float(np.abs(out.numpy() - g[tag + "_final"]).max()) <= 1e-6

@@ -136,7 +136,7 @@ def opts_from(config, T, S=None, objective="pred_x0", sched="sigmoid"):
         timesteps=T, sampling_timesteps=S, objective=objective, beta_schedule=sched,
         branch_out=config["branch_out"], start_intermediate=config["start_intermediate"],
         start_timestep=config["start_timestep"], data=config["data"], mask_x=config["mask_x"],
-        ood_AD=config["ood_AD"], ood_confidence=config["ood_confidence"])
+        ood_AD=config["ood_AD"], ood_confidence=config["ood_confidence"], classifier=bool(config.get("classifier", False)))
 
 
 def maxdiff(a, b):
@@ -429,6 +429,57 @@ def g8(ddpm):
     save("g8_fallback_objectives", **out)
 
 
+class StubClassifier:
+    """Deterministic stand-in for Classifier_PatchCore (ddpm.py:622-625, anomalib is not installed): same call
+    convention -- x0 -> (score, _, _) -- rejecting (score -1) the first ``reject`` calls, then accepting (+1).
+    Records the x0 it was shown."""
+    def __init__(self, reject):
+        self.reject, self.calls, self.seen = reject, 0, []
+
+    def __call__(self, x0):
+        self.calls += 1
+        self.seen.append(x0.detach().clone().cpu())
+        return (torch.tensor(-1.0 if self.calls <= self.reject else 1.0), None, None)
+
+
+def g9(ddpm):
+    print("G9 classifier-gated re-branching (fusion(), ddpm.py:883-916) with a stub classifier")
+    out = {}
+    for tag, cfg, H, data, reject in [("mnist28_reject2", CFG_MNIST, 28, "mnist", 2), ("mri32_reject3", CFG_MRI, 32, "mri", 3),
+                                      ("mri32_reject_all", CFG_MRI, 32, "mri", 99)]:
+        B, T = 2, 12
+        cond = torch.from_numpy(rng.uniform((B, 1, H, H), 9, 1, 0.0, 2.0))
+        mask = band_mask(B, H, H // 4)
+        kw = dict(data=data, branch_out=True, start_intermediate=True, start_timestep=7, mask_x=True, classifier=True)
+        sd = sd_torch(cfg)
+        ref_model = build_reference_unet(ddpm, cfg, sd)
+        gd = _ref_diffusion(ddpm, base_config(**kw), ref_model, H, T, "sigmoid", "pred_x0", None).eval()
+        stub = StubClassifier(reject)
+        gd.classifier = stub
+        noise = PortableNoise(10)
+        with reference_run(noise):
+            with torch.inference_mode():
+                ref_out = gd.sample(cond.clone(), None, batch_size=B, mask=mask.clone(), min_max_val=(0.0, 2.0))
+        o = opts_from(base_config(**kw), T)
+        smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd, cfg), o, cfg.channels, H)
+        stub2 = StubClassifier(reject)
+        smp.classifier = stub2
+        with torch.no_grad():
+            orc = smp.sample(cond, mask, (0.0, 2.0), B, PortableNoise(10))
+        compare("G9 " + tag, ref_out, orc, 2e-5)
+        assert stub.calls == stub2.calls, (stub.calls, stub2.calls)
+        for a, b in zip(stub.seen, stub2.seen):
+            assert maxdiff(a, b) <= 2e-5
+        print(f"    classifier calls: {stub.calls}")
+        out[tag + "_final"] = to_np(ref_out)
+        out[tag + "_calls"] = np.array([stub.calls, reject])
+        if tag == "mnist28_reject2":
+            out["cond28"], out["mask28"] = cond.numpy(), mask.numpy()
+        elif tag == "mri32_reject3":
+            out["cond32"], out["mask32"] = cond.numpy(), mask.numpy()
+    save("g9_classifier_gate", **out)
+
+
 def g0_inventory(ddpm):
     print("G0 parameter inventory")
     lines = []
@@ -451,7 +502,7 @@ def main():
     ddpm = import_reference()
     os.makedirs(GOLD, exist_ok=True)
     todo = [("G0", g0_inventory), ("G1", g1), ("G2", g2), ("G3", g3), ("G4", g4), ("G6", g6),
-            ("G7", g7), ("G8", g8), ("G5", g5)]
+            ("G7", g7), ("G8", g8), ("G9", g9), ("G5", g5)]
     only = set(filter(None, a.only.split(",")))
     for name, fn in todo:
         if only and name not in only:
