@@ -262,6 +262,14 @@ int ld_final_step(const void* x, const float* w, const float* b, float* model_ou
                   int64_t noise_stream, int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 
 
+/* ld_final_step for a sub-batch inside a replayed HIP graph: the noise stream index is
+ * noise_base + noise_tmul * (*t_ptr) (the sampler's draw counter as a function of the device step counter) and
+ * the sub-batch's elements are [noise_first, noise_first + B*Cout*H*W) of that stream's sequence. */
+int ld_final_step_at(const void* x, const float* w, const float* b, float* model_out, float* x_t, float* x0_out,
+                     const float* sched, const int32_t* t_ptr, float lo, float hi, int objective, uint64_t seed,
+                     int64_t noise_base, int64_t noise_tmul, int64_t noise_first, int B, int H, int W, int Cin,
+                     int Cout, int dtype, void* stream);
+
 /* ---- reverse-process pointwise kernels (NCHW fp32) ---------------------------------------- */
 #define LD_OBJ_X0 0
 #define LD_OBJ_NOISE 1
@@ -280,6 +288,9 @@ int ld_final_step(const void* x, const float* w, const float* b, float* model_ou
 /* portable counter-based normals (rng.py): stream = stream_base + stream_tmul * (*t_ptr) */
 int ld_randn(float* out, int64_t n, uint64_t seed, int64_t stream_base, int64_t stream_tmul,
              const int32_t* t_ptr, void* stream);
+/* the slice [first, first + n) of that stream's sequence: sub-batches of one draw generated separately */
+int ld_randn_at(float* out, int64_t n, int64_t first, uint64_t seed, int64_t stream_base, int64_t stream_tmul,
+                const int32_t* t_ptr, void* stream);
 /* *t_ptr += delta  (graph-replayable step counter) */
 int ld_step_add(int32_t* t_ptr, int delta, void* stream);
 

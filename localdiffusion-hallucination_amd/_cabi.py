@@ -82,7 +82,10 @@ _SIGS = {
     "ld_final_conv": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_final_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, u64, i64, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, vp]),
+    "ld_final_step_at": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, u64, i64, i64, i64, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_randn": (C.c_int, [vp, i64, u64, i64, i64, vp, vp]),
+    "ld_randn_at": (C.c_int, [vp, i64, i64, u64, i64, i64, vp, vp]),
     "ld_step_add": (C.c_int, [vp, C.c_int, vp]),
     "ld_ddpm_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, i64, vp]),
     "ld_posterior_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp]),

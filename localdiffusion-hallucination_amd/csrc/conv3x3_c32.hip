@@ -379,7 +379,8 @@ int launch_c32(const C32Dev& a0, hipStream_t st) {
   a.ntiles = a.tiles_x * (a.H / 16);
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
   const size_t lds = (size_t)NCH * 9 * 2 * 1024 + (size_t)R * 21 * 1024 + 2 * ctot * sizeof(float);
-  int G = (256 + a.B - 1) / a.B;                       // one workgroup per CU over the whole launch
+  static const int cus = getenv("LD_CONV_C32_CUS") ? atoi(getenv("LD_CONV_C32_CUS")) : 256;
+  int G = (cus + a.B - 1) / a.B;                       // one workgroup per CU over the whole launch
   if (G > a.ntiles) G = a.ntiles;
   const dim3 grid(G, a.B);
   // the LD_CONV_DEBUG ablation / trace variants are separate instantiations: the production kernel carries none
@@ -413,7 +414,7 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   // register-staged kernel but LOSES 1-6 us on the two-chunk 64->32 ones (the kernel template still carries NCH).
   if (ctot != ck || p->nsrc != 1) return 0;
   if (p->out_stats && (p->out_groups <= 0 || 32 % p->out_groups != 0)) return 0;
-  static const long min_tiles = getenv("LD_CONV_C32_MIN_TILES") ? atol(getenv("LD_CONV_C32_MIN_TILES")) : 1024;
+  static const long min_tiles = getenv("LD_CONV_C32_MIN_TILES") ? atol(getenv("LD_CONV_C32_MIN_TILES")) : 2048;
   const long tiles = (long)(p->W / 16) * (p->H / 16) * p->B;
   if (tiles < min_tiles) return 0;                     // too few tiles to amortise a persistent workgroup
   for (int s = 0; s < p->nsrc; ++s) {                  // the kernel uses 32-bit element offsets

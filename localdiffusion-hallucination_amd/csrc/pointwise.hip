@@ -27,12 +27,12 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
-__global__ void randn_kernel(float* out, long n, unsigned long long seed, long stream_base, long stream_tmul,
+__global__ void randn_kernel(float* out, long n, long first, unsigned long long seed, long stream_base, long stream_tmul,
                              const int* t_ptr) {
   const long stream = stream_base + (t_ptr ? stream_tmul * (long)(*t_ptr) : 0);
   const unsigned long long base = mix64(seed ^ ((unsigned long long)stream * 0xD1B54A32D192ED03ull));
   GRID_STRIDE(i, n) {
-    const unsigned long long h = mix64(base + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull);
+    const unsigned long long h = mix64(base + (unsigned long long)(first + i + 1) * 0x9E3779B97F4A7C15ull);
     const float u1 = ((float)(unsigned)(h >> 40) + 1.0f) * 5.9604644775390625e-8f;          // 2^-24
     const float u2 = (float)(unsigned)((h >> 16) & 0xFFFFFFu) * 5.9604644775390625e-8f;
     out[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
@@ -190,10 +190,12 @@ template <typename T>
 __global__ void final_step_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                   float* __restrict__ model_out, float* __restrict__ x_t, float* __restrict__ x0o,
                                   const float* __restrict__ sched, const int* __restrict__ t_ptr, float lo, float hi,
-                                  int obj, unsigned long long seed, long stream, int HW, int Cin, int Cout, long npix) {
+                                  int obj, unsigned long long seed, long stream_base, long stream_tmul, long first,
+                                  int HW, int Cin, int Cout, long npix) {
   extern __shared__ float s_fw[];
   for (int i = threadIdx.x; i < Cin * Cout; i += BS) s_fw[i] = w[i];
   const int t = t_ptr ? *t_ptr : 0;
+  const long stream = stream_base + stream_tmul * (long)t;
   const float* row = sched + (size_t)t * LD_SCHED_COLS;
   const float c1 = row[LD_SCHED_COEF1], c2 = row[LD_SCHED_COEF2], sg = row[LD_SCHED_SIGMA];
   const unsigned long long base = mix64(seed ^ ((unsigned long long)stream * 0xD1B54A32D192ED03ull));
@@ -211,7 +213,7 @@ __global__ void final_step_kernel(const T* __restrict__ x, const float* __restri
       const float mean = c1 * x0 + c2 * xi;
       float r = mean;
       if (t > 0) {
-        const unsigned long long h = mix64(base + (unsigned long long)(idx + 1) * 0x9E3779B97F4A7C15ull);
+        const unsigned long long h = mix64(base + (unsigned long long)(first + idx + 1) * 0x9E3779B97F4A7C15ull);
         const float u1 = ((float)(unsigned)(h >> 40) + 1.0f) * 5.9604644775390625e-8f;          // 2^-24
         const float u2 = (float)(unsigned)((h >> 16) & 0xFFFFFFu) * 5.9604644775390625e-8f;
         r = mean + sg * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
@@ -225,13 +227,17 @@ __global__ void final_step_kernel(const T* __restrict__ x, const float* __restri
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
-extern "C" int ld_randn(float* out, int64_t n, uint64_t seed, int64_t stream_base, int64_t stream_tmul,
-                        const int32_t* t_ptr, void* stream) {
-  LD_REQUIRE(out && n > 0, "ld_randn: bad args");
-  hipLaunchKernelGGL(randn_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), out, (long)n,
+extern "C" int ld_randn_at(float* out, int64_t n, int64_t first, uint64_t seed, int64_t stream_base,
+                           int64_t stream_tmul, const int32_t* t_ptr, void* stream) {
+  LD_REQUIRE(out && n > 0 && first >= 0, "ld_randn: bad args");
+  hipLaunchKernelGGL(randn_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), out, (long)n, (long)first,
                      (unsigned long long)seed, (long)stream_base, (long)stream_tmul, t_ptr);
   LD_LAUNCH_CHECK("randn");
   return LD_OK;
+}
+extern "C" int ld_randn(float* out, int64_t n, uint64_t seed, int64_t stream_base, int64_t stream_tmul,
+                        const int32_t* t_ptr, void* stream) {
+  return ld_randn_at(out, n, 0, seed, stream_base, stream_tmul, t_ptr, stream);
 }
 extern "C" int ld_step_add(int32_t* t_ptr, int delta, void* stream) {
   LD_REQUIRE(t_ptr, "ld_step_add: null");
@@ -332,10 +338,13 @@ extern "C" int ld_final_conv(const void* x, const float* w, const float* b, floa
   return LD_OK;
 }
 
-extern "C" int ld_final_step(const void* x, const float* w, const float* b, float* model_out, float* x_t, float* x0_out,
-                             const float* sched, const int32_t* t_ptr, float lo, float hi, int objective, uint64_t seed,
-                             int64_t noise_stream, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+extern "C" int ld_final_step_at(const void* x, const float* w, const float* b, float* model_out, float* x_t,
+                                float* x0_out, const float* sched, const int32_t* t_ptr, float lo, float hi,
+                                int objective, uint64_t seed, int64_t noise_base, int64_t noise_tmul,
+                                int64_t noise_first, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
   LD_REQUIRE(x && w && b && model_out && x_t && sched, "ld_final_step: null pointer");
+  LD_REQUIRE(noise_first >= 0 && (noise_tmul == 0 || t_ptr), "ld_final_step: noise_first %ld, noise_tmul without t_ptr",
+             (long)noise_first);
   LD_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 8 == 0, "ld_final_step: Cout %d (1..4), Cin %d (multiple of 8)", Cout, Cin);
   LD_REQUIRE(objective >= 0 && objective <= 2, "ld_final_step: objective %d", objective);
   LD_REQUIRE(dtype == LD_F32 || dtype == LD_BF16, "ld_final_step: bad dtype %d", dtype);
@@ -343,10 +352,18 @@ extern "C" int ld_final_step(const void* x, const float* w, const float* b, floa
   const size_t lds = (size_t)Cin * Cout * sizeof(float);
   if (dtype == LD_F32)
     hipLaunchKernelGGL(final_step_kernel<float>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const float*)x, w, b, model_out,
-                       x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_stream, H * W, Cin, Cout, npix);
+                       x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_base, (long)noise_tmul,
+                       (long)noise_first, H * W, Cin, Cout, npix);
   else
     hipLaunchKernelGGL(final_step_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const bf16*)x, w, b, model_out,
-                       x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_stream, H * W, Cin, Cout, npix);
+                       x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_base, (long)noise_tmul,
+                       (long)noise_first, H * W, Cin, Cout, npix);
   LD_LAUNCH_CHECK("final_step");
   return LD_OK;
+}
+extern "C" int ld_final_step(const void* x, const float* w, const float* b, float* model_out, float* x_t, float* x0_out,
+                             const float* sched, const int32_t* t_ptr, float lo, float hi, int objective, uint64_t seed,
+                             int64_t noise_stream, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+  return ld_final_step_at(x, w, b, model_out, x_t, x0_out, sched, t_ptr, lo, hi, objective, seed, noise_stream, 0, 0,
+                          B, H, W, Cin, Cout, dtype, stream);
 }

@@ -31,6 +31,82 @@ from . import rng, schedule
 _REPLACE_OUT = ("mnist", "mvtec", "oct", "imagenet")
 
 
+class _SubBatches:
+    """The joint reverse steps of one batch run as S independent sub-batches, each on its own HIP stream as a
+    replayed HIP graph of one step.
+
+    Patches do not interact inside the T-loop, so a batch can be cut anywhere.  A step alternates between
+    HBM-bound launches (256^2, 128^2 maps) and latency / L2-bound ones (64^2, 32^2 maps: a few hundred
+    workgroups, dependent K-chunk round trips); two sub-batches on two hardware queues fill each other's gaps
+    (measured on cfg3: 1.87 -> 1.66 ms per step of 8 patches).  Every sub-batch draws its slice of the batch's
+    noise stream (ld_final_step_at), so the samples are those of the unsplit batch up to the tiling-dependent
+    summation order of the kernels.  x_t is scattered from / gathered back into the parent plan's ``x_in``."""
+
+    def __init__(self, gd, jp, S):
+        self.gd, self.jp, self.S = gd, jp, S
+        B, _, H, W = jp.x_in.shape
+        self.b = B // S
+        self.plans = [gd.model.plan(self.b, H, W, table_T=gd.num_timesteps_ori, instance=i + 1) for i in range(S)]
+        self.streams = [torch.cuda.Stream() for _ in range(S)]
+        self.graphs = {}
+        self.cond_seen = None
+
+    def _step(self, i, st, lo, hi, base):
+        gd, sp = self.gd, self.plans[i]
+        lib = cabi.lib()
+        xa, wf, bf = sp.final
+        B_, C_, H_, W_ = sp.model_out.shape
+        sp.run_main(st, skip_final=True)
+        cabi.check(lib.ld_final_step_at(xa.data_ptr(), wf.data_ptr(), bf.data_ptr(), sp.model_out.data_ptr(),
+                                        sp.x_in.data_ptr(), None, gd._sched_table().data_ptr(), sp.t_dev.data_ptr(),
+                                        lo, hi, cabi.OBJ[gd.objective], gd.noise_seed, base, -1,
+                                        i * sp.x_in.numel(), B_, H_, W_, wf.shape[1], C_, sp.dt, st), "final_step")
+        cabi.check(lib.ld_step_add(sp.t_dev.data_ptr(), -1, st), "step_add")
+
+    def run(self, t_start, n_steps, lo, hi, draw):
+        import ctypes as C
+        lib, jp, b = cabi.lib(), self.jp, self.b
+        cur = torch.cuda.current_stream()
+        base = draw + t_start                       # noise stream index of step t is base - t (one draw per t > 0)
+        recond = self.cond_seen != getattr(jp, "cond_version", 0)
+        self.cond_seen = getattr(jp, "cond_version", 0)
+        todo, ex = [n_steps] * self.S, [None] * self.S
+        for i, (sp, gs) in enumerate(zip(self.plans, self.streams)):
+            gs.wait_stream(cur)
+            st = gs.cuda_stream
+            with torch.cuda.stream(gs):
+                sp.x_in.copy_(jp.x_in[i * b:(i + 1) * b])
+                if recond:                          # the parent's conditioning changed: encode this slice of it
+                    sp.cond_in.copy_(jp.cond_in[i * b:(i + 1) * b])
+                    sp.run_cond(st)
+                sp.set_step(t_start)
+                key = (i, float(lo), float(hi), base)
+                if key not in self.graphs:
+                    # one eager step first: lazy hipFuncSetAttribute calls must not happen inside a capture
+                    self._step(i, st, lo, hi, base)
+                    todo[i] -= 1
+                    gs.synchronize()
+                    cabi.check(lib.ld_graph_begin(st), "graph_begin")
+                    try:
+                        self._step(i, st, lo, hi, base)      # recorded, not run: the step counter stays put
+                    finally:
+                        g = C.c_void_p()
+                        rc = lib.ld_graph_end(st, C.byref(g))
+                    cabi.check(rc, "graph_end")
+                    self.graphs[key] = g
+                ex[i] = self.graphs[key]
+        # interleave the launches so that neither hardware queue runs ahead of the other
+        for k in range(max(todo)):
+            for i, gs in enumerate(self.streams):
+                if k < todo[i]:
+                    cabi.check(lib.ld_graph_launch(ex[i], gs.cuda_stream), "graph_launch")
+        for i, (sp, gs) in enumerate(zip(self.plans, self.streams)):
+            with torch.cuda.stream(gs):
+                jp.x_in[i * b:(i + 1) * b].copy_(sp.x_in)
+            cur.wait_stream(gs)
+        return draw + min(n_steps, t_start)         # steps t > 0 consumed one draw each
+
+
 class GaussianDiffusion(nn.Module):
     def __init__(self, config, model, *, image_size, timesteps=1000, sampling_timesteps=None,
                  objective="pred_v", beta_schedule="sigmoid", schedule_fn_kwargs=dict(),
@@ -74,8 +150,12 @@ class GaussianDiffusion(nn.Module):
         self.fuse_final_step = os.environ.get("LD_NO_FUSED_FINAL") is None
         self.noise_seed = 10                      # torch.manual_seed(10), ddpm.py:934
         self.use_graph = False
+        # concurrent sub-batches of the joint steps (see _SubBatches); 1 = one batch on the caller's stream
+        self.sub_batches = int(os.environ.get("LD_SUB_BATCHES", "2"))
+        self.min_sub_batch = int(os.environ.get("LD_MIN_SUB_BATCH", "4"))
         self._sched = None
         self._graphs = {}
+        self._subs = {}
 
     # ------------------------------------------------------------------ small API pieces
     def call_classifier(self):
@@ -174,6 +254,15 @@ class GaussianDiffusion(nn.Module):
         sched = self._sched_table()
         obj = cabi.OBJ[self.objective]
         n = jp.x_in.numel()
+        B_ = jp.x_in.shape[0]
+        S = self.sub_batches
+        if (S > 1 and B_ % S == 0 and B_ // S >= self.min_sub_batch and self.noise_source == "device"
+                and x0_buf is None and after is None and timers is None and n_steps >= 4 and not self.use_graph
+                and jp.x_in.shape[1] == jp.model_out.shape[1]):
+            key = (id(jp), S)
+            if key not in self._subs:
+                self._subs[key] = _SubBatches(self, jp, S)
+            return self._subs[key].run(t_start, n_steps, lo, hi, draw)
         if (self.use_graph and self.noise_source == "device" and x0_buf is None and after is None
                 and timers is None and n_steps > 1):
             return self._run_joint_steps_graph(jp, t_start, n_steps, lo, hi, z, draw)

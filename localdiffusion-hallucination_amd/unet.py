@@ -232,11 +232,12 @@ class Unet(nn.Module):
         return P
 
     # ------------------------------------------------------------------ plans
-    def plan(self, B, H, W, table_T=None):
+    def plan(self, B, H, W, table_T=None, instance=0):
+        """``instance`` > 0: further plans of the same shape with their own buffers (concurrent sub-batches)."""
         f = self.downsample_factor
         assert H % f == 0 and W % f == 0, \
             f"your input dimensions {(H, W)} need to be divisible by {f}, given the unet"   # ddpm.py:405
-        key = (B, H, W, table_T, self.compute_dtype)
+        key = (B, H, W, table_T, self.compute_dtype, instance)
         if key not in self._plans:
             self._plans[key] = _Plan(self, B, H, W, table_T)
         return self._plans[key]
@@ -692,6 +693,7 @@ class _Plan:
             op(st)
 
     def run_cond(self, st):
+        self.cond_version = getattr(self, "cond_version", 0) + 1
         s = self.stats[:self.cond_slots]
         cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
         for op in self.ops_cond:

@@ -449,10 +449,10 @@ def test_linear_attention_fused_bf16(c, H, W, single_sweep):
 # ------------------------------------------------------------------------------ persistent C=32 conv (conv3x3_c32.hip)
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_c32_persistent_path(dtype):
-    """32 -> 32 at 256^2 (>= 1024 tiles, one K-chunk, H and W multiples of 16) takes the persistent deep-ring
+    """32 -> 32 at 256^2 (>= 2048 tiles, one K-chunk, H and W multiples of 16) takes the persistent deep-ring
     LDS-DMA kernel: plain + statistics, GroupNorm+FiLM+SiLU prologue; the 64 -> 32 concat / nearest-x2 cases
     (two K-chunks, also a ragged width) take the register-staged kernel at the same size."""
-    B, H, W, cout = 4, 256, 256, 32
+    B, H, W, cout = 8, 256, 256, 32
     cin = 32
     x, w, b = _q(hh.rand((B, cin, H, W), 201), dtype), _q(hh.rand((cout, cin, 3, 3), 202, -0.1, 0.1), dtype), hh.rand((cout,), 203)
     ref = F.conv2d(x, w, b, padding=1)

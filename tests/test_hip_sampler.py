@@ -167,6 +167,28 @@ def test_graph_replay_matches_eager():
     assert np.array_equal(graph, again)
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+def test_concurrent_sub_batches_match_the_single_batch(dtype, tol):
+    """The joint steps of 8 patches as two sub-batches of 4 on two streams (replayed HIP graphs, sliced noise
+    stream) give the samples of the single batch: same noise, same per-patch arithmetic up to the summation
+    order of the statistics atomics (fp32) / the tile variants picked for the smaller batch (bf16)."""
+    cond = torch.from_numpy(rng.uniform((8, 1, 32, 32), 8, 1, 0.0, 2.0))
+    gd = make(dict(mode="mri"), dict(data="mri"), 32, 12, dtype=dtype)
+    gd.noise_source = "device"
+    gd.sub_batches = 1
+    single = run(gd, cond, None, 8)
+    gd.sub_batches, gd.min_sub_batch = 2, 4
+    split = run(gd, cond, None, 8)
+    again = run(gd, cond, None, 8)            # second call replays the cached graphs
+    assert len(gd._subs) == 1 and np.isfinite(split).all()
+    d = float(np.abs(split - single).max())
+    print(f"sub-batches vs single batch ({dtype}): max-abs {d:.3e}")
+    assert d <= tol
+    assert float(np.abs(again - split).max()) <= tol
+    gd.sub_batches, gd.min_sub_batch = 4, 2   # four sub-batches of 2
+    check("4x2 " + dtype, run(gd, cond, None, 8), single, tol)
+
+
 def test_eval_driver_matches_cfg1_golden(golden, tmp_path):
     """evalio.evaluate (test.py-equivalent loop) on the 4 golden digits == the reference's cfg1 output."""
     from localdiffusion_hallucination_amd import evalio
