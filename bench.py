@@ -192,7 +192,8 @@ def main():
                                f"4-stage dim-32 conditional UNet (12.1M params), DDPM T={T_STEPS}, pred_x0, sigmoid schedule",
                    "patches_per_gpu": P, "image": [3, H, H], "timesteps": T_STEPS,
                    "parallelism": f"patch-sharded x{world}, one all-gather per sample",
-                   "hip_graph": bool(gd.use_graph)},
+                   "hip_graph": bool(gd.use_graph),
+                   "concurrent_sub_batches": (gd.sub_batches if gd.timed_plan(jp) is not jp else 1)},
     }
 
     if rank == 0 and not a.no_roofline:
@@ -200,10 +201,11 @@ def main():
         acc = {}
         torch.cuda.synchronize()
         gd.run_joint_steps(jp, 500, 5, lo, hi, z, 1, timers=acc)
+        tp = gd.timed_plan(jp)            # sub-batch 0 (timed beside the other sub-batch) when the step runs split
         fam = {}
         total_ms = 0.0
         for i, (ms, cnt) in acc.items():
-            m = jp.meta.get(i, {})
+            m = tp.meta.get(i, {})
             total_ms += ms
             f = fam.setdefault(m.get("family", m.get("what", "other").split(" ")[0]), dict(ms=0.0, launches=0, bytes=0, flops=0))
             f["ms"] += ms
@@ -214,7 +216,7 @@ def main():
             with open(os.environ["LD_BENCH_OPS"], "w") as f:
                 for i in sorted(acc):
                     ms, cnt = acc[i]
-                    m = jp.meta.get(i, {})
+                    m = tp.meta.get(i, {})
                     us = 1e3 * ms / cnt
                     f.write(f"{i:4d} {m.get('family', '?'):22s} {m.get('what', '?'):38s} {m.get('shape', ''):20s} "
                             f"{us:9.1f} us  {m.get('bytes', 0) / max(us, 1e-9) / 1e3:8.1f} GB/s  "
@@ -237,7 +239,7 @@ def main():
                 traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof.update({"kernel": name, "traffic": traffic, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),
+        roof.update({"kernel": name, "launch_batch": int(tp.x_in.shape[0]), "traffic": traffic, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),
                      "algorithmic_GBps": gbs, "algorithmic_TFLOPps": tfs,
                      "share_of_step": d["ms"] / max(total_ms, 1e-9),
                      # whole path: 0.7036 TB of algorithmic traffic per 256^2 bf16 patch over T=1000

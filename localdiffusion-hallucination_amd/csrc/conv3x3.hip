@@ -348,7 +348,8 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
   bool mt4 = (a.Cout % 64) == 0;
   // a launch that would not even give every CU one 64-channel-tile workgroup uses 32-channel tiles instead
   // (128->128 @32^2, B=8: 128 workgroups -> 256; rocprofv3: 10.3 -> 8.3 us)
-  if (mt4 && (long)((a.W + 15) / 16) * ((a.H + 7) / 8) * (a.Cout / 64) * a.B < 256) mt4 = false;
+  static const long mt4_min = getenv("LD_CONV_MT4_MIN_WGS") ? atol(getenv("LD_CONV_MT4_MIN_WGS")) : 256;
+  if (mt4 && (long)((a.W + 15) / 16) * ((a.H + 7) / 8) * (a.Cout / 64) * a.B < mt4_min) mt4 = false;
   // enough workgroups to fill 256 CUs a couple of times over with the big tile?
   const long blocks16 = (long)((a.W + 15) / 16) * ((a.H + 15) / 16) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
   // 64-channel tiles keep 2 pixel rows per wave: with the prefetch registers the 4-row variant

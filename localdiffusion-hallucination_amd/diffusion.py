@@ -63,8 +63,31 @@ class _SubBatches:
                                         i * sp.x_in.numel(), B_, H_, W_, wf.shape[1], C_, sp.dt, st), "final_step")
         cabi.check(lib.ld_step_add(sp.t_dev.data_ptr(), -1, st), "step_add")
 
-    def run(self, t_start, n_steps, lo, hi, draw):
+    def _ensure_graph(self, i, gs, lo, hi, base):
+        """Capture sub-batch i's step for this noise base if not done yet (call with ``gs`` current).  Returns the
+        number of steps run eagerly on the way (1 the first time: lazy hipFuncSetAttribute calls must not
+        happen inside a capture)."""
         import ctypes as C
+        lib, st = cabi.lib(), gs.cuda_stream
+        key = (i, float(lo), float(hi), base)
+        if key in self.graphs:
+            return 0
+        ran = 0
+        if not any(k[0] == i for k in self.graphs):
+            self._step(i, st, lo, hi, base)
+            ran = 1
+        gs.synchronize()
+        cabi.check(lib.ld_graph_begin(st), "graph_begin")
+        try:
+            self._step(i, st, lo, hi, base)          # recorded, not run: the step counter stays put
+        finally:
+            g = C.c_void_p()
+            rc = lib.ld_graph_end(st, C.byref(g))
+        cabi.check(rc, "graph_end")
+        self.graphs[key] = g
+        return ran
+
+    def run(self, t_start, n_steps, lo, hi, draw):
         lib, jp, b = cabi.lib(), self.jp, self.b
         cur = torch.cuda.current_stream()
         base = draw + t_start                       # noise stream index of step t is base - t (one draw per t > 0)
@@ -80,21 +103,8 @@ class _SubBatches:
                     sp.cond_in.copy_(jp.cond_in[i * b:(i + 1) * b])
                     sp.run_cond(st)
                 sp.set_step(t_start)
-                key = (i, float(lo), float(hi), base)
-                if key not in self.graphs:
-                    # one eager step first: lazy hipFuncSetAttribute calls must not happen inside a capture
-                    self._step(i, st, lo, hi, base)
-                    todo[i] -= 1
-                    gs.synchronize()
-                    cabi.check(lib.ld_graph_begin(st), "graph_begin")
-                    try:
-                        self._step(i, st, lo, hi, base)      # recorded, not run: the step counter stays put
-                    finally:
-                        g = C.c_void_p()
-                        rc = lib.ld_graph_end(st, C.byref(g))
-                    cabi.check(rc, "graph_end")
-                    self.graphs[key] = g
-                ex[i] = self.graphs[key]
+                todo[i] -= self._ensure_graph(i, gs, lo, hi, base)
+                ex[i] = self.graphs[(i, float(lo), float(hi), base)]
         # interleave the launches so that neither hardware queue runs ahead of the other
         for k in range(max(todo)):
             for i, gs in enumerate(self.streams):
@@ -105,6 +115,40 @@ class _SubBatches:
                 jp.x_in[i * b:(i + 1) * b].copy_(sp.x_in)
             cur.wait_stream(gs)
         return draw + min(n_steps, t_start)         # steps t > 0 consumed one draw each
+
+    def run_timed(self, t_start, n_steps, lo, hi, draw, acc):
+        """bench.py's per-kernel leg in the regime the timed region runs in: sub-batch 0 steps eagerly with
+        HIP events around every launch (``acc``, see _Plan.run_main_timed) while the other sub-batches replay
+        their graphs beside it."""
+        lib, jp, b, gd = cabi.lib(), self.jp, self.b, self.gd
+        cur = torch.cuda.current_stream()
+        base = draw + t_start
+        sched, obj = gd._sched_table(), cabi.OBJ[gd.objective]
+        for i, (sp, gs) in enumerate(zip(self.plans, self.streams)):
+            gs.wait_stream(cur)
+            with torch.cuda.stream(gs):
+                sp.x_in.copy_(jp.x_in[i * b:(i + 1) * b])
+                sp.set_step(t_start)
+        for i in range(1, self.S):
+            with torch.cuda.stream(self.streams[i]):
+                self._ensure_graph(i, self.streams[i], lo, hi, base)
+            g = self.graphs[(i, float(lo), float(hi), base)]
+            for _ in range(n_steps + 2):
+                cabi.check(lib.ld_graph_launch(g, self.streams[i].cuda_stream), "graph_launch")
+        sp, gs = self.plans[0], self.streams[0]
+        z = torch.empty_like(sp.x_in)
+        with torch.cuda.stream(gs):
+            st = gs.cuda_stream
+            for k in range(n_steps):
+                sp.set_step(t_start - k)
+                sp.run_main_timed(st, acc)
+                cabi.check(lib.ld_randn_at(z.data_ptr(), z.numel(), 0, gd.noise_seed, base, -1, sp.t_dev.data_ptr(), st), "randn")
+                cabi.check(lib.ld_ddpm_step(sp.x_in.data_ptr(), sp.model_out.data_ptr(), z.data_ptr(), sp.x_in.data_ptr(),
+                                            None, sched.data_ptr(), sp.t_dev.data_ptr(), lo, hi, obj, z.numel(), st), "ddpm_step")
+        for gs in self.streams:
+            cur.wait_stream(gs)
+        torch.cuda.synchronize()
+        return draw + min(n_steps, t_start)
 
 
 class GaussianDiffusion(nn.Module):
@@ -244,6 +288,12 @@ class GaussianDiffusion(nn.Module):
                                     float(min_max_val[1]), cabi.OBJ[self.objective], x.numel(), st), "ddpm_step")
         return x_prev, x0
 
+    def timed_plan(self, jp):
+        """The plan whose launches ``run_joint_steps(..., timers=acc)`` times: sub-batch 0 when the joint steps
+        of ``jp`` run as concurrent sub-batches, else ``jp`` itself."""
+        sub = self._subs.get((id(jp), self.sub_batches))
+        return sub.plans[0] if sub is not None else jp
+
     # ------------------------------------------------------------------ joint reverse steps
     def run_joint_steps(self, jp, t_start, n_steps, lo, hi, z, draw, x0_buf=None, after=None, timers=None):
         """``n_steps`` ancestral steps t_start, t_start-1, ... on plan ``jp`` (x_t lives in
@@ -263,6 +313,8 @@ class GaussianDiffusion(nn.Module):
             if key not in self._subs:
                 self._subs[key] = _SubBatches(self, jp, S)
             return self._subs[key].run(t_start, n_steps, lo, hi, draw)
+        if timers is not None and (id(jp), S) in self._subs and x0_buf is None and after is None:
+            return self._subs[(id(jp), S)].run_timed(t_start, n_steps, lo, hi, draw, timers)
         if (self.use_graph and self.noise_source == "device" and x0_buf is None and after is None
                 and timers is None and n_steps > 1):
             return self._run_joint_steps_graph(jp, t_start, n_steps, lo, hi, z, draw)
