@@ -239,7 +239,9 @@ def main():
                 traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof.update({"kernel": name, "launch_batch": int(tp.x_in.shape[0]), "traffic": traffic, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),
+        roof.update({"kernel": name, "launch_batch": int(tp.x_in.shape[0]),
+                     # launches of that many independent sub-batches share the GPU while this one is timed
+                     "concurrent_streams": (gd.sub_batches if tp is not jp else 1), "traffic": traffic, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),
                      "algorithmic_GBps": gbs, "algorithmic_TFLOPps": tfs,
                      "share_of_step": d["ms"] / max(total_ms, 1e-9),
                      # whole path: 0.7036 TB of algorithmic traffic per 256^2 bf16 patch over T=1000

@@ -62,6 +62,12 @@ int ld_graph_destroy(void* graph_exec);
 /* hipMemsetAsync(ptr, 0, bytes) on the stream (statistics arenas are zeroed once per forward) */
 int ld_memset_zero(void* ptr, size_t bytes, void* stream);
 /* event timing on the stream the kernels run on (bench.py's roofline leg) */
+/* Per-launch timing session: between begin and end every kernel launched by this library (from the calling
+ * process, any stream) carries its own start/stop events; ld_timing_count() = launches so far, ld_timing_end fills
+ * ms[i] with launch i's execution time (dispatch begin -> end, what rocprofv3 --kernel-trace reports). */
+int ld_timing_begin(int max_launches);
+int ld_timing_count(void);
+int ld_timing_end(float* ms, int cap, int* count);
 int ld_event_create(void** ev_out);
 int ld_event_record(void* ev, void* stream);
 int ld_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on stop */

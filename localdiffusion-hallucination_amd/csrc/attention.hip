@@ -247,9 +247,9 @@ extern "C" int ld_attention(const void* qkv, void* out, int B, int n, int heads,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((n + 63) / 64, heads, B);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, (float*)out, n, heads);
+    LD_LAUNCH(attention_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, (float*)out, n, heads);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(attention_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, n, heads);
+    LD_LAUNCH(attention_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, n, heads);
   else
     return ld_fail(LD_EINVAL, "ld_attention: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("attention");

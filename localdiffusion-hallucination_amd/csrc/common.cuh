@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels (wave64, MFMA 16x16 tiles, 64-byte K-chunks).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -19,6 +20,19 @@ int ld_fail(int code, const char* fmt, ...);   // runtime.hip
     hipError_t e_ = (call);                                                            \
     if (e_ != hipSuccess) return ld_fail(LD_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
   } while (0)
+// Every kernel launch goes through LD_LAUNCH: while a timing session is open (ld_timing_begin, runtime.hip) the launch
+// carries its own start/stop events (hipExtLaunchKernelGGL: the dispatch packet's begin/end timestamps, i.e. the
+// kernel's execution time as rocprofv3 reports it, without the barrier packets of events recorded between launches).
+bool ld_timing_next(hipEvent_t* start, hipEvent_t* stop);
+#define LD_LAUNCH(kernel, grid, block, lds, st, ...)                                                              \
+  do {                                                                                                            \
+    hipEvent_t ld_e0_, ld_e1_;                                                                                    \
+    if (ld_timing_next(&ld_e0_, &ld_e1_))                                                                         \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ld_e0_, ld_e1_, 0, __VA_ARGS__);                        \
+    else                                                                                                          \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                              \
+  } while (0)
+
 #define LD_LAUNCH_CHECK(name)                                                          \
   do {                                                                                 \
     hipError_t e_ = hipGetLastError();                                                 \

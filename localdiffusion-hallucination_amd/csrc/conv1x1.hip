@@ -278,7 +278,7 @@ int launch_epi(const Conv1Dev& a, hipStream_t st) {
   const size_t lds = 4 * NPT * 16 + MT * 1024 + NPT * sizeof(float) + (EPI == LD_EPI_GN_TAIL ? 2 * a.Cout * sizeof(float) + 64 * sizeof(double) : 0);
   const int HW = a.H * a.W;
   dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
-  hipLaunchKernelGGL((conv1x1_kernel<T, MT, NW, EPI>), grid, dim3(256), lds, st, a);
+  LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI>), grid, dim3(256), lds, st, a);
   LD_LAUNCH_CHECK("conv1x1");
   return LD_OK;
 }

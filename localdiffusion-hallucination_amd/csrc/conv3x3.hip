@@ -316,7 +316,7 @@ int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   d.tiles_x = (a.W + 15) / 16;
   const int tiles_y = (a.H + TR - 1) / TR;
   dim3 grid(d.tiles_x * tiles_y, a.Cout / (16 * MT), a.B);
-  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NW, DEEP, DBG>), grid, dim3(256), lds, st, d);
+  LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG>), grid, dim3(256), lds, st, d);
   LD_LAUNCH_CHECK("conv3x3");
   return LD_OK;
 }

@@ -367,7 +367,7 @@ int launch_c32_dbg(C32Dev& a, size_t lds, dim3 grid, hipStream_t st) {
     LD_HIP(ld_allow_lds(conv3x3_c32_kernel<T, NCH, R, DBG>, lds));
     allowed = lds;
   }
-  hipLaunchKernelGGL((conv3x3_c32_kernel<T, NCH, R, DBG>), grid, dim3(512), lds, st, a);
+  LD_LAUNCH((conv3x3_c32_kernel<T, NCH, R, DBG>), grid, dim3(512), lds, st, a);
   LD_LAUNCH_CHECK("conv3x3_c32");
   return LD_OK;
 }

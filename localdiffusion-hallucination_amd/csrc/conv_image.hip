@@ -221,9 +221,9 @@ int run(const float* x, const float* w, const float* bias, void* out, double* os
   const int tiles_x = (W + TS - 1) / TS, tiles_y = (H + TH - 1) / TH;
   dim3 grid(tiles_x * tiles_y, B);
   if (ks == 7)
-    hipLaunchKernelGGL((conv_image_kernel<T, 7>), grid, dim3(256), 0, st, x, w, bias, (T*)out, ostats, ogroups, B, Cin, H, W, tiles_x);
+    LD_LAUNCH((conv_image_kernel<T, 7>), grid, dim3(256), 0, st, x, w, bias, (T*)out, ostats, ogroups, B, Cin, H, W, tiles_x);
   else
-    hipLaunchKernelGGL((conv_image_kernel<T, 3>), grid, dim3(256), 0, st, x, w, bias, (T*)out, ostats, ogroups, B, Cin, H, W, tiles_x);
+    LD_LAUNCH((conv_image_kernel<T, 3>), grid, dim3(256), 0, st, x, w, bias, (T*)out, ostats, ogroups, B, Cin, H, W, tiles_x);
   LD_LAUNCH_CHECK("conv_image");
   return LD_OK;
 }
@@ -246,7 +246,7 @@ extern "C" size_t ld_stem_packed_bytes(void) { return (size_t)STEM_PACKED_U16 * 
 extern "C" int ld_pack_stem_weight(const float* w_oihw, void* out_packed, int Cin, void* stream) {
   LD_REQUIRE(w_oihw && out_packed, "ld_pack_stem_weight: null pointer");
   LD_REQUIRE(Cin >= 1 && Cin <= 3, "ld_pack_stem_weight: Cin %d (1..3)", Cin);
-  hipLaunchKernelGGL(stem_pack_kernel, dim3((32 * STEM_NCHK * 32 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  LD_LAUNCH(stem_pack_kernel, dim3((32 * STEM_NCHK * 32 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      w_oihw, (unsigned short*)out_packed, Cin);
   LD_LAUNCH_CHECK("pack_stem_weight");
   return LD_OK;
@@ -259,7 +259,7 @@ extern "C" int ld_conv_stem(const float* x, const void* w_packed, const float* b
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 31) / 32, ntiles = tiles_x * tiles_y;
   int G = (512 + B - 1) / B;                             // ~2 persistent workgroups per CU
   if (G > ntiles) G = ntiles;
-  hipLaunchKernelGGL(conv_stem_mfma_kernel, dim3(G, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+  LD_LAUNCH(conv_stem_mfma_kernel, dim3(G, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
                      (const uint4*)w_packed, bias, (bf16*)out, B, Cin, H, W, tiles_x, ntiles);
   LD_LAUNCH_CHECK("conv_stem");
   return LD_OK;

@@ -111,11 +111,11 @@ int run(const GnDev& g, hipStream_t st) {
   dim3 grid((unsigned)blocks, g.B);
   const size_t lds = 4 * g.a.C * sizeof(float) + 64 * sizeof(double);
   if (g.has_b) {
-    if (g.pool) hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), grid, dim3(256), lds, st, g);
-    else hipLaunchKernelGGL((gn_apply_kernel<T, true, false>), grid, dim3(256), lds, st, g);
+    if (g.pool) LD_LAUNCH((gn_apply_kernel<T, true, true>), grid, dim3(256), lds, st, g);
+    else LD_LAUNCH((gn_apply_kernel<T, true, false>), grid, dim3(256), lds, st, g);
   } else {
-    if (g.pool) hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), grid, dim3(256), lds, st, g);
-    else hipLaunchKernelGGL((gn_apply_kernel<T, false, false>), grid, dim3(256), lds, st, g);
+    if (g.pool) LD_LAUNCH((gn_apply_kernel<T, false, true>), grid, dim3(256), lds, st, g);
+    else LD_LAUNCH((gn_apply_kernel<T, false, false>), grid, dim3(256), lds, st, g);
   }
   LD_LAUNCH_CHECK("gn_apply");
   return LD_OK;

@@ -353,9 +353,9 @@ extern "C" int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const floa
   LD_REQUIRE(!(perm && dtype != LD_BF16), "ld_linattn_ctxfold: perm=1 is the bf16 chained-operand order");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(ctxfold_kernel<float>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (float*)w_packed, C, heads, perm);
+    LD_LAUNCH(ctxfold_kernel<float>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (float*)w_packed, C, heads, perm);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(ctxfold_kernel<bf16>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (bf16*)w_packed, C, heads, perm);
+    LD_LAUNCH(ctxfold_kernel<bf16>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (bf16*)w_packed, C, heads, perm);
   else
     return ld_fail(LD_EINVAL, "ld_linattn_ctxfold: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("linattn_ctxfold");
@@ -378,11 +378,11 @@ extern "C" int ld_linattn_kmax(const void* qkv, uint32_t* kmax_enc, int B, int n
   if (dtype == LD_F32) {
     const int rows = 256 / (hidden / 4);
     LD_REQUIRE(rows >= 1, "ld_linattn_kmax: hidden %d too large", hidden);
-    hipLaunchKernelGGL(kmax_kernel<float>, grid, dim3(256), rows * hidden * sizeof(float), st,
+    LD_LAUNCH(kmax_kernel<float>, grid, dim3(256), rows * hidden * sizeof(float), st,
                        (const float*)qkv, kmax_enc, n, hidden, nparts);
   } else if (dtype == LD_BF16) {
     const int rows = 256 / (hidden / 8);
-    hipLaunchKernelGGL(kmax_kernel<bf16>, grid, dim3(256), rows * hidden * sizeof(float), st,
+    LD_LAUNCH(kmax_kernel<bf16>, grid, dim3(256), rows * hidden * sizeof(float), st,
                        (const bf16*)qkv, kmax_enc, n, hidden, nparts);
   } else {
     return ld_fail(LD_EINVAL, "ld_linattn_kmax: bad dtype %d", dtype);
@@ -398,9 +398,9 @@ extern "C" int ld_linattn_ctx(const void* qkv, const uint32_t* kmax_enc, float* 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   dim3 grid(nchunks, heads, B);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(ctx_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, kmax_enc, ctx_part, n, heads, nchunks);
+    LD_LAUNCH(ctx_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, kmax_enc, ctx_part, n, heads, nchunks);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(ctx_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, kmax_enc, ctx_part, n, heads, nchunks);
+    LD_LAUNCH(ctx_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, kmax_enc, ctx_part, n, heads, nchunks);
   else
     return ld_fail(LD_EINVAL, "ld_linattn_ctx: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("linattn_ctx");
@@ -411,7 +411,7 @@ extern "C" int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* 
                                      int dim_head, void* stream) {
   LD_REQUIRE(ctx_part && ctxn && B > 0 && nchunks > 0 && nchunks <= MAXCH && heads > 0, "ld_linattn_ctx_reduce: bad args (nchunks 1..128)");
   LD_REQUIRE(dim_head == 32, "ld_linattn_*: dim_head must be 32 (got %d)", dim_head);
-  hipLaunchKernelGGL(ctx_reduce_kernel, dim3(heads, B, 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  LD_LAUNCH(ctx_reduce_kernel, dim3(heads, B, 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      ctx_part, nchunks, ctxn, heads);
   LD_LAUNCH_CHECK("linattn_ctx_reduce");
   return LD_OK;
@@ -425,9 +425,9 @@ extern "C" int ld_linattn_fold(const float* ctxn, const float* w_out, void* w_pa
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds = (size_t)heads * 32 * 33 * sizeof(float);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(fold_kernel<float>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (float*)w_packed, C, heads, perm);
+    LD_LAUNCH(fold_kernel<float>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (float*)w_packed, C, heads, perm);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(fold_kernel<bf16>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (bf16*)w_packed, C, heads, perm);
+    LD_LAUNCH(fold_kernel<bf16>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (bf16*)w_packed, C, heads, perm);
   else
     return ld_fail(LD_EINVAL, "ld_linattn_fold: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("linattn_fold");

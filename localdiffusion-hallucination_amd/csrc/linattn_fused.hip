@@ -571,19 +571,19 @@ extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const flo
     static bool ok2[5] = {false, false, false, false, false};
     dim3 grid2(nchunks, B);
     if (nch == 1) {
-      if (kshift) hipLaunchKernelGGL((kvctx_wph_kernel<1, true>), grid2, dim3(256), lds2, st, a);
-      else hipLaunchKernelGGL((kvctx_wph_kernel<1, false>), grid2, dim3(256), lds2, st, a);
+      if (kshift) LD_LAUNCH((kvctx_wph_kernel<1, true>), grid2, dim3(256), lds2, st, a);
+      else LD_LAUNCH((kvctx_wph_kernel<1, false>), grid2, dim3(256), lds2, st, a);
     } else if (nch == 2) {
-      if (kshift) hipLaunchKernelGGL((kvctx_wph_kernel<2, true>), grid2, dim3(256), lds2, st, a);
-      else hipLaunchKernelGGL((kvctx_wph_kernel<2, false>), grid2, dim3(256), lds2, st, a);
+      if (kshift) LD_LAUNCH((kvctx_wph_kernel<2, true>), grid2, dim3(256), lds2, st, a);
+      else LD_LAUNCH((kvctx_wph_kernel<2, false>), grid2, dim3(256), lds2, st, a);
     } else {
       if (!ok2[4]) {
         LD_HIP(ld_allow_lds((kvctx_wph_kernel<4, true>), lds2));
         LD_HIP(ld_allow_lds((kvctx_wph_kernel<4, false>), lds2));
         ok2[4] = true;
       }
-      if (kshift) hipLaunchKernelGGL((kvctx_wph_kernel<4, true>), grid2, dim3(256), lds2, st, a);
-      else hipLaunchKernelGGL((kvctx_wph_kernel<4, false>), grid2, dim3(256), lds2, st, a);
+      if (kshift) LD_LAUNCH((kvctx_wph_kernel<4, true>), grid2, dim3(256), lds2, st, a);
+      else LD_LAUNCH((kvctx_wph_kernel<4, false>), grid2, dim3(256), lds2, st, a);
     }
     LD_LAUNCH_CHECK("linattn_kvctx(wave-per-head)");
     return LD_OK;
@@ -592,13 +592,13 @@ extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const flo
   const size_t lds = (size_t)nch * 4 * KTN * 16 + 2 * KTN * PROW + KTN * sizeof(float) + 128 * sizeof(float);
   static bool allowed[5] = {false, false, false, false, false};
   if (nch == 1) {
-    hipLaunchKernelGGL(kvctx_kernel<1>, grid, dim3(256), lds, st, a);
+    LD_LAUNCH(kvctx_kernel<1>, grid, dim3(256), lds, st, a);
   } else if (nch == 2) {
     if (!allowed[2]) { LD_HIP(ld_allow_lds(kvctx_kernel<2>, lds)); allowed[2] = true; }
-    hipLaunchKernelGGL(kvctx_kernel<2>, grid, dim3(256), lds, st, a);
+    LD_LAUNCH(kvctx_kernel<2>, grid, dim3(256), lds, st, a);
   } else {
     if (!allowed[4]) { LD_HIP(ld_allow_lds(kvctx_kernel<4>, lds)); allowed[4] = true; }
-    hipLaunchKernelGGL(kvctx_kernel<4>, grid, dim3(256), lds, st, a);
+    LD_LAUNCH(kvctx_kernel<4>, grid, dim3(256), lds, st, a);
   }
   LD_LAUNCH_CHECK("linattn_kvctx");
   return LD_OK;
@@ -617,12 +617,12 @@ extern "C" int ld_linattn_out(const void* x, const void* wq_packed, const float*
   const size_t lds = (size_t)nch * 4 * 128 * 16 + (size_t)nch * 8 * 1024 + (size_t)4 * 2 * nch * 1024 + 128 * sizeof(float);
   static bool allowed[5] = {false, false, false, false, false};
   if (nch == 1) {
-    hipLaunchKernelGGL(linout_kernel<1>, grid, dim3(256), lds, st, a);
+    LD_LAUNCH(linout_kernel<1>, grid, dim3(256), lds, st, a);
   } else if (nch == 2) {
-    hipLaunchKernelGGL(linout_kernel<2>, grid, dim3(256), lds, st, a);
+    LD_LAUNCH(linout_kernel<2>, grid, dim3(256), lds, st, a);
   } else {
     if (!allowed[4]) { LD_HIP(ld_allow_lds(linout_kernel<4>, lds)); allowed[4] = true; }
-    hipLaunchKernelGGL(linout_kernel<4>, grid, dim3(256), lds, st, a);
+    LD_LAUNCH(linout_kernel<4>, grid, dim3(256), lds, st, a);
   }
   LD_LAUNCH_CHECK("linattn_out");
   return LD_OK;

@@ -46,9 +46,9 @@ extern "C" int ld_pack_conv_weight(const float* w, const float* scale_in, void* 
   const unsigned grid = (unsigned)((total + bs - 1) / bs);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(bs), 0, st, w, scale_in, (float*)out, cout, cin, ksize, unshuffle);
+    LD_LAUNCH(pack_kernel<float>, dim3(grid), dim3(bs), 0, st, w, scale_in, (float*)out, cout, cin, ksize, unshuffle);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(pack_kernel<bf16>, dim3(grid), dim3(bs), 0, st, w, scale_in, (bf16*)out, cout, cin, ksize, unshuffle);
+    LD_LAUNCH(pack_kernel<bf16>, dim3(grid), dim3(bs), 0, st, w, scale_in, (bf16*)out, cout, cin, ksize, unshuffle);
   else
     return ld_fail(LD_EINVAL, "ld_pack_conv_weight: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("pack_conv_weight");

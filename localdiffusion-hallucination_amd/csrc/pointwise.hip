@@ -230,7 +230,7 @@ __global__ void final_step_kernel(const T* __restrict__ x, const float* __restri
 extern "C" int ld_randn_at(float* out, int64_t n, int64_t first, uint64_t seed, int64_t stream_base,
                            int64_t stream_tmul, const int32_t* t_ptr, void* stream) {
   LD_REQUIRE(out && n > 0 && first >= 0, "ld_randn: bad args");
-  hipLaunchKernelGGL(randn_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), out, (long)n, (long)first,
+  LD_LAUNCH(randn_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), out, (long)n, (long)first,
                      (unsigned long long)seed, (long)stream_base, (long)stream_tmul, t_ptr);
   LD_LAUNCH_CHECK("randn");
   return LD_OK;
@@ -241,7 +241,7 @@ extern "C" int ld_randn(float* out, int64_t n, uint64_t seed, int64_t stream_bas
 }
 extern "C" int ld_step_add(int32_t* t_ptr, int delta, void* stream) {
   LD_REQUIRE(t_ptr, "ld_step_add: null");
-  hipLaunchKernelGGL(step_add_kernel, dim3(1), dim3(64), 0, ST(stream), t_ptr, delta);
+  LD_LAUNCH(step_add_kernel, dim3(1), dim3(64), 0, ST(stream), t_ptr, delta);
   LD_LAUNCH_CHECK("step_add");
   return LD_OK;
 }
@@ -250,7 +250,7 @@ extern "C" int ld_ddpm_step(const float* x_t, const float* model_out, const floa
                             int objective, int64_t n, void* stream) {
   LD_REQUIRE(x_t && model_out && x_prev && sched && n > 0, "ld_ddpm_step: null pointer");
   LD_REQUIRE(objective >= 0 && objective <= 2, "ld_ddpm_step: objective %d", objective);
-  hipLaunchKernelGGL(ddpm_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, model_out, noise, x_prev,
+  LD_LAUNCH(ddpm_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, model_out, noise, x_prev,
                      x0_out, sched, t_ptr, lo, hi, objective, (long)n);
   LD_LAUNCH_CHECK("ddpm_step");
   return LD_OK;
@@ -258,7 +258,7 @@ extern "C" int ld_ddpm_step(const float* x_t, const float* model_out, const floa
 extern "C" int ld_posterior_step(const float* x_t, const float* x0, const float* noise, float* x_prev,
                                  const float* sched, const int32_t* t_ptr, int64_t n, void* stream) {
   LD_REQUIRE(x_t && x0 && x_prev && sched && n > 0, "ld_posterior_step: null pointer");
-  hipLaunchKernelGGL(posterior_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, x0, noise, x_prev,
+  LD_LAUNCH(posterior_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, x0, noise, x_prev,
                      sched, t_ptr, (long)n);
   LD_LAUNCH_CHECK("posterior_step");
   return LD_OK;
@@ -269,7 +269,7 @@ extern "C" int ld_ddim_step(const float* x_t, const float* model_out, const floa
                             int last, int64_t n, void* stream) {
   LD_REQUIRE(x_t && model_out && x_next && n > 0, "ld_ddim_step: null pointer");
   DdimK k{sqrt_recip, sqrt_recipm1, sqrt_ab, sqrt_1mab, sqrt_abar_next, c, sigma, lo, hi, objective, last};
-  hipLaunchKernelGGL(ddim_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, model_out, noise, x_next, k, (long)n);
+  LD_LAUNCH(ddim_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, model_out, noise, x_next, k, (long)n);
   LD_LAUNCH_CHECK("ddim_step");
   return LD_OK;
 }
@@ -277,14 +277,14 @@ extern "C" int ld_branch_conditions(const float* cond, const float* mask, float*
                                     float lo_clip, int B, int C, int HW, void* stream) {
   LD_REQUIRE(cond && mask && cond_out && cond_in, "ld_branch_conditions: null pointer");
   const long n = (long)B * C * HW;
-  hipLaunchKernelGGL(branch_cond_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), cond, mask, cond_out, cond_in, lo_clip, C, HW, n);
+  LD_LAUNCH(branch_cond_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), cond, mask, cond_out, cond_in, lo_clip, C, HW, n);
   LD_LAUNCH_CHECK("branch_conditions");
   return LD_OK;
 }
 extern "C" int ld_mask_out(float* model_out, const float* mask, float min_val, int B, int C, int HW, void* stream) {
   LD_REQUIRE(model_out && mask, "ld_mask_out: null pointer");
   const long n = (long)B * C * HW;
-  hipLaunchKernelGGL(mask_out_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), model_out, mask, min_val, C, HW, n);
+  LD_LAUNCH(mask_out_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), model_out, mask, min_val, C, HW, n);
   LD_LAUNCH_CHECK("mask_out");
   return LD_OK;
 }
@@ -293,7 +293,7 @@ extern "C" int ld_fuse_ddpm(const float* x_out, const float* x_in, const float* 
                             void* stream) {
   LD_REQUIRE(x_out && x_in && x0_out && x0_in && mask && x && x0, "ld_fuse_ddpm: null pointer");
   const long n = (long)B * C * HW;
-  hipLaunchKernelGGL(fuse_ddpm_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_out, x_in, x0_out, x0_in, mask, x, x0, lo, hi, C, HW, n);
+  LD_LAUNCH(fuse_ddpm_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_out, x_in, x0_out, x0_in, mask, x, x0, lo, hi, C, HW, n);
   LD_LAUNCH_CHECK("fuse_ddpm");
   return LD_OK;
 }
@@ -304,14 +304,14 @@ extern "C" int ld_fuse_ddim(const float* x_out, const float* x_in, const float* 
   LD_REQUIRE(x_out && x_in && x0_out && x0_in && mask && x_next, "ld_fuse_ddim: null pointer");
   const long n = (long)B * C * HW;
   FuseDdimK k{sqrt_recip, sqrt_recipm1, sqrt_abar_next, c, sigma, lo, hi};
-  hipLaunchKernelGGL(fuse_ddim_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_out, x_in, x0_out, x0_in, mask, noise, x_next, k, C, HW, n);
+  LD_LAUNCH(fuse_ddim_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_out, x_in, x0_out, x0_in, mask, noise, x_next, k, C, HW, n);
   LD_LAUNCH_CHECK("fuse_ddim");
   return LD_OK;
 }
 extern "C" int ld_q_sample(const float* x0, const float* noise, float* out, float sqrt_ab, float sqrt_1mab,
                            int64_t n, void* stream) {
   LD_REQUIRE(x0 && noise && out && n > 0, "ld_q_sample: null pointer");
-  hipLaunchKernelGGL(q_sample_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x0, noise, out, sqrt_ab, sqrt_1mab, (long)n);
+  LD_LAUNCH(q_sample_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x0, noise, out, sqrt_ab, sqrt_1mab, (long)n);
   LD_LAUNCH_CHECK("q_sample");
   return LD_OK;
 }
@@ -319,7 +319,7 @@ extern "C" int ld_recompose(const float* patches, const float* masks, float* out
                             void* stream) {
   LD_REQUIRE(patches && masks && out && K > 0, "ld_recompose: bad args");
   const long n = (long)B * C * HW;
-  hipLaunchKernelGGL(recompose_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), patches, masks, out, K, C, HW, n);
+  LD_LAUNCH(recompose_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), patches, masks, out, K, C, HW, n);
   LD_LAUNCH_CHECK("recompose");
   return LD_OK;
 }
@@ -329,9 +329,9 @@ extern "C" int ld_final_conv(const void* x, const float* w, const float* b, floa
   LD_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 8 == 0, "ld_final_conv: Cout %d (1..4), Cin %d (multiple of 8)", Cout, Cin);
   const long npix = (long)B * H * W;
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(final_conv_kernel<float>, dim3(nblocks(npix)), dim3(BS), Cin * Cout * sizeof(float), ST(stream), (const float*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
+    LD_LAUNCH(final_conv_kernel<float>, dim3(nblocks(npix)), dim3(BS), Cin * Cout * sizeof(float), ST(stream), (const float*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
   else if (dtype == LD_BF16)
-    hipLaunchKernelGGL(final_conv_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), Cin * Cout * sizeof(float), ST(stream), (const bf16*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
+    LD_LAUNCH(final_conv_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), Cin * Cout * sizeof(float), ST(stream), (const bf16*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
   else
     return ld_fail(LD_EINVAL, "ld_final_conv: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("final_conv");
@@ -351,11 +351,11 @@ extern "C" int ld_final_step_at(const void* x, const float* w, const float* b, f
   const long npix = (long)B * H * W;
   const size_t lds = (size_t)Cin * Cout * sizeof(float);
   if (dtype == LD_F32)
-    hipLaunchKernelGGL(final_step_kernel<float>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const float*)x, w, b, model_out,
+    LD_LAUNCH(final_step_kernel<float>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const float*)x, w, b, model_out,
                        x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_base, (long)noise_tmul,
                        (long)noise_first, H * W, Cin, Cout, npix);
   else
-    hipLaunchKernelGGL(final_step_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const bf16*)x, w, b, model_out,
+    LD_LAUNCH(final_step_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const bf16*)x, w, b, model_out,
                        x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_base, (long)noise_tmul,
                        (long)noise_first, H * W, Cin, Cout, npix);
   LD_LAUNCH_CHECK("final_step");

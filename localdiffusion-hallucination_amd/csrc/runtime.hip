@@ -71,6 +71,44 @@ extern "C" int ld_event_destroy(void* ev) {
   return LD_OK;
 }
 
+// ---- per-launch timing session (bench.py's per-kernel leg) --------------------------------------------------
+namespace {
+hipEvent_t* g_tev = nullptr;      // 2 events per launch
+int g_tcap = 0, g_tn = -1;        // g_tn < 0: no session
+}
+bool ld_timing_next(hipEvent_t* start, hipEvent_t* stop) {
+  if (g_tn < 0 || g_tn >= g_tcap) return false;
+  *start = g_tev[2 * g_tn];
+  *stop = g_tev[2 * g_tn + 1];
+  ++g_tn;
+  return true;
+}
+extern "C" int ld_timing_begin(int max_launches) {
+  LD_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), "ld_timing_begin: max_launches %d", max_launches);
+  if (max_launches > g_tcap) {
+    hipEvent_t* ev = new hipEvent_t[2 * (size_t)max_launches];
+    for (int i = 0; i < 2 * g_tcap; ++i) ev[i] = g_tev[i];
+    for (int i = 2 * g_tcap; i < 2 * max_launches; ++i) LD_HIP(hipEventCreate(&ev[i]));
+    delete[] g_tev;
+    g_tev = ev;
+    g_tcap = max_launches;
+  }
+  g_tn = 0;
+  return LD_OK;
+}
+extern "C" int ld_timing_count(void) { return g_tn < 0 ? 0 : g_tn; }
+extern "C" int ld_timing_end(float* ms, int cap, int* count) {
+  LD_REQUIRE(g_tn >= 0, "ld_timing_end: no session");
+  const int n = g_tn;
+  g_tn = -1;
+  if (count) *count = n;
+  for (int i = 0; i < n && i < cap && ms; ++i) {
+    LD_HIP(hipEventSynchronize(g_tev[2 * i + 1]));
+    LD_HIP(hipEventElapsedTime(&ms[i], g_tev[2 * i], g_tev[2 * i + 1]));
+  }
+  return LD_OK;
+}
+
 extern "C" int ld_memset_zero(void* ptr, size_t bytes, void* stream) {
   LD_REQUIRE(ptr || bytes == 0, "ld_memset_zero: null");
   if (bytes) LD_HIP(hipMemsetAsync(ptr, 0, bytes, reinterpret_cast<hipStream_t>(stream)));

@@ -56,7 +56,7 @@ extern "C" int ld_time_mlp(const int32_t* times, int n, const float* freqs, int 
                            void* stream) {
   LD_REQUIRE(times && freqs && w1 && b1 && w2 && b2 && temb && n > 0, "ld_time_mlp: bad args");
   LD_REQUIRE(dim % 2 == 0 && dim / 2 <= 128, "ld_time_mlp: dim %d", dim);
-  hipLaunchKernelGGL(time_mlp_kernel, dim3(n), dim3(128), (dim + time_dim) * sizeof(float),
+  LD_LAUNCH(time_mlp_kernel, dim3(n), dim3(128), (dim + time_dim) * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), times, freqs, dim, w1, b1, w2, b2, time_dim, temb);
   LD_LAUNCH_CHECK("time_mlp");
   return LD_OK;
@@ -65,7 +65,7 @@ extern "C" int ld_time_mlp(const int32_t* times, int n, const float* freqs, int 
 extern "C" int ld_film(const float* temb, int n, int time_dim, const float* w, const float* b, int two_c,
                        float* film, void* stream) {
   LD_REQUIRE(temb && w && b && film && n > 0, "ld_film: bad args");
-  hipLaunchKernelGGL(film_kernel, dim3(n), dim3(128), time_dim * sizeof(float),
+  LD_LAUNCH(film_kernel, dim3(n), dim3(128), time_dim * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), temb, time_dim, w, b, two_c, film);
   LD_LAUNCH_CHECK("film");
   return LD_OK;

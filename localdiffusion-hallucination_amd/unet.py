@@ -709,28 +709,27 @@ class _Plan:
             op(st)
 
     def run_main_timed(self, st, acc):
-        """Like run_main, but brackets every op with HIP events on ``st`` and adds the elapsed time
-        to ``acc[index] = [ms_total, launches]`` (bench.py's per-kernel roofline leg)."""
+        """Like run_main, inside a per-launch timing session of the library (ld_timing_*: every kernel launch carries
+        its own start/stop events, so the times are kernel execution times as rocprofv3 reports them); adds each
+        op's kernel time to ``acc[index] = [ms_total, launches]`` (bench.py's per-kernel roofline leg)."""
         lib = self.lib
         s = self.stats[self.cond_slots:]
         cabi.check(lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
         cabi.check(lib.ld_memset_zero(self.kmax_arena.data_ptr(), self.kmax_arena.numel() * 4, st), "memset")
-        if not hasattr(self, "_events"):
-            self._events = []
-            for _ in range(len(self.ops_main) + 1):
-                e = C.c_void_p()
-                cabi.check(lib.ld_event_create(C.byref(e)), "event_create")
-                self._events.append(e)
-        ev = self._events
-        cabi.check(lib.ld_event_record(ev[0], st), "event_record")
-        for i, op in enumerate(self.ops_main):
-            op(st)
-            cabi.check(lib.ld_event_record(ev[i + 1], st), "event_record")
-        ms = C.c_float()
+        cabi.check(lib.ld_timing_begin(8 * len(self.ops_main)), "timing_begin")
+        marks = [0]
+        try:
+            for op in self.ops_main:
+                op(st)
+                marks.append(lib.ld_timing_count())
+        finally:
+            n = max(1, lib.ld_timing_count())
+            ms, cnt = (C.c_float * n)(), C.c_int()
+            rc = lib.ld_timing_end(ms, n, C.byref(cnt))
+        cabi.check(rc, "timing_end")
         for i in range(len(self.ops_main)):
-            cabi.check(lib.ld_event_elapsed_ms(ev[i], ev[i + 1], C.byref(ms)), "event_elapsed")
             a = acc.setdefault(i, [0.0, 0])
-            a[0] += ms.value
+            a[0] += sum(ms[marks[i]:marks[i + 1]])
             a[1] += 1
 
     def set_step(self, t):
