@@ -312,6 +312,43 @@ def test_randn_matches_host_stream():
     assert float((out.cpu() - torch.from_numpy(rng.randn((n,), 10, 93))).abs().max()) < 2e-5
 
 
+def test_randn_at_is_a_slice_of_the_draw():
+    """ld_randn_at(first, n) == ld_randn[first : first + n] bit for bit (sub-batches draw their part of a batch's noise)."""
+    n, first, m = 1 << 14, 5000, 3000
+    full, part = torch.empty(n, device=hh.DEV), torch.empty(m, device=hh.DEV)
+    tdev = torch.tensor([7], dtype=torch.int32, device=hh.DEV)
+    cabi.check(cabi.lib().ld_randn(full.data_ptr(), n, 10, 100, -1, tdev.data_ptr(), hh.st()), "randn")
+    cabi.check(cabi.lib().ld_randn_at(part.data_ptr(), m, first, 10, 100, -1, tdev.data_ptr(), hh.st()), "randn_at")
+    assert torch.equal(part, full[first:first + m])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_final_step_at_matches_the_batch_call(dtype):
+    """Two ld_final_step_at calls on the halves of a batch (noise index from the device step counter, element
+    offset of the half) == one ld_final_step on the whole batch, bit for bit; t == 0 adds no noise."""
+    B, cin, cout, H, W, T = 4, 32, 3, 16, 16, 20
+    lib = cabi.lib()
+    x = hh.nhwc(_q(hh.rand((B, cin, H, W), 110), dtype), dtype)
+    w, b = hh.rand((cout, cin), 111, -0.3, 0.3).to(hh.DEV), hh.rand((cout,), 112).to(hh.DEV)
+    sched = hh.rand((T, 8), 113, 0.1, 0.9).to(hh.DEV)
+    xt = hh.rand((B, cout, H, W), 114, -1, 1).to(hh.DEV)
+    for t, base in ((7, 13 + 7), (0, 20)):
+        tdev = torch.tensor([t], dtype=torch.int32, device=hh.DEV)
+        mo1, x1, x01 = torch.empty_like(xt), xt.clone(), torch.empty_like(xt)
+        cabi.check(lib.ld_final_step(x.data_ptr(), w.data_ptr(), b.data_ptr(), mo1.data_ptr(), x1.data_ptr(), x01.data_ptr(),
+                                     sched.data_ptr(), tdev.data_ptr(), 0.0, 2.0, 0, 10, base - t if t > 0 else 0,
+                                     B, H, W, cin, cout, cabi.dtype_code(dtype), hh.st()), "final_step")
+        mo2, x2, x02 = torch.empty_like(xt), xt.clone(), torch.empty_like(xt)
+        h = B // 2
+        for i in range(2):
+            cabi.check(lib.ld_final_step_at(x[i * h:].data_ptr(), w.data_ptr(), b.data_ptr(), mo2[i * h:].data_ptr(),
+                                            x2[i * h:].data_ptr(), x02[i * h:].data_ptr(), sched.data_ptr(), tdev.data_ptr(),
+                                            0.0, 2.0, 0, 10, base, -1, i * h * cout * H * W,
+                                            h, H, W, cin, cout, cabi.dtype_code(dtype), hh.st()), "final_step_at")
+        assert torch.equal(mo1, mo2) and torch.equal(x1, x2) and torch.equal(x01, x02)
+        assert bool(torch.isfinite(x1).all())
+
+
 @pytest.mark.parametrize("objective", ["pred_x0", "pred_noise", "pred_v"])
 def test_ddpm_step(objective):
     T, shape = 50, (2, 3, 8, 8)
