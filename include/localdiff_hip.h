@@ -270,11 +270,13 @@ int ld_final_step(const void* x, const float* w, const float* b, float* model_ou
 
 /* ld_final_step for a sub-batch inside a replayed HIP graph: the noise stream index is
  * noise_base + noise_tmul * (*t_ptr) (the sampler's draw counter as a function of the device step counter) and
- * the sub-batch's elements are [noise_first, noise_first + B*Cout*H*W) of that stream's sequence. */
+ * the sub-batch's elements are [noise_first, noise_first + B*Cout*H*W) of that stream's sequence.
+ * keep_mask (optional, [B, H*W]): ld_mask_out folded in -- where keep_mask < 1 the prediction is replaced by `lo`
+ * before the update (the OOD branch with mask_x, ddpm.py:693-696). */
 int ld_final_step_at(const void* x, const float* w, const float* b, float* model_out, float* x_t, float* x0_out,
                      const float* sched, const int32_t* t_ptr, float lo, float hi, int objective, uint64_t seed,
-                     int64_t noise_base, int64_t noise_tmul, int64_t noise_first, int B, int H, int W, int Cin,
-                     int Cout, int dtype, void* stream);
+                     int64_t noise_base, int64_t noise_tmul, int64_t noise_first, const float* keep_mask,
+                     int B, int H, int W, int Cin, int Cout, int dtype, void* stream);
 
 /* ---- reverse-process pointwise kernels (NCHW fp32) ---------------------------------------- */
 #define LD_OBJ_X0 0

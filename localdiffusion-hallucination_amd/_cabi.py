@@ -82,8 +82,8 @@ _SIGS = {
     "ld_final_conv": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_final_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, u64, i64, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, vp]),
-    "ld_final_step_at": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, u64, i64, i64, i64, C.c_int, C.c_int,
-                                   C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_final_step_at": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, u64, i64, i64, i64, vp, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_timing_begin": (C.c_int, [C.c_int]),
     "ld_timing_count": (C.c_int, []),
     "ld_timing_end": (C.c_int, [vp, C.c_int, vp]),

@@ -191,7 +191,7 @@ __global__ void final_step_kernel(const T* __restrict__ x, const float* __restri
                                   float* __restrict__ model_out, float* __restrict__ x_t, float* __restrict__ x0o,
                                   const float* __restrict__ sched, const int* __restrict__ t_ptr, float lo, float hi,
                                   int obj, unsigned long long seed, long stream_base, long stream_tmul, long first,
-                                  int HW, int Cin, int Cout, long npix) {
+                                  const float* __restrict__ keep_mask, int HW, int Cin, int Cout, long npix) {
   extern __shared__ float s_fw[];
   for (int i = threadIdx.x; i < Cin * Cout; i += BS) s_fw[i] = w[i];
   const int t = t_ptr ? *t_ptr : 0;
@@ -204,9 +204,11 @@ __global__ void final_step_kernel(const T* __restrict__ x, const float* __restri
     const long b = i / HW, p = i - b * HW;
     float acc[4];
     final_conv_pixel<T>(x + (size_t)i * Cin, s_fw, Cin, Cout, acc);
+    // ld_mask_out folded in: outside the mask the prediction is replaced by the range minimum (ddpm.py:693-696)
+    const bool keep = keep_mask ? keep_mask[i] >= 1.0f : true;
     for (int o = 0; o < Cout; ++o) {
       const size_t idx = ((size_t)b * Cout + o) * HW + p;
-      const float mo = acc[o] + bias[o];
+      const float mo = keep ? acc[o] + bias[o] : lo;
       model_out[idx] = mo;
       const float xi = x_t[idx];
       const float x0 = clampf(to_x0(xi, mo, row, obj), lo, hi);
@@ -341,7 +343,8 @@ extern "C" int ld_final_conv(const void* x, const float* w, const float* b, floa
 extern "C" int ld_final_step_at(const void* x, const float* w, const float* b, float* model_out, float* x_t,
                                 float* x0_out, const float* sched, const int32_t* t_ptr, float lo, float hi,
                                 int objective, uint64_t seed, int64_t noise_base, int64_t noise_tmul,
-                                int64_t noise_first, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+                                int64_t noise_first, const float* keep_mask, int B, int H, int W, int Cin, int Cout,
+                                int dtype, void* stream) {
   LD_REQUIRE(x && w && b && model_out && x_t && sched, "ld_final_step: null pointer");
   LD_REQUIRE(noise_first >= 0 && (noise_tmul == 0 || t_ptr), "ld_final_step: noise_first %ld, noise_tmul without t_ptr",
              (long)noise_first);
@@ -353,11 +356,11 @@ extern "C" int ld_final_step_at(const void* x, const float* w, const float* b, f
   if (dtype == LD_F32)
     LD_LAUNCH(final_step_kernel<float>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const float*)x, w, b, model_out,
                        x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_base, (long)noise_tmul,
-                       (long)noise_first, H * W, Cin, Cout, npix);
+                       (long)noise_first, keep_mask, H * W, Cin, Cout, npix);
   else
     LD_LAUNCH(final_step_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const bf16*)x, w, b, model_out,
                        x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_base, (long)noise_tmul,
-                       (long)noise_first, H * W, Cin, Cout, npix);
+                       (long)noise_first, keep_mask, H * W, Cin, Cout, npix);
   LD_LAUNCH_CHECK("final_step");
   return LD_OK;
 }
@@ -365,5 +368,5 @@ extern "C" int ld_final_step(const void* x, const float* w, const float* b, floa
                              const float* sched, const int32_t* t_ptr, float lo, float hi, int objective, uint64_t seed,
                              int64_t noise_stream, int B, int H, int W, int Cin, int Cout, int dtype, void* stream) {
   return ld_final_step_at(x, w, b, model_out, x_t, x0_out, sched, t_ptr, lo, hi, objective, seed, noise_stream, 0, 0,
-                          B, H, W, Cin, Cout, dtype, stream);
+                          nullptr, B, H, W, Cin, Cout, dtype, stream);
 }

@@ -42,14 +42,25 @@ class _SubBatches:
     noise stream (ld_final_step_at), so the samples are those of the unsplit batch up to the tiling-dependent
     summation order of the kernels.  x_t is scattered from / gathered back into the parent plan's ``x_in``."""
 
-    def __init__(self, gd, jp, S):
+    def __init__(self, gd, jp, S, shared_noise=False, masked=(), instance_base=0):
+        """``shared_noise``: every sub-batch uses the SAME draw (the OOD and IND branch of the branch phase,
+        ddpm.py:852-858) instead of its slice of one draw.  ``masked``: sub-batches whose prediction is replaced
+        by the range minimum outside a mask (``set_mask``), i.e. ld_mask_out folded into their final step."""
         self.gd, self.jp, self.S = gd, jp, S
         B, _, H, W = jp.x_in.shape
         self.b = B // S
-        self.plans = [gd.model.plan(self.b, H, W, table_T=gd.num_timesteps_ori, instance=i + 1) for i in range(S)]
-        self.streams = [torch.cuda.Stream() for _ in range(S)]
+        # plans are cached per shape: instances 1..S of this batch size belong to the sub-batch runners
+        self.plans = [gd.model.plan(self.b, H, W, table_T=gd.num_timesteps_ori, instance=instance_base + i + 1)
+                      for i in range(S)]
+        self.streams = gd._sub_streams(S)
+        self.shared_noise = shared_noise
+        self.masks = {i: torch.ones(self.b, H * W, dtype=torch.float32, device=jp.x_in.device) for i in masked}
         self.graphs = {}
         self.cond_seen = None
+
+    def set_mask(self, mask):
+        for m in self.masks.values():
+            m.copy_(mask.reshape(m.shape))
 
     def _step(self, i, st, lo, hi, base):
         gd, sp = self.gd, self.plans[i]
@@ -60,7 +71,8 @@ class _SubBatches:
         cabi.check(lib.ld_final_step_at(xa.data_ptr(), wf.data_ptr(), bf.data_ptr(), sp.model_out.data_ptr(),
                                         sp.x_in.data_ptr(), None, gd._sched_table().data_ptr(), sp.t_dev.data_ptr(),
                                         lo, hi, cabi.OBJ[gd.objective], gd.noise_seed, base, -1,
-                                        i * sp.x_in.numel(), B_, H_, W_, wf.shape[1], C_, sp.dt, st), "final_step")
+                                        0 if self.shared_noise else i * sp.x_in.numel(), cabi.ptr(self.masks.get(i)),
+                                        B_, H_, W_, wf.shape[1], C_, sp.dt, st), "final_step")
         cabi.check(lib.ld_step_add(sp.t_dev.data_ptr(), -1, st), "step_add")
 
     def _ensure_graph(self, i, gs, lo, hi, base):
@@ -143,6 +155,9 @@ class _SubBatches:
                 sp.set_step(t_start - k)
                 sp.run_main_timed(st, acc)
                 cabi.check(lib.ld_randn_at(z.data_ptr(), z.numel(), 0, gd.noise_seed, base, -1, sp.t_dev.data_ptr(), st), "randn")
+                if 0 in self.masks:
+                    cabi.check(lib.ld_mask_out(sp.model_out.data_ptr(), self.masks[0].data_ptr(), lo, sp.x_in.shape[0],
+                                               sp.x_in.shape[1], z.shape[2] * z.shape[3], st), "mask_out")
                 cabi.check(lib.ld_ddpm_step(sp.x_in.data_ptr(), sp.model_out.data_ptr(), z.data_ptr(), sp.x_in.data_ptr(),
                                             None, sched.data_ptr(), sp.t_dev.data_ptr(), lo, hi, obj, z.numel(), st), "ddpm_step")
         for gs in self.streams:
@@ -287,6 +302,15 @@ class GaussianDiffusion(nn.Module):
                                     x0.data_ptr(), row.data_ptr(), None, float(min_max_val[0]),
                                     float(min_max_val[1]), cabi.OBJ[self.objective], x.numel(), st), "ddpm_step")
         return x_prev, x0
+
+    def _sub_streams(self, S):
+        """The S side streams of the sub-batch runners (shared by all of them: HIP maps streams onto a few
+        hardware queues per process, so more streams than needed only make two of them share a queue)."""
+        if not hasattr(self, "_side_streams"):
+            self._side_streams = []
+        while len(self._side_streams) < S:
+            self._side_streams.append(torch.cuda.Stream())
+        return self._side_streams[:S]
 
     def timed_plan(self, jp):
         """The plan whose launches ``run_joint_steps(..., timers=acc)`` times: sub-batch 0 when the joint steps
@@ -469,6 +493,20 @@ class GaussianDiffusion(nn.Module):
             x_in_view.copy_(x_T)
             mo_in = plan.model_out if replaced else plan.model_out[B:]
             mo_out = cond_out if replaced else plan.model_out[:B]
+            # the steps before the fusion time: the OOD and the IND branch as two concurrent sub-batches (same
+            # draw for both, ld_mask_out folded into the OOD branch's final step)
+            n_plain = (t - int(self.config["start_timestep"])) if fuse else t + 1
+            if (not replaced and self.sub_batches > 1 and B >= self.min_sub_batch and self.noise_source == "device"
+                    and not return_all_timesteps and not return_all_outputs and n_plain >= 4
+                    and C == plan.model_out.shape[1] and not self.use_graph):
+                key = (id(plan), "branch", bool(mask_x))
+                if key not in self._subs:
+                    self._subs[key] = _SubBatches(self, plan, 2, shared_noise=True, masked=(0,) if mask_x else (),
+                                                  instance_base=100)
+                if mask_x:
+                    self._subs[key].set_mask(mask)
+                draw = self._subs[key].run(t, n_plain, lo, hi, draw)
+                t -= n_plain
             while t >= 0:
                 plan.set_step(t)
                 plan.run_main(st)

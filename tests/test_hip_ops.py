@@ -343,7 +343,7 @@ def test_final_step_at_matches_the_batch_call(dtype):
         for i in range(2):
             cabi.check(lib.ld_final_step_at(x[i * h:].data_ptr(), w.data_ptr(), b.data_ptr(), mo2[i * h:].data_ptr(),
                                             x2[i * h:].data_ptr(), x02[i * h:].data_ptr(), sched.data_ptr(), tdev.data_ptr(),
-                                            0.0, 2.0, 0, 10, base, -1, i * h * cout * H * W,
+                                            0.0, 2.0, 0, 10, base, -1, i * h * cout * H * W, None,
                                             h, H, W, cin, cout, cabi.dtype_code(dtype), hh.st()), "final_step_at")
         assert torch.equal(mo1, mo2) and torch.equal(x1, x2) and torch.equal(x01, x02)
         assert bool(torch.isfinite(x1).all())

@@ -189,6 +189,28 @@ def test_concurrent_sub_batches_match_the_single_batch(dtype, tol):
     check("4x2 " + dtype, run(gd, cond, None, 8), single, tol)
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+def test_branch_phase_as_concurrent_sub_batches(dtype, tol, fuse):
+    """The branch steps before the fusion time with the OOD and the IND branch as two concurrent sub-batches
+    (one shared draw per step, mask_x folded into the OOD branch's final step) == the batched eager branch loop."""
+    B, H = 4, 32
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 6, 1, 0.0, 2.0))
+    mask = torch.zeros(B, 1, H, H)
+    mask[:, :, :, :H // 4] = 1.0
+    gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=3, mask_x=True),
+              H, 14, dtype=dtype)
+    gd.noise_source = "device"
+    gd.sub_batches = 1
+    single = run(gd, cond, mask, B)
+    gd.sub_batches, gd.min_sub_batch = 2, 4
+    split = run(gd, cond, mask, B)
+    assert any(k[1] == "branch" for k in gd._subs), "the branch phase did not take the sub-batch path"
+    assert single.shape == ((B, 1, H, H) if fuse else (2, B, 1, H, H))
+    check(f"branch sub-batches {dtype} fuse={fuse}", split, single, tol)
+    check(f"branch sub-batches {dtype} fuse={fuse} (replayed)", run(gd, cond, mask, B), single, tol)
+
+
 def test_eval_driver_matches_cfg1_golden(golden, tmp_path):
     """evalio.evaluate (test.py-equivalent loop) on the 4 golden digits == the reference's cfg1 output."""
     from localdiffusion_hallucination_amd import evalio
