@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblocaldiff_hip.so")
+LIB_PATH = os.environ.get("LD_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "liblocaldiff_hip.so")   # override: A/B builds
 
 LD_F32, LD_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2

@@ -41,6 +41,10 @@ struct Conv3Dev {
   int dbg;     // ablation switches (LD_CONV_DEBUG env, 0 in production): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
 
+// LD_CONV_DEBUG=64: cycle stamps of one workgroup from the middle of the launch (tools/trace_conv.py)
+__device__ unsigned long long g_conv_trace[16];
+#define TR_STAMP(k) do { if ((DBG & 64) && tracing) tr_t[k] = __builtin_readcyclecounter(); } while (0)
+
 template <typename T, int MT, int NW, bool DEEP, int DBG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3 : 1, MT == 2 ? 3 : 2))) void conv3x3_kernel(Conv3Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
@@ -61,6 +65,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
   double* s_stat = reinterpret_cast<double*>(s_coef + 2 * ctot);
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
+  unsigned long long tr_t[16] = {0};
+  const bool tracing = (DBG & 64) && tid == 0 && blockIdx.z == gridDim.z / 2 && blockIdx.y == 0 &&
+                       blockIdx.x == (gridDim.x * 5) / 8;
+  TR_STAMP(0);
   const int b = blockIdx.z, m0 = blockIdx.y * MT;
   const int ty0 = (blockIdx.x / a.tiles_x) * TR, tx0 = (blockIdx.x % a.tiles_x) * TC;
   const int H = a.H, W = a.W;
@@ -76,48 +84,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
   // Loop-invariant addressing (with one wave per SIMD every VALU instruction in the chunk loop is on the
   // critical path, PMC: MFMA busy ~20 % of wave cycles): per-thread element offsets of the halo pixels for
   // both source geometries and of the weight units are computed once; a chunk only adds a scalar stride.
+  // Addresses are a workgroup-uniform 64-bit base (scalar registers) plus a non-negative 32-bit per-lane byte
+  // offset built from 24-bit multiplies: the first version spent ~1,500 VALU instructions per wave around 72 MFMAs
+  // (3.5k cycles of 64-bit / quarter-rate integer address arithmetic before the first load), which made the
+  // single-chunk launches instruction-issue-bound (in-kernel trace, tools/trace_conv.py).
   unsigned hvalid = 0;                                  // bit it: halo item `it` is inside the image
-  int hoff0[ITER], hoff1[ITER];
+  unsigned hoffb0[ITER], hoffb1[ITER];                  // byte offsets from sbase0 / sbase1
+  const char* sbase0;
+  const char* sbase1;
   {
-    const SrcDev S0 = a.s[0], S1 = a.s[1];
-    const int Hs0 = S0.ups ? H / 2 : H, Ws0 = S0.ups ? W / 2 : W;
-    const int Hs1 = S1.ups ? H / 2 : H, Ws1 = S1.ups ? W / 2 : W;
+    auto src_base = [&](const SrcDev& S, unsigned (&hoffb)[ITER]) -> const char* {
+      const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
+      const int row0 = S.ups ? (ty0 - 1) >> 1 : ty0 - 1, col0 = S.ups ? (tx0 - 1) >> 1 : tx0 - 1;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int q = (it * 4 + wv) * 16 + px;
+        const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;        // q / 18 for q < 400
+        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
+        const int r = (S.ups ? gy >> 1 : gy) - row0, c = (S.ups ? gx >> 1 : gx) - col0;   // 0 .. HR, 0 .. HC
+        hoffb[it] = (__umul24(__umul24(r, Ws) + c, S.ld) + kq * E) * (unsigned)sizeof(T);
+      }
+      return reinterpret_cast<const char*>(S.data) + (((long)b * Hs + row0) * Ws + col0) * S.ld * (long)sizeof(T);
+    };
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int q = (it * 4 + wv) * 16 + px;
-      hoff0[it] = hoff1[it] = 0;
-      if (q < NPIX) {
-        const int hy = q / HC, hx_ = q - hy * HC;
-        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W && !(DBG & 1)) {
-          hvalid |= 1u << it;
-          hoff0[it] = ((b * Hs0 + (S0.ups ? gy >> 1 : gy)) * Ws0 + (S0.ups ? gx >> 1 : gx)) * S0.ld + kq * E;
-          hoff1[it] = ((b * Hs1 + (S1.ups ? gy >> 1 : gy)) * Ws1 + (S1.ups ? gx >> 1 : gx)) * S1.ld + kq * E;
-        }
-      }
+      const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;
+      const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
+      if (q < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && !(DBG & 1)) hvalid |= 1u << it;
+    }
+    sbase0 = src_base(a.s[0], hoffb0);
+    sbase1 = sbase0;
+    if (a.nsrc > 1) sbase1 = src_base(a.s[1], hoffb1);
+    else {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) hoffb1[it] = hoffb0[it];
     }
   }
-  int woff[WU];
+  unsigned woffb[WU];                                   // byte offsets into a chunk's packed weights; ~0u = none
 #pragma unroll
   for (int k = 0; k < WU; ++k) {
     const int u = k * 256 + tid;
     const int tap = u / (MT * 64), r = u - tap * (MT * 64);
-    woff[k] = (u < UNITS && !(DBG & 2)) ? (tap * mt_total + m0) * 64 + r : -1;
+    woffb[k] = (u < UNITS && !(DBG & 2)) ? (__umul24(tap, mt_total) + m0) * 1024u + r * 16u : ~0u;
   }
-  const int wstride = 9 * mt_total * 64;                // uint4 units per chunk
+  const long wstride = 9L * mt_total * 1024;            // bytes per chunk
   auto issue_loads = [&](int ch, uint4 (&hx)[ITER], uint4 (&wx)[WU]) {
     const int si = ch >= nch0 ? 1 : 0;
-    const T* sdata = reinterpret_cast<const T*>(si ? a.s[1].data : a.s[0].data) + (ch - si * nch0) * CK;
+    const char* sp = (si ? sbase1 : sbase0) + (long)(ch - si * nch0) * CK * (long)sizeof(T);
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       hx[it] = make_uint4(0u, 0u, 0u, 0u);
-      if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sdata + (si ? hoff1[it] : hoff0[it]));
+      if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sp + (si ? hoffb1[it] : hoffb0[it]));
     }
-    const uint4* wc = wg + (size_t)ch * wstride;
+    const char* wc = reinterpret_cast<const char*>(wg) + (long)ch * wstride;
 #pragma unroll
     for (int k = 0; k < WU; ++k) {
       wx[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (woff[k] >= 0) wx[k] = wc[woff[k]];
+      if (woffb[k] != ~0u) wx[k] = *reinterpret_cast<const uint4*>(wc + woffb[k]);
     }
   };
   auto write_lds = [&](int ch, const uint4 (&hx)[ITER], const uint4 (&wx)[WU]) {
@@ -154,7 +178,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
     }
   };
 
+  TR_STAMP(1);
   issue_loads(0, hxA, wxA);
+  TR_STAMP(2);
   float4 bias[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + (m0 + m) * 16 + kq * 4);
@@ -176,6 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
     }
   }
 
+  TR_STAMP(3);
   f32x4 acc[MT][NW];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -219,11 +246,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
   if constexpr (!DEEP) {
     for (int ch = 0; ch < nch; ++ch) {
       __syncthreads();               // previous chunk fully consumed (first time: coefficients visible)
+      if (ch == 0) TR_STAMP(4);
       write_lds(ch, hxA, wxA);
+      if (ch == 0) TR_STAMP(5);
       __syncthreads();
+      if (ch == 0) TR_STAMP(6);
       if (ch + 1 < nch) issue_loads(ch + 1, hxA, wxA);
       compute();
+      if (ch == 0) TR_STAMP(7);
     }
+    TR_STAMP(8);
   } else {
     // prefetch distance 2 with two register sets (the launches that use this variant run one wave per SIMD,
     // so the 512-entry register file is theirs): chunk k+2 is requested before chunk k is computed
@@ -245,8 +277,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
   }
 
   // ---- epilogue: bias, statistics, NHWC store.  lane holds channels 16m+4kq..+3 of pixel px.
-  T* out = reinterpret_cast<T*>(a.out);
   const int gx = tx0 + px;
+  // uniform base of the tile + one 32-bit lane offset; rows and m-tiles add constants
+  const long obase = (((long)b * H + ty0) * W + tx0) * a.Cout + m0 * 16;
+  char* outb = reinterpret_cast<char*>(a.out) + obase * (long)sizeof(T);
+  const char* addb = reinterpret_cast<const char*>(a.addend) + obase * (long)sizeof(T);
+  const unsigned lane_off = (__umul24(__umul24(wv * NW, W) + px, a.Cout) + kq * 4) * (unsigned)sizeof(T);
+  const unsigned row_off = __umul24(W, a.Cout) * (unsigned)sizeof(T);
   float ssum[MT][4], ssq[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -254,26 +291,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
     for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.f;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const int co = (m0 + m) * 16 + kq * 4;
     const float4 bv = bias[m];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int gy = ty0 + wv * NW + j;
       const bool valid = gy < H && gx < W;
+      const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
       float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
       if (valid && a.addend) {
         float ad[4];
-        load4<T>(reinterpret_cast<const T*>(a.addend) + (((size_t)b * H + gy) * W + gx) * a.Cout + co, ad);
+        load4<T>(reinterpret_cast<const T*>(addb + off), ad);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += ad[r];
       }
       if (valid) {
-        if (!(DBG & 8)) store4<T>(out + (((size_t)b * H + gy) * W + gx) * a.Cout + co, v);
+        if (!(DBG & 8)) store4<T>(reinterpret_cast<T*>(outb + off), v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
       }
     }
   }
+  TR_STAMP(9);
   if (a.ostats) {
     __syncthreads();                            // s_stat may still be read as build_gn_coef scratch
 #pragma unroll
@@ -298,6 +336,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
       const int stripe = blockIdx.x % LD_STAT_STRIPES;
       atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + g) * 2 + k], acc1);
     }
+  }
+  if ((DBG & 64) && tracing) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores have left
+    tr_t[10] = __builtin_readcyclecounter();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g_conv_trace[k] = tr_t[k];
   }
 }
 
@@ -335,6 +379,7 @@ int launch(const Conv3Dev& a, hipStream_t st) {
       case 8: return launch_dbg<T, MT, NW, DEEP, 8>(a, st);
       case 12: return launch_dbg<T, MT, NW, DEEP, 12>(a, st);
       case 15: return launch_dbg<T, MT, NW, DEEP, 15>(a, st);
+      case 64: return launch_dbg<T, MT, NW, DEEP, 64>(a, st);
       default: break;
     }
   }
@@ -373,6 +418,13 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
 }
 
 }  // namespace
+
+// Debug hook (not part of the public ABI): cycle stamps of the last LD_CONV_DEBUG=64 launch (16 uint64).
+extern "C" int ld_debug_conv_trace(unsigned long long* host) {
+  LD_HIP(hipDeviceSynchronize());
+  LD_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * 16));
+  return LD_OK;
+}
 
 extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   LD_REQUIRE(p != nullptr, "ld_conv3x3: null args");

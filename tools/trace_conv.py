@@ -1,0 +1,46 @@
+"""GPU box: cycle stamps of one mid-launch workgroup of the generic conv3x3 kernel (LD_CONV_DEBUG=64)."""
+import os, sys, ctypes as C
+os.environ["LD_CONV_DEBUG"] = "64"
+os.environ.setdefault("LD_CONV_NO_C32", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import hip_helpers as hh
+from localdiffusion_hallucination_amd import _cabi as cabi
+
+NAMES = ["start", "setup", "loads issued", "coef built", "barrier0", "lds written (wait+transform)", "barrier1",
+         "mfma chunk0", "all chunks", "stores issued", "stats + stores drained"]
+
+
+def run(B, cin, cout, H, W, dtype="bf16", prologue=False, stats=True):
+    x = torch.randn(B, H, W, cin, device="cuda").to(hh.TDT[dtype])
+    w = hh.pack(torch.randn(cout, cin, 3, 3) * 0.05, dtype, 3)
+    b = torch.zeros(cout, device="cuda")
+    st = hh.stats_buffer(B, 8) if stats else None
+    if prologue:
+        gn = (hh.stats_striped(x.float().permute(0, 3, 1, 2), 8), torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda"), 8)
+        src = hh.make_src(x, cin, gn=gn, act=1)
+    else:
+        src = hh.make_src(x, cin)
+    for _ in range(5):
+        hh.conv3x3([src], w, b, B, H, W, cout, dtype, stats=st)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 16)()
+    fn = cabi.lib().ld_debug_conv_trace
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_ulonglong)]
+    assert fn(buf) == 0
+    t = [buf[k] for k in range(16)]
+    print(f"== {cin}->{cout}@{H}x{W} B{B} prologue={prologue} stats={stats}")
+    prev = t[0]
+    for k, n in enumerate(NAMES):
+        if t[k]:
+            print(f"   {n:32s} +{t[k] - prev:6d}   (at {t[k] - t[0]})")
+            prev = t[k]
+
+
+if __name__ == "__main__":
+    run(8, 32, 32, 256, 256, stats=True)
+    run(8, 32, 32, 256, 256, prologue=True)
+    run(8, 64, 32, 256, 256, stats=True)
+    run(8, 64, 64, 128, 128, prologue=True)
+    run(8, 256, 256, 32, 32, prologue=True)
