@@ -314,27 +314,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
   TR_STAMP(9);
   if (a.ostats) {
     __syncthreads();                            // s_stat may still be read as build_gn_coef scratch
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
-        if (px == 0) {
-          s_stat[(wv * 2 + 0) * 16 * MT + m * 16 + kq * 4 + r] = (double)s1;
-          s_stat[(wv * 2 + 1) * 16 * MT + m * 16 + kq * 4 + r] = (double)s2;
-        }
-      }
-    __syncthreads();
     const int gs = a.Cout / a.ogroups;          // channels per group; gs <= 16*MT by construction
     const int ngrp_blk = (16 * MT) / gs;
-    if (tid < 2 * ngrp_blk) {
-      const int gi = tid >> 1, k = tid & 1;
-      double acc1 = 0.0;
-      for (int w4 = 0; w4 < 4; ++w4)
-        for (int c = 0; c < gs; ++c) acc1 += s_stat[(w4 * 2 + k) * 16 * MT + gi * gs + c];
-      const int g = (m0 * 16) / gs + gi;
-      const int stripe = blockIdx.x % LD_STAT_STRIPES;
-      atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + g) * 2 + k], acc1);
+    const int stripe = blockIdx.x % LD_STAT_STRIPES;
+    if (!P && (gs & 3) == 0) {
+      // a lane's four channels (4kq .. 4kq+3 of m-tile m) always fall into ONE group when gs is a multiple of 4:
+      // add them before the cross-lane reduction -- 4*MT row reductions and LDS values per wave instead of 16*MT
+      // (the statistics were 20 % of a workgroup's cycles, tools/trace_conv.py).  bf16 storage only: the fp32
+      // path keeps its short fp32 partial sums.
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float s1 = wave16_sum((ssum[m][0] + ssum[m][1]) + (ssum[m][2] + ssum[m][3]));
+        const float s2 = wave16_sum((ssq[m][0] + ssq[m][1]) + (ssq[m][2] + ssq[m][3]));
+        if (px == 0) {
+          s_stat[(wv * 2 + 0) * 4 * MT + m * 4 + kq] = (double)s1;
+          s_stat[(wv * 2 + 1) * 4 * MT + m * 4 + kq] = (double)s2;
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * ngrp_blk) {
+        const int gi = tid >> 1, k = tid & 1, q4 = gs >> 2;
+        double acc1 = 0.0;
+        for (int w4 = 0; w4 < 4; ++w4)
+          for (int c = 0; c < q4; ++c) acc1 += s_stat[(w4 * 2 + k) * 4 * MT + gi * q4 + c];
+        const int g = (m0 * 16) / gs + gi;
+        atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + g) * 2 + k], acc1);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
+          if (px == 0) {
+            s_stat[(wv * 2 + 0) * 16 * MT + m * 16 + kq * 4 + r] = (double)s1;
+            s_stat[(wv * 2 + 1) * 16 * MT + m * 16 + kq * 4 + r] = (double)s2;
+          }
+        }
+      __syncthreads();
+      if (tid < 2 * ngrp_blk) {
+        const int gi = tid >> 1, k = tid & 1;
+        double acc1 = 0.0;
+        for (int w4 = 0; w4 < 4; ++w4)
+          for (int c = 0; c < gs; ++c) acc1 += s_stat[(w4 * 2 + k) * 16 * MT + gi * gs + c];
+        const int g = (m0 * 16) / gs + gi;
+        atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + g) * 2 + k], acc1);
+      }
     }
   }
   if ((DBG & 64) && tracing) {
