@@ -253,6 +253,13 @@ __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, 
   __syncthreads();
 }
 
+// RMSNorm's 1 / max(||x||, 1e-12) from the sum of squares (ddpm.py:131, F.normalize): exact IEEE sqrt + divide for fp32
+// storage (parity mode), one v_rsq_f32 for bf16 storage (the pair costs ~25 VALU instructions).
+template <bool PRECISE> __device__ __forceinline__ float rms_rinv(float sumsq) {
+  if (PRECISE) return 1.0f / fmaxf(sqrtf(sumsq), 1e-12f);
+  return __builtin_amdgcn_rsqf(fmaxf(sumsq, 1e-24f));
+}
+
 // DPP row rotate inside each 16-lane row (one VALU op, no LDS crossbar): dpp_ctrl 0x120+n = row_ror:n
 template <int N> __device__ __forceinline__ float row_ror(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
       float r = rs[it];
       r += __shfl_xor(r, 16);
       r += __shfl_xor(r, 32);
-      if (kq == 0) s_rinv[(it * 4 + wv) * 16 + px] = 1.0f / fmaxf(sqrtf(r), 1e-12f);
+      if (kq == 0) s_rinv[(it * 4 + wv) * 16 + px] = rms_rinv<DT<T>::precise>(r);
     }
     __syncthreads();
   }
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
         }
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
-        const float sc = a.q_scale / sum;
+        const float sc = DT<T>::precise ? a.q_scale / sum : a.q_scale * __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[m][r] *= sc; v[m + 1][r] *= sc; }
       }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
         for (int r = 0; r < 4; ++r) ss = fmaf(v[m][r], v[m][r], ss);
       ss += __shfl_xor(ss, 16);
       ss += __shfl_xor(ss, 32);
-      const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+      const float inv = rms_rinv<DT<T>::precise>(ss);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int co = (m0 + m) * 16 + kq * 4;

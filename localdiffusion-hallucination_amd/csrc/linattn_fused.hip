@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
         float r = rs[it];
         r += __shfl_xor(r, 16);
         r += __shfl_xor(r, 32);
-        if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = 1.0f / fmaxf(sqrtf(r), 1e-12f);
+        if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = rms_rinv<false>(r);
       }
       __syncthreads();
       {
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
         float r = rs[it];
         r += __shfl_xor(r, 16);
         r += __shfl_xor(r, 32);
-        if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = 1.0f / fmaxf(sqrtf(r), 1e-12f);
+        if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = rms_rinv<false>(r);
       }
       __syncthreads();
       {
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
     float r = rs[it];
     r += __shfl_xor(r, 16);
     r += __shfl_xor(r, 32);
-    if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = 1.0f / fmaxf(sqrtf(r), 1e-12f);
+    if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = rms_rinv<false>(r);
   }
   __syncthreads();
 #pragma unroll
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
       }
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
-      const float sc = a.q_scale / sum;
+      const float sc = a.q_scale * __builtin_amdgcn_rcpf(sum);
       B2[hh] = make_uint4(pack_bf16x2(v0[0] * sc, v0[1] * sc), pack_bf16x2(v0[2] * sc, v0[3] * sc),
                           pack_bf16x2(v1[0] * sc, v1[1] * sc), pack_bf16x2(v1[2] * sc, v1[3] * sc));
     }
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
     }
     ss += __shfl_xor(ss, 16);
     ss += __shfl_xor(ss, 32);
-    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    const float inv = rms_rinv<false>(ss);
     if (valid) {
 #pragma unroll
       for (int m2 = 0; m2 < MT2; ++m2) {
