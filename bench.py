@@ -221,6 +221,15 @@ def main():
                     f.write(f"{i:4d} {m.get('family', '?'):22s} {m.get('what', '?'):38s} {m.get('shape', ''):20s} "
                             f"{us:9.1f} us  {m.get('bytes', 0) / max(us, 1e-9) / 1e3:8.1f} GB/s  "
                             f"{m.get('flops', 0) / max(us, 1e-9) / 1e6:8.1f} TF/s\n")
+        # the north star's "ResBlock conv path": the C=32 3x3 convolutions at full resolution (SURVEY 8a census, first
+        # two lines), priced against the HBM roofline with their algorithmic bytes
+        rb_ms = rb_bytes = rb_n = 0
+        for i, (ms, cnt) in acc.items():
+            m = tp.meta.get(i, {})
+            if m.get("family", "").startswith("conv3x3") and m.get("shape", "").endswith(f"@{H}x{H}"):
+                rb_ms += ms
+                rb_bytes += m.get("bytes", 0) * cnt
+                rb_n += cnt
         name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
         sec = d["ms"] * 1e-3
         gbs = d["bytes"] / sec / 1e9 if d["bytes"] else 0.0
@@ -246,6 +255,9 @@ def main():
                      "share_of_step": d["ms"] / max(total_ms, 1e-9),
                      # whole path: 0.7036 TB of algorithmic traffic per 256^2 bf16 patch over T=1000
                      "path_frac": value / world * ALGO_TB_PER_PATCH * 1e3 / HBM_PEAK_GBS,
+                     "resblock_conv_path": {"launches_per_step": rb_n // 5, "ms_per_step": round(rb_ms / 5, 4),
+                                            "algorithmic_GBps": rb_bytes / max(rb_ms, 1e-9) / 1e6,
+                                            "hbm_frac": rb_bytes / max(rb_ms, 1e-9) / 1e6 / HBM_PEAK_GBS},
                      "families_ms_per_step": {k: round(v["ms"] / 5, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}})
         out["roofline"] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:        # contract: CPU baseline on rank 0 at N=1 only

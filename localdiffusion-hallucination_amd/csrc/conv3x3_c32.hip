@@ -430,7 +430,12 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   a.B = p->B; a.H = p->H; a.W = p->W; a.t_ptr = p->t_ptr; a.tiles_x = a.ntiles = 0;
   static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
   a.dbg = dbg;
-  const int rc = p->dtype == LD_F32 ? launch_c32<float, 1, 6>(a, st) : launch_c32<bf16, 1, 6>(a, st);
+  static const int ring = getenv("LD_CONV_C32_R") ? atoi(getenv("LD_CONV_C32_R")) : 6;   // experiment: ring depth
+  int rc;
+  if (p->dtype == LD_F32) rc = launch_c32<float, 1, 6>(a, st);
+  else if (ring == 3) rc = launch_c32<bf16, 1, 3>(a, st);
+  else if (ring == 4) rc = launch_c32<bf16, 1, 4>(a, st);
+  else rc = launch_c32<bf16, 1, 6>(a, st);
   return rc == LD_OK ? 1 : rc;
 }
 
