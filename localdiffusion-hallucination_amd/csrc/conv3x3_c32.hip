@@ -433,6 +433,7 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   static const int ring = getenv("LD_CONV_C32_R") ? atoi(getenv("LD_CONV_C32_R")) : 6;   // experiment: ring depth
   int rc;
   if (p->dtype == LD_F32) rc = launch_c32<float, 1, 6>(a, st);
+  else if (ring == 2) rc = launch_c32<bf16, 1, 2>(a, st);
   else if (ring == 3) rc = launch_c32<bf16, 1, 3>(a, st);
   else if (ring == 4) rc = launch_c32<bf16, 1, 4>(a, st);
   else rc = launch_c32<bf16, 1, 6>(a, st);
