@@ -45,8 +45,13 @@ struct Conv3Dev {
 __device__ unsigned long long g_conv_trace[16];
 #define TR_STAMP(k) do { if ((DBG & 64) && tracing) tr_t[k] = __builtin_readcyclecounter(); } while (0)
 
-template <typename T, int MT, int NW, bool DEEP, int DBG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3 : 1, MT == 2 ? 3 : 2))) void conv3x3_kernel(Conv3Dev a) {
+// SK ("split-K halves", bf16 small-map launches): a 512-thread workgroup whose two halves each own every other
+// K-chunk with their own staging buffers.  The barrier schedule is shared and the halves run it in opposite phase:
+// while one half waits for its loads, transforms and writes them to LDS, the other reads fragments and issues MFMAs,
+// so every SIMD holds two waves whose staging and matrix phases overlap (a 256-thread workgroup alone on a CU is one
+// dependent chain per SIMD with the matrix pipe 25 % busy, DESIGN finding 24).  The halves' partial sums meet in LDS.
+template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false>
+__global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(SK ? 2 : (MT == 2 ? 3 : 1), SK ? 2 : (MT == 2 ? 3 : 2)))) void conv3x3_kernel(Conv3Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int TR = 4 * NW, TC = 16, HR = TR + 2, HC = TC + 2;
   constexpr int NPIX = HR * HC, NPIXP = (NPIX + 15) / 16 * 16, PLANE = NPIXP * 16;
@@ -55,18 +60,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
   constexpr bool P = DT<T>::precise;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* s_x = smem;
-  char* s_w = smem + 4 * PLANE;
-  float* s_coef = reinterpret_cast<float*>(s_w + 9 * MT * 1024);
+  constexpr int STAGE = 4 * PLANE + 9 * MT * 1024;         // one half's staging buffers
+  const int half = SK ? (int)(threadIdx.x >> 8) : 0;       // wave-uniform
+  char* s_x = smem + half * STAGE;
+  char* s_w = s_x + 4 * PLANE;
+  float* s_coef = reinterpret_cast<float*>(smem + (SK ? 2 : 1) * STAGE);
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
   // fp64 scratch: [4 waves][2][16*MT] per-wave channel sums (also the stripe-reduction scratch of
   // build_gn_coef, 32 doubles).  Per-lane/per-wave partials are fp32 over <= 16*NW values; every
   // sum across waves and workgroups is fp64, so E[x^2]-mean^2 does not see fp32 partial-sum rounding.
   double* s_stat = reinterpret_cast<double*>(s_coef + 2 * ctot);
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;   // within the half
   unsigned long long tr_t[16] = {0};
-  const bool tracing = (DBG & 64) && tid == 0 && blockIdx.z == gridDim.z / 2 && blockIdx.y == 0 &&
+  const bool tracing = (DBG & 64) && threadIdx.x == 0 && blockIdx.z == gridDim.z / 2 && blockIdx.y == 0 &&
                        blockIdx.x == (gridDim.x * 5) / 8;
   TR_STAMP(0);
   const int b = blockIdx.z, m0 = blockIdx.y * MT;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
   };
 
   TR_STAMP(1);
-  issue_loads(0, hxA, wxA);
+  if (!SK || half < nch) issue_loads(half, hxA, wxA);     // half h owns chunks h, h+2, ...
   TR_STAMP(2);
   float4 bias[MT];
 #pragma unroll
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
         const SrcDev S = s ? a.s[1] : a.s[0];
         if (S.stats) {
           const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
-          build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, tid, 256);
+          build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, (int)threadIdx.x, SK ? 512 : 256);
         }
         off += 2 * S.C;
       }
@@ -243,7 +250,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
       }
     }
   };
-  if constexpr (!DEEP) {
+  if constexpr (SK) {
+    for (int k = 0; k <= nch; ++k) {
+      __syncthreads();               // first time: coefficients visible; then: the other half's phase is complete
+      if ((k & 1) == half) {         // staging phase: chunk k (mine) into my buffers, request chunk k+2
+        if (k < nch) {
+          write_lds(k, hxA, wxA);
+          if (k + 2 < nch) issue_loads(k + 2, hxA, wxA);
+        }
+      } else if (k >= 1) {           // matrix phase: chunk k-1 (mine, staged in the previous interval)
+        compute();
+      }
+    }
+    // join the partial sums: half 1 -> LDS (its own staging buffers are dead) -> half 0
+    __syncthreads();
+    float4* s_red = reinterpret_cast<float4*>(smem + STAGE);
+    if (half == 1) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+          s_red[(m * NW + j) * 256 + tid] = make_float4(acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]);
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const float4 o = s_red[(m * NW + j) * 256 + tid];
+          acc[m][j][0] += o.x; acc[m][j][1] += o.y; acc[m][j][2] += o.z; acc[m][j][3] += o.w;
+        }
+    }
+  } else if constexpr (!DEEP) {
     for (int ch = 0; ch < nch; ++ch) {
       __syncthreads();               // previous chunk fully consumed (first time: coefficients visible)
       if (ch == 0) TR_STAMP(4);
@@ -295,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int gy = ty0 + wv * NW + j;
-      const bool valid = gy < H && gx < W;
+      const bool valid = gy < H && gx < W && half == 0;   // (SK: half 0 holds the joined sums)
       const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
       float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
       if (valid && a.addend) {
@@ -326,13 +365,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
       for (int m = 0; m < MT; ++m) {
         const float s1 = wave16_sum((ssum[m][0] + ssum[m][1]) + (ssum[m][2] + ssum[m][3]));
         const float s2 = wave16_sum((ssq[m][0] + ssq[m][1]) + (ssq[m][2] + ssq[m][3]));
-        if (px == 0) {
+        if (px == 0 && half == 0) {
           s_stat[(wv * 2 + 0) * 4 * MT + m * 4 + kq] = (double)s1;
           s_stat[(wv * 2 + 1) * 4 * MT + m * 4 + kq] = (double)s2;
         }
       }
       __syncthreads();
-      if (tid < 2 * ngrp_blk) {
+      if (tid < 2 * ngrp_blk && half == 0) {
         const int gi = tid >> 1, k = tid & 1, q4 = gs >> 2;
         double acc1 = 0.0;
         for (int w4 = 0; w4 < 4; ++w4)
@@ -346,13 +385,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
-          if (px == 0) {
+          if (px == 0 && half == 0) {
             s_stat[(wv * 2 + 0) * 16 * MT + m * 16 + kq * 4 + r] = (double)s1;
             s_stat[(wv * 2 + 1) * 16 * MT + m * 16 + kq * 4 + r] = (double)s2;
           }
         }
       __syncthreads();
-      if (tid < 2 * ngrp_blk) {
+      if (tid < 2 * ngrp_blk && half == 0) {
         const int gi = tid >> 1, k = tid & 1;
         double acc1 = 0.0;
         for (int w4 = 0; w4 < 4; ++w4)
@@ -370,22 +409,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 2 ? 3
   }
 }
 
-template <typename T, int MT, int NW, bool DEEP, int DBG>
+template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false>
 int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   constexpr int TR = 4 * NW, HR = TR + 2, HC = 18;
   constexpr int NPIXP = (HR * HC + 15) / 16 * 16;
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
-  const size_t lds = 4 * NPIXP * 16 + 9 * MT * 1024 + 2 * ctot * sizeof(float) + 4 * 2 * 16 * MT * sizeof(double);
+  const size_t lds = (SK ? 2 : 1) * (4 * NPIXP * 16 + 9 * MT * 1024) + 2 * ctot * sizeof(float) + 4 * 2 * 16 * MT * sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
-    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG>, lds));
+    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG, SK>, lds));
     allowed = lds;
   }
   Conv3Dev d = a;
   d.tiles_x = (a.W + 15) / 16;
   const int tiles_y = (a.H + TR - 1) / TR;
   dim3 grid(d.tiles_x * tiles_y, a.Cout / (16 * MT), a.B);
-  LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG>), grid, dim3(256), lds, st, d);
+  LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG, SK>), grid, dim3(SK ? 512 : 256), lds, st, d);
   LD_LAUNCH_CHECK("conv3x3");
   return LD_OK;
 }
@@ -436,8 +475,18 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
   // measured: distance-2 prefetch is within noise of distance 1 on every small-map shape (the waits there are
   // barrier skew, not load latency), so it stays an opt-in experiment (LD_CONV_DEEP=1)
   bool deep = false;
-  (void)nch; (void)wg;
   if (force_deep >= 0) deep = force_deep != 0;
+  // split-K halves (opt-in, LD_CONV_SK=1: launches with >= 8 chunks and at most LD_CONV_SK_MAX_WGS workgroups;
+  // LD_CONV_SK=2: every eligible launch).  Measured: 256->256 @32^2 18.0 -> 17.1 us, with the GroupNorm prologue
+  // 25.5 -> 22.5, 512->256 46.0 -> 37.6; four-chunk launches and grids beyond one workgroup per CU lose.  Over a
+  // step: +0.6 % for one batch of 8 on one stream, -1 % with two concurrent sub-batches (the second stream already
+  // fills the gaps this variant closes), hence off by default.
+  static const int force_sk = getenv("LD_CONV_SK") ? atoi(getenv("LD_CONV_SK")) : 0;
+  static const long sk_max_wgs = getenv("LD_CONV_SK_MAX_WGS") ? atol(getenv("LD_CONV_SK_MAX_WGS")) : 256;
+  bool sk = force_sk >= 1 && sizeof(T) == 2 && !big && !deep && ((nch >= 8 && wg <= sk_max_wgs) || force_sk == 2);
+  if constexpr (sizeof(T) == 2) {
+    if (sk) return mt4 ? launch_dbg<T, 4, 2, false, 0, true>(a, st) : launch_dbg<T, 2, 2, false, 0, true>(a, st);
+  }
   if (mt4) return big ? launch<T, 4, 4, false>(a, st) : (deep ? launch<T, 4, 2, true>(a, st) : launch<T, 4, 2, false>(a, st));
   return big ? launch<T, 2, 4, false>(a, st) : (deep ? launch<T, 2, 2, true>(a, st) : launch<T, 2, 2, false>(a, st));
 }

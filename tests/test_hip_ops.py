@@ -522,6 +522,39 @@ def test_conv3x3_c32_persistent_path(dtype):
         assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, 8)) < 1e-2
 
 
+def test_conv3x3_split_k_halves_variant():
+    """The opt-in 512-thread variant (LD_CONV_SK=2: two halves of a workgroup own alternate K-chunks in opposite
+    phase, partial sums joined through LDS) against F.conv2d: plain, with statistics, with the GroupNorm prologue,
+    ragged size, odd chunk count.  The switch is read once per process, hence the child process."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, torch, torch.nn.functional as F
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import hip_helpers as hh
+        from localdiffusion_hallucination_amd import _cabi as cabi
+        dtype = "bf16"
+        q = lambda t: t.to(torch.bfloat16).float()
+        for (B, cin, cout, H, W) in [(2, 256, 64, 16, 16), (1, 96, 32, 13, 18), (2, 64, 64, 8, 24)]:
+            x, w, b = q(hh.rand((B, cin, H, W), 301)), q(hh.rand((cout, cin, 3, 3), 302, -0.1, 0.1)), hh.rand((cout,), 303)
+            ref = F.conv2d(x, w, b, padding=1)
+            stats = hh.stats_buffer(B, 8)
+            out = hh.conv3x3([hh.make_src(hh.nhwc(x, dtype), cin)], hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype,
+                             stats=stats, groups=8)
+            assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype], ("plain", cin, cout)
+            assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, 8)) < 1e-2
+            gamma, beta = hh.rand((cin,), 304, 0.5, 1.5), hh.rand((cin,), 305, -0.3, 0.3)
+            y = F.silu(F.group_norm(x, 8, gamma, beta, eps=1e-5))
+            ref = F.conv2d(y, w, b, padding=1)
+            src = hh.make_src(hh.nhwc(x, dtype), cin, gn=(hh.stats_striped(x, 8), gamma.to(hh.DEV), beta.to(hh.DEV), 8), act=cabi.ACT_SILU)
+            out = hh.conv3x3([src], hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype)
+            assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2, ("prologue", cin, cout)
+        print("SK-OK")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LD_CONV_SK="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv1x1_gn_tail_epilogue(dtype):
     """ResnetBlock tail fused into res_conv: out = conv1x1(cat(x1,x2)) + SiLU(GN(raw2))."""
