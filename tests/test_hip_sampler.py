@@ -250,6 +250,41 @@ def test_cfg3_shape_sub_batches_and_batch_independence():
     assert float(np.abs(same - same[:1]).max()) == 0.0, "identical patches in one batch must give identical outputs"
 
 
+def test_cfg5_shape_ddim_branch_fusion_matches_oracle():
+    """BASELINE.json configs[4] at full size -- one 1x512x512 patch, T=1000 strided to 3 DDIM steps (eta 0), OOD/IND
+    branches with a circular OOD mask of radius 64, fusion at the last step -- against the oracle sampler run on the
+    host cores with the same noise stream (about 20 s of oracle time).  fp32, the 1e-3 gate."""
+    from oracle import diffusion_ref
+    H, T, S = 512, 1000, 3
+    kw = dict(mode="mri")
+    net = ldh.Unet(dim=32, init_dim=32, compute_dtype="fp32", **kw)
+    sd = {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()}
+    net.load_state_dict(sd)
+    yy, xx = np.mgrid[0:H, 0:H]
+    mask = torch.from_numpy((((yy - H / 2) ** 2 + (xx - H / 2) ** 2) <= 64 ** 2).astype(np.float32))[None, None]
+    cond = torch.from_numpy(rng.uniform((1, 1, H, H), 12, 1, 0.0, 2.0))
+    conf = dict(branch_out=True, start_intermediate=True, start_timestep=0, data="mri", mask_x=True, mask_cond=False,
+                ood_AD=False, ood_confidence=False, classifier=False, use_gt=False, use_gt_timestep=100)
+    gd = ldh.GaussianDiffusion(conf, net, image_size=H, timesteps=T, beta_schedule="sigmoid", objective="pred_x0",
+                               auto_normalize=False, sampling_timesteps=S).to("cuda")
+    gd.noise_source = "host"
+    got = run(gd, cond, mask, 1)
+
+    class Noise:
+        def __init__(self):
+            self.s = rng.NoiseStream(10)
+
+        def __call__(self, shape):
+            return torch.from_numpy(self.s.next(tuple(shape)))
+    o = diffusion_ref.SamplerOptions(timesteps=T, sampling_timesteps=S, branch_out=True, start_intermediate=True,
+                                     start_timestep=0, data="mri", mask_x=True)
+    smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd, net.cfg), o, 1, H)
+    with torch.no_grad():
+        ref = smp.sample(cond, mask, (0.0, 2.0), 1, Noise())
+    ref = np.stack([t.numpy() for t in ref]) if isinstance(ref, list) else ref.numpy()
+    check("cfg5 shape (512^2, DDIM, branch + fusion)", got, ref)
+
+
 def test_eval_driver_matches_cfg1_golden(golden, tmp_path):
     """evalio.evaluate (test.py-equivalent loop) on the 4 golden digits == the reference's cfg1 output."""
     from localdiffusion_hallucination_amd import evalio

@@ -59,6 +59,25 @@ def test_forward_fp32_matches_oracle_and_golden(tag, golden):
         assert float((y - torch.from_numpy(g[f"{tag}_t{t}_out"])).abs().max()) < 2e-4
 
 
+@pytest.mark.parametrize("kw,B,H,what", [(dict(mode="mri"), 1, 512, "cfg5: 1-ch 512^2, full attention over 4,096 tokens"),
+                                         (dict(channels=3, out_dim=3, mode="mvtec"), 1, 256, "cfg3: 3-ch 256^2")])
+def test_forward_fp32_at_baseline_sizes_matches_oracle(kw, B, H, what):
+    """One denoiser evaluation at BASELINE.json's largest shapes against the CPU oracle (a few seconds of oracle time
+    each): the sizes where the 16-row conv tiles, the 1,024-pixel linear-attention chunks and the 128-key attention
+    tiles are actually exercised."""
+    net, sd = build(kw, "fp32")
+    cfg = net.cfg
+    x = torch.from_numpy(rng.randn((B, cfg.channels, H, H), 1, 110))
+    cond = torch.from_numpy(rng.uniform((B, cfg.cond_in_channels, H, H), 1, 111, 0.0, 2.0))
+    tv = torch.full((B,), 417, dtype=torch.long)
+    y = net(x.cuda(), cond.cuda(), tv.cuda()).cpu()
+    with torch.no_grad():
+        y_ref = unet_ref.unet_forward(sd, cfg, x, cond, tv, {})
+    err, scale = float((y - y_ref).abs().max()), float(y_ref.abs().max())
+    print(f"{what}: out err {err:.3e} (ref max {scale:.3e})")
+    assert err < 2e-4 * max(1.0, scale)
+
+
 @pytest.mark.parametrize("tag", list(CASES))
 def test_forward_bf16_within_tolerance(tag):
     """bf16 storage / fp32 accumulate: relative max error of the output vs the fp32 oracle < 5 %
