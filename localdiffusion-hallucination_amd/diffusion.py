@@ -223,7 +223,7 @@ class GaussianDiffusion(nn.Module):
         self.use_graph = False
         # concurrent sub-batches of the joint steps (see _SubBatches); 1 = one batch on the caller's stream
         self.sub_batches = int(os.environ.get("LD_SUB_BATCHES", "2"))
-        self.min_sub_batch = int(os.environ.get("LD_MIN_SUB_BATCH", "4"))
+        self.min_sub_batch = int(os.environ.get("LD_MIN_SUB_BATCH", "2"))
         self._sched = None
         self._graphs = {}
         self._subs = {}
