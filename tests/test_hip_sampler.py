@@ -283,6 +283,16 @@ def test_cfg5_shape_ddim_branch_fusion_matches_oracle():
         ref = smp.sample(cond, mask, (0.0, 2.0), 1, Noise())
     ref = np.stack([t.numpy() for t in ref]) if isinstance(ref, list) else ref.numpy()
     check("cfg5 shape (512^2, DDIM, branch + fusion)", got, ref)
+    # the same run with bf16 storage (MFMA attention over 4,096 keys, fused linear attention with 1,024-pixel chunks):
+    # outside the 1e-3 gate by construction, bounded against the fp32 result
+    net16 = ldh.Unet(dim=32, init_dim=32, compute_dtype="bf16", **kw)
+    net16.load_state_dict(sd)
+    gd16 = ldh.GaussianDiffusion(conf, net16, image_size=H, timesteps=T, beta_schedule="sigmoid", objective="pred_x0",
+                                 auto_normalize=False, sampling_timesteps=S).to("cuda")
+    gd16.noise_source = "host"
+    d = np.abs(run(gd16, cond, mask, 1) - got)
+    print(f"cfg5 shape, bf16 vs fp32 storage: mean-abs {d.mean():.3e}  max-abs {d.max():.3e}")
+    assert d.mean() <= 2e-2 and d.max() <= 0.3
 
 
 def test_eval_driver_matches_cfg1_golden(golden, tmp_path):
