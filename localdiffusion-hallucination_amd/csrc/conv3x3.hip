@@ -463,7 +463,8 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
   const long blocks16 = (long)((a.W + 15) / 16) * ((a.H + 15) / 16) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
   // 64-channel tiles keep 2 pixel rows per wave: with the prefetch registers the 4-row variant
   // drops to one wave per SIMD and measured slower (64->64@128^2: 23.3 vs 19.7 us)
-  bool big = blocks16 >= 512 && a.H >= 16 && !mt4;
+  static const long big_min = getenv("LD_CONV_BIG_MIN") ? atol(getenv("LD_CONV_BIG_MIN")) : 512;   // tuning override
+  bool big = blocks16 >= big_min && a.H >= 16 && !mt4;
   if (force_mt == 2) mt4 = false;
   if (force_mt == 4 && (a.Cout % 64) == 0) mt4 = true;
   if (force_nw == 2) big = false;
