@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 
 T_STEPS = 1000
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks (same guide)
+MFMA_PEAK_TF = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA peaks (same guide)
 ALGO_TB_PER_PATCH = 0.7036       # algorithmic bytes per 3x256x256 bf16 patch over T=1000
 
 
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--patches", type=int, default=8, help="local patches per GPU (K masks of one image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -14,8 +14,9 @@
  *     0 on success or a negative LD_E* code; ld_last_error() gives a thread-local message.
  *   - no allocation, no synchronisation, no global mutable state inside launch functions, so they
  *     may be captured into a HIP graph (ld_graph_*).
- *   - internal activations are NHWC (channels-last) in the storage dtype (LD_F32 or LD_BF16),
- *     accumulation is always fp32; tensors that cross the reference's API (x_t, cond, mask, model
+ *   - internal activations are NHWC (channels-last) in the storage dtype (LD_F32, LD_BF16 or LD_F16),
+ *     accumulation is always fp32 (the 16-bit types run v_mfma_f32_16x16x32_bf16 / _f16 at the same rate; fp16
+ *     keeps 10 mantissa bits against bf16's 7, at a range of 6e-8 .. 65504); tensors that cross the reference's API (x_t, cond, mask, model
  *     output) are NCHW fp32 exactly as the reference holds them.
  *   - "t_ptr" arguments are device pointers to the current timestep index (int32).  Kernels read
  *     the step through them so that one captured graph can be replayed for every timestep; pass
@@ -37,6 +38,7 @@ extern "C" {
 
 #define LD_F32 0
 #define LD_BF16 1
+#define LD_F16 2
 
 /* GroupNorm statistics buffers are [B, LD_STAT_STRIPES, groups, 2] fp64 (sum, sum of squares):
  * a producer workgroup adds into stripe (workgroup index % LD_STAT_STRIPES) so that the 256
@@ -169,14 +171,14 @@ int ld_conv_image(const float* x_nchw, const float* w_oihw, const float* bias, v
                   double* out_stats, int out_groups, int B, int Cin, int H, int W, int ksize,
                   int dtype, void* stream);
 
-/* init_conv 7x7 (ddpm.py:319,413) for bf16 storage as an implicit GEMM on MFMA: x NCHW fp32 [B,Cin<=3,H,W] ->
- * out NHWC bf16 [B,H,W,32].  Image and weights are split into bf16 hi+lo parts (three MFMA products, fp32
+/* init_conv 7x7 (ddpm.py:319,413) for 16-bit storage as an implicit GEMM on MFMA: x NCHW fp32 [B,Cin<=3,H,W] ->
+ * out NHWC bf16 / fp16 [B,H,W,32].  Image and weights are split into bf16 hi+lo parts (three MFMA products, fp32
  * accumulate), so the result equals the fp32-FMA kernel of ld_conv_image up to the rounding of the stored bf16.
  * w_packed: ld_stem_packed_bytes() bytes written once per model by ld_pack_stem_weight from the OIHW fp32 weight. */
 size_t ld_stem_packed_bytes(void);
 int ld_pack_stem_weight(const float* w_oihw /*[32,Cin,7,7]*/, void* out_packed, int Cin, void* stream);
 int ld_conv_stem(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H, int W,
-                 void* stream);
+                 int dtype /* LD_BF16 or LD_F16: type of the stored output */, void* stream);
 
 
 /* ---- GroupNorm apply (+FiLM) + activation + residual, optional second normalised input ----- */
@@ -211,7 +213,7 @@ int ld_linattn_ctx(const void* qkv, const uint32_t* kmax_enc, float* ctx_part,
                    int B, int n, int heads, int dim_head, int nchunks, int dtype, void* stream);
 int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* ctxn, int B, int heads,
                           int dim_head, void* stream);
-/* perm=0: standard k=1 packing (consumed by ld_conv1x1); perm=1 (bf16): chained-MFMA operand order
+/* perm=0: standard k=1 packing (consumed by ld_conv1x1); perm=1 (bf16 / fp16): chained-MFMA operand order
  * consumed by ld_linattn_out. */
 int ld_linattn_fold(const float* ctxn, const float* w_out /*[C,hidden] fp32*/,
                     void* w_packed /*[B] packed C x hidden*/, int B, int C, int heads, int dim_head,
@@ -221,7 +223,7 @@ int ld_linattn_fold(const float* ctxn, const float* w_out /*[C,hidden] fp32*/,
 int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const float* w_out /*[C,hidden] fp32*/,
                        void* w_packed /*[B] packed C x hidden*/, int B, int C, int heads, int dim_head,
                        int perm, int dtype, void* stream);
-/* Fused bf16 path: q, k, v never reach HBM (both kernels recompute their slice of to_qkv from x).
+/* Fused 16-bit (bf16 / fp16) path: q, k, v never reach HBM (both kernels recompute their slice of to_qkv from x).
  *   ld_linattn_kvctx: x [B,n,C] -> ctx partials (same layout/consumers as ld_linattn_ctx), with the
  *        RMSNorm (ddpm.py:237), the k/v rows of to_qkv (:239) and softmax_n(k) (:243) inside;
  *        wkv_packed = per head the 64 rows (k_h | v_h) of to_qkv, packed k=1 with g*sqrt(C) folded.

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LD_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "liblocaldiff_hip.so")   # override: A/B builds
 
-LD_F32, LD_BF16 = 0, 1
+LD_F32, LD_BF16, LD_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 EPI_PLAIN, EPI_QKV_LINEAR, EPI_QKV_FULL, EPI_RMS_RES, EPI_RES, EPI_GN_TAIL = 0, 1, 2, 3, 4, 5
 OBJ = {"pred_x0": 0, "pred_noise": 1, "pred_v": 2}
@@ -66,7 +66,7 @@ _SIGS = {
                                 C.c_int, C.c_int, vp]),
     "ld_stem_packed_bytes": (C.c_size_t, []),
     "ld_pack_stem_weight": (C.c_int, [vp, vp, C.c_int, vp]),
-    "ld_conv_stem": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_conv_stem": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_gn_apply": (C.c_int, [C.POINTER(GnApplyArgs), vp]),
     "ld_linattn_kmax": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_linattn_ctx": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -142,4 +142,5 @@ def ptr(t):
 
 
 def dtype_code(name):
-    return {"fp32": LD_F32, "float32": LD_F32, "bf16": LD_BF16, "bfloat16": LD_BF16}[name]
+    return {"fp32": LD_F32, "float32": LD_F32, "bf16": LD_BF16, "bfloat16": LD_BF16, "fp16": LD_F16, "float16": LD_F16,
+            "half": LD_F16}[name]

@@ -7,8 +7,8 @@
 // keys 16w..16w+15 of every tile for all 64 queries (lane = query) with an online softmax
 // (running max m, normaliser l), and the four partial (m, l, o) are merged at the end.
 // fp32 storage: VALU arithmetic below (the parity path, exact fp32 products).
-// bf16 storage: attention_mfma_kernel further down (QK^T and PV on v_mfma_f32_16x16x32_bf16).
-#include "common.cuh"
+// bf16 / fp16 storage: attention_mfma_kernel further down (QK^T and PV on v_mfma_f32_16x16x32_bf16 / _f16).
+#include "common.hip.h"
 
 namespace {
 constexpr int D = 32;     // dim_head
@@ -133,7 +133,8 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                              int n, int heads) {
   constexpr int NKT = TKV / 16, NST = TKV / 64;          // 16-key MFMA tiles per tile; staging rows per thread
   __shared__ __attribute__((aligned(16))) uint4 s_k[4][TKV + 1];   // +1: the 4 chunk lanes of a key write 4 distinct bank quads
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restr
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kg = lane >> 4;
   const size_t rowstride = (size_t)3 * hidden;
-  const bf16* base = qkv + (size_t)b * n * rowstride;
+  const T* base = qkv + (size_t)b * n * rowstride;
   const int qi = q0 + wv * 16 + li;
   uint4 qf = make_uint4(0u, 0u, 0u, 0u);
   if (qi < n) qf = *reinterpret_cast<const uint4*>(base + (size_t)qi * rowstride + h * D + kg * 8);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restr
       kk[u] = make_uint4(0u, 0u, 0u, 0u);
       vv[u] = kk[u];
       if (j < n) {
-        const bf16* rp = base + (size_t)j * rowstride + h * D + schunk * 8;
+        const T* rp = base + (size_t)j * rowstride + h * D + schunk * 8;
         kk[u] = *reinterpret_cast<const uint4*>(rp + hidden);
         vv[u] = *reinterpret_cast<const uint4*>(rp + 2 * hidden);
       }
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restr
     for (int kt = 0; kt < NKT; ++kt) {
       const uint4 kf = s_k[kg][kt * 16 + li];
       s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mma16<bf16>(s[kt], kf, qf);
+      mma16<T>(s[kt], kf, qf);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (!full && (j0 + kt * 16 + kg * 4 + r) >= n) s[kt][r] = -1e30f;
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restr
         pv[r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], 1.4426950408889634f, -mn2));   // masked keys: exp2(-huge) = 0
         l += pv[r];
       }
-      pk[kt][0] = pack_bf16x2(pv[0], pv[1]);
-      pk[kt][1] = pack_bf16x2(pv[2], pv[3]);
+      pk[kt][0] = pack2<T>(pv[0], pv[1]);
+      pk[kt][1] = pack2<T>(pv[2], pv[3]);
     }
 #pragma unroll
     for (int ks = 0; ks < NKT / 2; ++ks) {
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restr
         const uint2 v1 = tr_read(vrow + dt * 32);
         const uint2 v2 = tr_read(vrow + 16 * VROW + dt * 32);
         const uint4 vf = make_uint4(v1.x, v1.y, v2.x, v2.y);
-        if (dt == 0) mma16<bf16>(o0, vf, pf);
-        else mma16<bf16>(o1, vf, pf);
+        if (dt == 0) mma16<T>(o0, vf, pf);
+        else mma16<T>(o1, vf, pf);
       }
     }
   }
@@ -231,11 +232,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16* __restr
   l += __shfl_xor(l, 32);
   if (qi < n) {
     const float inv = 1.0f / l;
-    bf16* op = out + ((size_t)b * n + qi) * hidden + h * D + kg * 4;
+    T* op = out + ((size_t)b * n + qi) * hidden + h * D + kg * 4;
     float r0[4] = {o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv};
     float r1[4] = {o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
-    store4<bf16>(op, r0);
-    store4<bf16>(op + 16, r1);
+    store4<T>(op, r0);
+    store4<T>(op + 16, r1);
   }
 }
 }  // namespace
@@ -248,8 +249,11 @@ extern "C" int ld_attention(const void* qkv, void* out, int B, int n, int heads,
   dim3 grid((n + 63) / 64, heads, B);
   if (dtype == LD_F32)
     LD_LAUNCH(attention_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, (float*)out, n, heads);
-  else if (dtype == LD_BF16)
-    LD_LAUNCH(attention_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, n, heads);
+  else if (ld_dtype_16(dtype))
+    LD_DISPATCH16(dtype, [&] {
+      LD_LAUNCH(attention_mfma_kernel<T>, grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n, heads);
+      return 0;
+    }());
   else
     return ld_fail(LD_EINVAL, "ld_attention: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("attention");

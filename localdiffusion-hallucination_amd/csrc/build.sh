@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ff
 mkdir -p build
 pids=()
 for f in runtime pack conv3x3 conv3x3_c32 conv1x1 conv_image gn_apply linattn linattn_fused attention time_embed pointwise; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.cuh -nt build/$f.o ] || [ ../../include/localdiff_hip.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.hip.h -nt build/$f.o ] || [ ../../include/localdiff_hip.h -nt build/$f.o ]; then
     # MFMA results in VGPRs (no v_accvgpr_read/mov traffic in the epilogues that post-process accumulators);
     # the register-staged generic conv measured 1.5 % slower with it and keeps the default AGPR form
     EXTRA="-mllvm -amdgpu-mfma-vgpr-form"

@@ -12,6 +12,10 @@
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __bf16 bf16;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // ---------------------------------------------------------------- host-side error plumbing
 int ld_fail(int code, const char* fmt, ...);   // runtime.hip
@@ -51,19 +55,42 @@ static inline hipError_t ld_allow_lds(K kernel, size_t bytes) {
 }
 
 // ---------------------------------------------------------------- dtype traits
-// One "fragment" is 16 bytes per lane for both storage types: 8 bf16 or 4 fp32 consecutive
-// channels.  A K-chunk is 4 fragments = 64 bytes of channels per pixel (32 bf16 / 16 fp32).
+// One "fragment" is 16 bytes per lane for every storage type: 8 bf16 / 8 fp16 or 4 fp32 consecutive
+// channels.  A K-chunk is 4 fragments = 64 bytes of channels per pixel (32 bf16 or fp16 / 16 fp32).
+// The two 16-bit types share every tiling constant and every kernel template; they differ in the
+// unpack / pack conversions and in the MFMA opcode (v_mfma_f32_16x16x32_bf16 / _f16, same rate).
 template <typename T> struct DT;
 template <> struct DT<float> {
   static constexpr int E = 4;       // elements per fragment
   static constexpr int CK = 16;     // channels per K-chunk
   static constexpr bool precise = true;
+  static constexpr float pshift = 0.0f;
 };
 template <> struct DT<bf16> {
   static constexpr int E = 8;
   static constexpr int CK = 32;
   static constexpr bool precise = false;
+  static constexpr float pshift = 0.0f;
 };
+template <> struct DT<f16> {
+  static constexpr int E = 8;
+  static constexpr int CK = 32;
+  static constexpr bool precise = false;
+  // softmax_n(k) weights P = exp(k - m) <= 1 are stored as P * 2^pshift (their normaliser Z carries the same
+  // factor): fp16's normal range ends at 6e-5, so unscaled small weights would be rounded as subnormals
+  static constexpr float pshift = 10.0f;
+};
+// dtype code (LD_F32 / LD_BF16 / LD_F16) -> storage type: LD_DISPATCH(dtype, expr using T) evaluates the expression
+// for the matching type (the entry points validate the code first)
+#define LD_DISPATCH(dtype, ...)                                              \
+  ((dtype) == LD_F32 ? [&] { using T = float; return __VA_ARGS__; }()        \
+   : (dtype) == LD_BF16 ? [&] { using T = bf16; return __VA_ARGS__; }()      \
+                        : [&] { using T = f16; return __VA_ARGS__; }())
+#define LD_DISPATCH16(dtype, ...)                                            \
+  ((dtype) == LD_BF16 ? [&] { using T = bf16; return __VA_ARGS__; }()        \
+                      : [&] { using T = f16; return __VA_ARGS__; }())
+static inline bool ld_dtype_ok(int dtype) { return dtype == LD_F32 || dtype == LD_BF16 || dtype == LD_F16; }
+static inline bool ld_dtype_16(int dtype) { return dtype == LD_BF16 || dtype == LD_F16; }
 
 template <typename T> __device__ __forceinline__ void unpack16(const uint4& r, float* v);
 template <> __device__ __forceinline__ void unpack16<float>(const uint4& r, float* v) {
@@ -76,6 +103,14 @@ template <> __device__ __forceinline__ void unpack16<bf16>(const uint4& r, float
   v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
   v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
 }
+__device__ __forceinline__ void unpack_f16x2(unsigned r, float& a, float& b) {
+  const f32x2 f = __builtin_convertvector(__builtin_bit_cast(f16x2, r), f32x2);   // v_cvt_f32_f16 (+ SDWA high half)
+  a = f[0]; b = f[1];
+}
+template <> __device__ __forceinline__ void unpack16<f16>(const uint4& r, float* v) {
+  unpack_f16x2(r.x, v[0], v[1]); unpack_f16x2(r.y, v[2], v[3]);
+  unpack_f16x2(r.z, v[4], v[5]); unpack_f16x2(r.w, v[6], v[7]);
+}
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   // ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved) for the pair: converting the two values
   // separately costs a cvt each plus shift/or to merge them (4 VALU instructions per pair in every epilogue)
@@ -84,6 +119,14 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   const f32x2_t v = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+  const f32x2 v = {lo, hi};                                  // ONE v_cvt_pk_f16_f32 (round-to-nearest-even)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+// two fp32 values -> one packed pair of the 16-bit storage type T
+template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack2<bf16>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ unsigned pack2<f16>(float lo, float hi) { return pack_f16x2(lo, hi); }
 template <typename T> __device__ __forceinline__ uint4 pack16(const float* v);
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* v) {
   return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
@@ -93,6 +136,10 @@ template <> __device__ __forceinline__ uint4 pack16<bf16>(const float* v) {
                     pack_bf16x2(v[6], v[7]));
 }
 
+template <> __device__ __forceinline__ uint4 pack16<f16>(const float* v) {
+  return make_uint4(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7]));
+}
+
 // 4 consecutive output channels (one accumulator fragment) -> 8 or 16 bytes
 template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
 template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
@@ -100,6 +147,9 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float*
 }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+template <> __device__ __forceinline__ void store4<f16>(f16* p, const float* v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]));
 }
 template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
@@ -111,12 +161,18 @@ template <> __device__ __forceinline__ void load4<bf16>(const bf16* p, float* v)
   v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
   v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
 }
+template <> __device__ __forceinline__ void load4<f16>(const f16* p, float* v) {
+  uint2 r = *reinterpret_cast<const uint2*>(p);
+  unpack_f16x2(r.x, v[0], v[1]); unpack_f16x2(r.y, v[2], v[3]);
+}
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f<f16>(f16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+template <> __device__ __forceinline__ f16 from_f<f16>(float v) { return (f16)v; }
 
 // ---------------------------------------------------------------- MFMA, D[cout 16][pixel 16]
 // A = weights fragment (row = output channel, lane&15), B = activation fragment (col = pixel,
@@ -133,6 +189,10 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4
 template <> __device__ __forceinline__ void mma16<bf16>(f32x4& acc, const uint4& a, const uint4& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                  __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+template <> __device__ __forceinline__ void mma16<f16>(f32x4& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------- LDS-DMA

@@ -13,7 +13,7 @@
 //
 // Tiling: 256 threads = 4 waves; tile = 64*NW consecutive pixels of one image x 16*MT output
 // channels; wave w owns pixel tiles [w*NW,(w+1)*NW) and all MT channel tiles.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 namespace {
@@ -322,7 +322,7 @@ int dispatch(const Conv1Dev& a, hipStream_t st) {
 extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
   LD_REQUIRE(p != nullptr, "ld_conv1x1: null args");
   LD_REQUIRE(p->nsrc == 1 || p->nsrc == 2, "ld_conv1x1: nsrc must be 1 or 2");
-  LD_REQUIRE(p->dtype == LD_F32 || p->dtype == LD_BF16, "ld_conv1x1: bad dtype %d", p->dtype);
+  LD_REQUIRE(ld_dtype_ok(p->dtype), "ld_conv1x1: bad dtype %d", p->dtype);
   LD_REQUIRE(p->Cout > 0 && p->Cout % 32 == 0, "ld_conv1x1: Cout %d must be a multiple of 32", p->Cout);
   LD_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->weight && p->out, "ld_conv1x1: bad shape/null");
   LD_REQUIRE(!(p->unshuffle && p->nsrc != 1), "ld_conv1x1: unshuffle takes one source");
@@ -358,5 +358,5 @@ extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
   }
   a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  return p->dtype == LD_F32 ? dispatch<float>(a, st) : dispatch<bf16>(a, st);
+  return LD_DISPATCH(p->dtype, dispatch<T>(a, st));
 }

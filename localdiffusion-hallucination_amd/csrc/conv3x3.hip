@@ -19,7 +19,7 @@
 //       (ld_pack_conv_weight), read linearly.
 // Inner order: dx outer (3*MT weight fragments live), then halo rows rr: one activation fragment
 // feeds the (up to) 3 taps dy that touch it => 9*MT + 3*(NW+2) LDS reads per 9*MT*NW MFMAs.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st);   // conv3x3_c32.hip
@@ -429,11 +429,13 @@ int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   return LD_OK;
 }
 
-// The LD_CONV_DEBUG ablation variants are separate instantiations (bf16, non-DEEP only): the production kernel
-// carries none of their branches.
+// The LD_CONV_DEBUG ablation variants are separate instantiations (bf16, non-DEEP only) that exist only in a
+// library built with -DLD_DEBUG_VARIANTS (build.sh --debug-variants): the production library carries neither their
+// branches nor their code objects.
 template <typename T, int MT, int NW, bool DEEP>
 int launch(const Conv3Dev& a, hipStream_t st) {
-  if constexpr (sizeof(T) == 2 && !DEEP) {
+#ifdef LD_DEBUG_VARIANTS
+  if constexpr (std::is_same<T, bf16>::value && !DEEP) {
     switch (a.dbg) {
       case 1: return launch_dbg<T, MT, NW, DEEP, 1>(a, st);
       case 2: return launch_dbg<T, MT, NW, DEEP, 2>(a, st);
@@ -447,6 +449,7 @@ int launch(const Conv3Dev& a, hipStream_t st) {
       default: break;
     }
   }
+#endif
   return launch_dbg<T, MT, NW, DEEP, 0>(a, st);
 }
 
@@ -504,7 +507,7 @@ extern "C" int ld_debug_conv_trace(unsigned long long* host) {
 extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   LD_REQUIRE(p != nullptr, "ld_conv3x3: null args");
   LD_REQUIRE(p->nsrc == 1 || p->nsrc == 2, "ld_conv3x3: nsrc must be 1 or 2 (got %d)", p->nsrc);
-  LD_REQUIRE(p->dtype == LD_F32 || p->dtype == LD_BF16, "ld_conv3x3: bad dtype %d", p->dtype);
+  LD_REQUIRE(ld_dtype_ok(p->dtype), "ld_conv3x3: bad dtype %d", p->dtype);
   LD_REQUIRE(p->Cout > 0 && p->Cout % 32 == 0, "ld_conv3x3: Cout %d must be a multiple of 32", p->Cout);
   LD_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0, "ld_conv3x3: bad shape");
   LD_REQUIRE(p->weight && p->bias && p->out, "ld_conv3x3: null weight/bias/out");
@@ -537,5 +540,5 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
     const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }
-  return p->dtype == LD_F32 ? dispatch<float>(a, st) : dispatch<bf16>(a, st);
+  return LD_DISPATCH(p->dtype, dispatch<T>(a, st));
 }

@@ -15,12 +15,12 @@
 //     pixels hits 16 distinct 16-B slots (conflict-free for every tap);
 //   * at item i every wave (a) requests its blocks of item i+R-1 into the slot item i-1 just vacated, (b) runs
 //     the MFMAs of item i, (c) stores the tile if it is finished, (d) waits -- with an exact counted vmcnt: the
-//     DMA is issued as inline asm (common.cuh), every wave issues a fixed number of DMA and store instructions
+//     DMA is issued as inline asm (common.hip.h), every wave issues a fixed number of DMA and store instructions
 //     per item because out-of-image lanes read a clamped in-image address and tiles are never ragged
 //     (H, W multiples of 16) -- for its OWN blocks of item i+1 and normalises / activates / zero-pads them in
 //     place, then ONE workgroup barrier.  R-2 items (63-84 KiB per CU) stay in flight across that barrier and
 //     the VALU prologue of item i+1 overlaps the MFMAs of item i of the other wave on the SIMD.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 namespace {
@@ -385,7 +385,8 @@ int launch_c32(const C32Dev& a0, hipStream_t st) {
   const dim3 grid(G, a.B);
   // the LD_CONV_DEBUG ablation / trace variants are separate instantiations: the production kernel carries none
   // of their branches (only a few bit patterns are built; anything else runs the production kernel)
-  if (sizeof(T) == 2 && NCH == 1) {
+#ifdef LD_DEBUG_VARIANTS
+  if (std::is_same<T, bf16>::value && NCH == 1) {
     switch (a.dbg) {
       case 32: return launch_c32_dbg<T, NCH, R, 32>(a, lds, grid, st);
       case 13: return launch_c32_dbg<T, NCH, R, 13>(a, lds, grid, st);
@@ -398,6 +399,7 @@ int launch_c32(const C32Dev& a0, hipStream_t st) {
       default: break;
     }
   }
+#endif
   return launch_c32_dbg<T, NCH, R, 0>(a, lds, grid, st);
 }
 
@@ -432,10 +434,14 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   a.dbg = dbg;
   static const int ring = getenv("LD_CONV_C32_R") ? atoi(getenv("LD_CONV_C32_R")) : 6;   // experiment: ring depth
   int rc;
+  (void)ring;
   if (p->dtype == LD_F32) rc = launch_c32<float, 1, 6>(a, st);
+  else if (p->dtype == LD_F16) rc = launch_c32<f16, 1, 6>(a, st);
+#ifdef LD_DEBUG_VARIANTS
   else if (ring == 2) rc = launch_c32<bf16, 1, 2>(a, st);
   else if (ring == 3) rc = launch_c32<bf16, 1, 3>(a, st);
   else if (ring == 4) rc = launch_c32<bf16, 1, 4>(a, st);
+#endif
   else rc = launch_c32<bf16, 1, 6>(a, st);
   return rc == LD_OK ? 1 : rc;
 }

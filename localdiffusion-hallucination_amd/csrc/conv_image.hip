@@ -4,7 +4,7 @@
 // too ragged for the MFMA K dimension, so this is a VALU kernel: two output pixels per thread,
 // 2 x 32 accumulators, the input halo and the transposed weights [tap][32] in LDS (broadcast reads).
 // Optional epilogue: GroupNorm statistics of the result (conditioning encoder).
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 constexpr int TS = 16;       // tile = 16 columns x 32 rows, 256 threads, TWO output rows per thread
@@ -120,8 +120,9 @@ __global__ void stem_pack_kernel(const float* __restrict__ w, unsigned short* __
   out[STEM_NCHK * 2 * 64 * 8 + slot] = __builtin_bit_cast(unsigned short, lo);
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
-                                                             const float* __restrict__ bias, bf16* out, int B, int Cin,
+                                                             const float* __restrict__ bias, T* out, int B, int Cin,
                                                              int H, int W, int tiles_x, int ntiles) {
   constexpr int KS = 7, PAD = 3, TSX = 16, TSY = 32, HSX = TSX + KS - 1 + 1, HSY = TSY + KS - 1, NCHK = STEM_NCHK;
   constexpr int NIN = 3 * HSY * HSX, NLD = (NIN + 255) / 256;
@@ -204,11 +205,11 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(const float* __rest
       }
       const int gy = y0 + row;
       if (gy < H && gx < W) {
-        bf16* op = out + (((size_t)b * H + gy) * W + gx) * CO;
+        T* op = out + (((size_t)b * H + gy) * W + gx) * CO;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           float r4[4] = {acc[m][0] + bv[m].x, acc[m][1] + bv[m].y, acc[m][2] + bv[m].z, acc[m][3] + bv[m].w};
-          store4<bf16>(op + m * 16 + kq * 4, r4);
+          store4<T>(op + m * 16 + kq * 4, r4);
         }
       }
     }
@@ -236,9 +237,8 @@ extern "C" int ld_conv_image(const float* x, const float* w, const float* bias, 
   LD_REQUIRE(ksize == 3 || ksize == 7, "ld_conv_image: ksize %d (3 or 7)", ksize);
   LD_REQUIRE(!out_stats || (out_groups > 0 && 32 % out_groups == 0), "ld_conv_image: out_groups %d", out_groups);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == LD_F32) return run<float>(x, w, bias, out, out_stats, out_groups, B, Cin, H, W, ksize, st);
-  if (dtype == LD_BF16) return run<bf16>(x, w, bias, out, out_stats, out_groups, B, Cin, H, W, ksize, st);
-  return ld_fail(LD_EINVAL, "ld_conv_image: bad dtype %d", dtype);
+  LD_REQUIRE(ld_dtype_ok(dtype), "ld_conv_image: bad dtype %d", dtype);
+  return LD_DISPATCH(dtype, run<T>(x, w, bias, out, out_stats, out_groups, B, Cin, H, W, ksize, st));
 }
 
 extern "C" size_t ld_stem_packed_bytes(void) { return (size_t)STEM_PACKED_U16 * sizeof(unsigned short); }
@@ -253,14 +253,18 @@ extern "C" int ld_pack_stem_weight(const float* w_oihw, void* out_packed, int Ci
 }
 
 extern "C" int ld_conv_stem(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H,
-                            int W, void* stream) {
+                            int W, int dtype, void* stream) {
   LD_REQUIRE(x && w_packed && bias && out, "ld_conv_stem: null pointer");
+  LD_REQUIRE(ld_dtype_16(dtype), "ld_conv_stem: 16-bit storage only (fp32 uses ld_conv_image), got dtype %d", dtype);
   LD_REQUIRE(Cin >= 1 && Cin <= 3 && B > 0 && H > 0 && W > 0, "ld_conv_stem: bad shape (Cin %d)", Cin);
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 31) / 32, ntiles = tiles_x * tiles_y;
   int G = (512 + B - 1) / B;                             // ~2 persistent workgroups per CU
   if (G > ntiles) G = ntiles;
-  LD_LAUNCH(conv_stem_mfma_kernel, dim3(G, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-                     (const uint4*)w_packed, bias, (bf16*)out, B, Cin, H, W, tiles_x, ntiles);
+  LD_DISPATCH16(dtype, [&] {
+    LD_LAUNCH(conv_stem_mfma_kernel<T>, dim3(G, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+              (const uint4*)w_packed, bias, (T*)out, B, Cin, H, W, tiles_x, ntiles);
+    return 0;
+  }());
   LD_LAUNCH_CHECK("conv_stem");
   return LD_OK;
 }

@@ -6,7 +6,7 @@
 //
 // Pure HBM streaming: 16 B per lane, coefficient tables (2*C floats per operand) built per block
 // from the fp64 statistics.  grid = (pixel blocks, B).
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 struct GnDev {
@@ -140,7 +140,6 @@ extern "C" int ld_gn_apply(const ld_gn_apply_args* p, void* stream) {
   g.final_act = p->final_act; g.pool = p->pool; g.out = p->out;
   g.B = p->B; g.H = p->H; g.W = p->W; g.t_ptr = p->t_ptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (p->dtype == LD_F32) return run<float>(g, st);
-  if (p->dtype == LD_BF16) return run<bf16>(g, st);
-  return ld_fail(LD_EINVAL, "ld_gn_apply: bad dtype %d", p->dtype);
+  LD_REQUIRE(ld_dtype_ok(p->dtype), "ld_gn_apply: bad dtype %d", p->dtype);
+  return LD_DISPATCH(p->dtype, run<T>(g, st));
 }

@@ -11,7 +11,7 @@
 // two pixel rows of 32 contiguous channels per instruction -- coalesced, no transpose, exact fp32
 // (the instruction is a k-ordered fmaf chain).  Partial results per pixel chunk are written out
 // and reduced in the fold kernel (deterministic; no float atomics).
-#include "common.cuh"
+#include "common.hip.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -126,7 +126,8 @@ __device__ __forceinline__ uint2 tr_read8(const char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-__global__ __launch_bounds__(256) void ctx_mfma_kernel(const bf16* __restrict__ qkv, const unsigned* __restrict__ kmax_enc,
+template <typename T>
+__global__ __launch_bounds__(256) void ctx_mfma_kernel(const T* __restrict__ qkv, const unsigned* __restrict__ kmax_enc,
                                                        float* __restrict__ ctx_part, int n, int heads, int nchunks) {
   __shared__ __attribute__((aligned(16))) char s_p[TN * CROW];
   __shared__ __attribute__((aligned(16))) char s_v[TN * CROW];
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const bf16* __restrict__ 
   for (int e = 0; e < 8; ++e) z[e] = 0.f;
   const int npc = (n + nchunks - 1) / nchunks;
   const int lo = ck * npc, hi = min(n, lo + npc);
-  const bf16* kbase = qkv + (size_t)b * n * 3 * hidden + hidden + h * 32 + c8 * 8;
+  const T* kbase = qkv + (size_t)b * n * 3 * hidden + hidden + h * 32 + c8 * 8;
   const int dt = wv >> 1, et = wv & 1;
   const int tq = (lane >> 2) & 3, tp = lane & 3;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -159,14 +160,15 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const bf16* __restrict__ 
       const int r = prow + 64 * it, p = p0 + r;
       uint4 pk = make_uint4(0u, 0u, 0u, 0u), vv = pk;
       if (p < hi) {
-        const bf16* rp = kbase + (size_t)p * 3 * hidden;
+        const T* rp = kbase + (size_t)p * 3 * hidden;
         const uint4 kk = *reinterpret_cast<const uint4*>(rp);
         vv = *reinterpret_cast<const uint4*>(rp + hidden);
         float f[8];
-        unpack16<bf16>(kk, f);
+        unpack16<T>(kk, f);
+        // P is stored scaled by 2^pshift (fp16: keeps small weights out of the subnormals; Z carries the same factor)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { f[e] = __expf(f[e] - km[e]); z[e] += f[e]; }
-        pk = pack16<bf16>(f);
+        for (int e = 0; e < 8; ++e) { f[e] = __expf(f[e] - km[e] + DT<T>::pshift * 0.6931471805599453f); z[e] += f[e]; }
+        pk = pack16<T>(f);
       }
       *reinterpret_cast<uint4*>(s_p + r * CROW + c8 * 16) = pk;
       *reinterpret_cast<uint4*>(s_v + r * CROW + c8 * 16) = vv;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void ctx_mfma_kernel(const bf16* __restrict__ 
       const char* pb = s_v + row * CROW + et * 32 + tp * 8;
       const uint2 a1 = tr_read8(pa), a2 = tr_read8(pa + 16 * CROW);
       const uint2 b1 = tr_read8(pb), b2 = tr_read8(pb + 16 * CROW);
-      mma16<bf16>(acc, make_uint4(a1.x, a1.y, a2.x, a2.y), make_uint4(b1.x, b1.y, b2.x, b2.y));
+      mma16<T>(acc, make_uint4(a1.x, a1.y, a2.x, a2.y), make_uint4(b1.x, b1.y, b2.x, b2.y));
     }
   }
   float* dst = ctx_part + (((size_t)b * heads + h) * nchunks + ck) * CTX_STRIDE;
@@ -350,14 +352,13 @@ extern "C" int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const floa
   LD_REQUIRE(ctx_part && w_out && w_packed && B > 0 && heads > 0 && nchunks > 0 && nchunks <= MAXCH,
              "ld_linattn_ctxfold: bad args (nchunks 1..128)");
   LD_REQUIRE(dim_head == 32 && C % 16 == 0, "ld_linattn_ctxfold: dim_head 32, C %% 16 == 0");
-  LD_REQUIRE(!(perm && dtype != LD_BF16), "ld_linattn_ctxfold: perm=1 is the bf16 chained-operand order");
+  LD_REQUIRE(ld_dtype_ok(dtype), "ld_linattn_ctxfold: bad dtype %d", dtype);
+  LD_REQUIRE(!(perm && !ld_dtype_16(dtype)), "ld_linattn_ctxfold: perm=1 is the 16-bit chained-operand order");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == LD_F32)
-    LD_LAUNCH(ctxfold_kernel<float>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (float*)w_packed, C, heads, perm);
-  else if (dtype == LD_BF16)
-    LD_LAUNCH(ctxfold_kernel<bf16>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (bf16*)w_packed, C, heads, perm);
-  else
-    return ld_fail(LD_EINVAL, "ld_linattn_ctxfold: bad dtype %d", dtype);
+  LD_DISPATCH(dtype, [&] {
+    LD_LAUNCH(ctxfold_kernel<T>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (T*)w_packed, C, heads, perm);
+    return 0;
+  }());
   LD_LAUNCH_CHECK("linattn_ctxfold");
   return LD_OK;
 }
@@ -380,10 +381,12 @@ extern "C" int ld_linattn_kmax(const void* qkv, uint32_t* kmax_enc, int B, int n
     LD_REQUIRE(rows >= 1, "ld_linattn_kmax: hidden %d too large", hidden);
     LD_LAUNCH(kmax_kernel<float>, grid, dim3(256), rows * hidden * sizeof(float), st,
                        (const float*)qkv, kmax_enc, n, hidden, nparts);
-  } else if (dtype == LD_BF16) {
+  } else if (ld_dtype_16(dtype)) {
     const int rows = 256 / (hidden / 8);
-    LD_LAUNCH(kmax_kernel<bf16>, grid, dim3(256), rows * hidden * sizeof(float), st,
-                       (const bf16*)qkv, kmax_enc, n, hidden, nparts);
+    LD_DISPATCH16(dtype, [&] {
+      LD_LAUNCH(kmax_kernel<T>, grid, dim3(256), rows * hidden * sizeof(float), st, (const T*)qkv, kmax_enc, n, hidden, nparts);
+      return 0;
+    }());
   } else {
     return ld_fail(LD_EINVAL, "ld_linattn_kmax: bad dtype %d", dtype);
   }
@@ -399,8 +402,11 @@ extern "C" int ld_linattn_ctx(const void* qkv, const uint32_t* kmax_enc, float* 
   dim3 grid(nchunks, heads, B);
   if (dtype == LD_F32)
     LD_LAUNCH(ctx_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, kmax_enc, ctx_part, n, heads, nchunks);
-  else if (dtype == LD_BF16)
-    LD_LAUNCH(ctx_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, kmax_enc, ctx_part, n, heads, nchunks);
+  else if (ld_dtype_16(dtype))
+    LD_DISPATCH16(dtype, [&] {
+      LD_LAUNCH(ctx_mfma_kernel<T>, grid, dim3(256), 0, st, (const T*)qkv, kmax_enc, ctx_part, n, heads, nchunks);
+      return 0;
+    }());
   else
     return ld_fail(LD_EINVAL, "ld_linattn_ctx: bad dtype %d", dtype);
   LD_LAUNCH_CHECK("linattn_ctx");
@@ -419,17 +425,16 @@ extern "C" int ld_linattn_ctx_reduce(const float* ctx_part, int nchunks, float* 
 
 extern "C" int ld_linattn_fold(const float* ctxn, const float* w_out, void* w_packed, int B, int C, int heads,
                                int dim_head, int perm, int dtype, void* stream) {
-  LD_REQUIRE(!(perm && dtype != LD_BF16), "ld_linattn_fold: perm=1 is the bf16 chained-operand order");
+  LD_REQUIRE(ld_dtype_ok(dtype), "ld_linattn_fold: bad dtype %d", dtype);
+  LD_REQUIRE(!(perm && !ld_dtype_16(dtype)), "ld_linattn_fold: perm=1 is the 16-bit chained-operand order");
   LD_REQUIRE(ctxn && w_out && w_packed && B > 0, "ld_linattn_fold: bad args");
   LD_REQUIRE(dim_head == 32 && C % 16 == 0, "ld_linattn_fold: dim_head 32, C %% 16 == 0");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const size_t lds = (size_t)heads * 32 * 33 * sizeof(float);
-  if (dtype == LD_F32)
-    LD_LAUNCH(fold_kernel<float>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (float*)w_packed, C, heads, perm);
-  else if (dtype == LD_BF16)
-    LD_LAUNCH(fold_kernel<bf16>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (bf16*)w_packed, C, heads, perm);
-  else
-    return ld_fail(LD_EINVAL, "ld_linattn_fold: bad dtype %d", dtype);
+  LD_DISPATCH(dtype, [&] {
+    LD_LAUNCH(fold_kernel<T>, dim3(C / 16, B), dim3(256), lds, st, ctxn, w_out, (T*)w_packed, C, heads, perm);
+    return 0;
+  }());
   LD_LAUNCH_CHECK("linattn_fold");
   return LD_OK;
 }

@@ -1,4 +1,4 @@
-// Fused linear attention for bf16 storage: q, k and v are NEVER written to HBM.
+// Fused linear attention for 16-bit storage (bf16 / fp16): q, k and v are NEVER written to HBM.
 //
 // LinearAttention.forward (ddpm.py:234-251) reads x and produces to_out(ctx^T softmax_d(q)) with
 // ctx = softmax_n(k) v^T.  The unfused path materialises the [B,n,384] qkv tensor (403 MB at
@@ -14,7 +14,7 @@
 //        operand (cdna_hip_programming.md section 3: k-slot (lane>>4, e) of step s is q channel
 //        32s + 16(e>>2) + 4(lane>>4) + (e&3); ld_linattn_fold(perm=1) writes M_b in that order),
 //        + bias, RMSNorm, + x (ddpm.py:229-232,249,251,425).
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -30,14 +30,14 @@ __device__ __forceinline__ uint2 tr8(const char* p) {
 }
 
 struct KvCtxArgs {
-  const bf16* x;
+  const void* x;
   const uint4* wkv;     // [heads][NCH][4 tiles: k0 k1 v0 v1][64] fragments (g*sqrt(C) folded in)
   float* ctx_part;
   int n, C, heads, nchunks;
   const float* kshift;   // optional [heads*32]: softmax_n(k) shift per k-channel (>= max_n k): single-sweep mode
 };
 
-template <int NCH>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
   constexpr int PLANE = KTN * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
     for (int r = 0; r < 4; ++r) { cmax[m][r] = -INFINITY; mloc[m][r] = 0.f; zs[m][r] = 0.f; }
   f32x4 cacc = {0.f, 0.f, 0.f, 0.f};
   const int dt = wv >> 1, et = wv & 1, tq = (lane >> 2) & 3, tp = lane & 3;
-  const bf16* xb = a.x + (size_t)b * n * C;
+  const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * n * C;
 
   // register-staged prefetch of the next x tile (T14): loads of tile k+1 fly during tile k's MFMAs.
   // The tile sequence is pass 0: lo..hi, then pass 1: lo..hi again.
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
           const int qq = (it * 4 + wv) * 16 + li;
           const uint4 raw = xr[c][it];
           float v[8];
-          unpack16<bf16>(raw, v);
+          unpack16<T>(raw, v);
 #pragma unroll
           for (int e = 0; e < 8; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
           *reinterpret_cast<uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16) = raw;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
         for (int c = 0; c < NCH; ++c) {
           const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
 #pragma unroll
-          for (int m = 0; m < 4; ++m) mma16<bf16>(acc[m], A[m][c], Bf);
+          for (int m = 0; m < 4; ++m) mma16<T>(acc[m], A[m][c], Bf);
         }
         const float rinv = s_rinv[qq];
         if (pass == 0) {
@@ -135,14 +135,14 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
             float pv[4], vv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              pv[r] = valid ? __expf(acc[m][r] * rinv - mloc[m][r]) : 0.f;
+              pv[r] = valid ? __expf(acc[m][r] * rinv - mloc[m][r] + DT<T>::pshift * 0.6931471805599453f) : 0.f;
               vv[r] = valid ? acc[2 + m][r] * rinv : 0.f;
               zs[m][r] += pv[r];
             }
             *reinterpret_cast<uint2*>(s_p + qq * PROW + (16 * m + 4 * kq) * 2) =
-                make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+                make_uint2(pack2<T>(pv[0], pv[1]), pack2<T>(pv[2], pv[3]));
             *reinterpret_cast<uint2*>(s_v + qq * PROW + (16 * m + 4 * kq) * 2) =
-                make_uint2(pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3]));
+                make_uint2(pack2<T>(vv[0], vv[1]), pack2<T>(vv[2], vv[3]));
           }
         }
       }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
           const char* pb = s_v + row * PROW + et * 32 + tp * 8;
           const uint2 a1 = tr8(pa), a2 = tr8(pa + 16 * PROW);
           const uint2 b1 = tr8(pb), b2 = tr8(pb + 16 * PROW);
-          mma16<bf16>(cacc, make_uint4(a1.x, a1.y, a2.x, a2.y), make_uint4(b1.x, b1.y, b2.x, b2.y));
+          mma16<T>(cacc, make_uint4(a1.x, a1.y, a2.x, a2.y), make_uint4(b1.x, b1.y, b2.x, b2.y));
         }
       }
     }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
 constexpr int SROW = 32;                  // pixels per wave-private P/V strip (= one MFMA K-step)
 
 // SINGLE (caller-supplied shift): the max sweep, its registers and its code are compiled out.
-template <int NCH, bool SINGLE>
+template <typename T, int NCH, bool SINGLE>
 __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
   constexpr int PLANE = KTN * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) cacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int tq = (lane >> 2) & 3, tp = lane & 3;
-  const bf16* xb = a.x + (size_t)b * n * C;
+  const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * n * C;
   char* my_p = s_pv + (wv * 2 + 0) * SROW * PROW;
   char* my_v = s_pv + (wv * 2 + 1) * SROW * PROW;
 
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) m2[m][r] = mloc[m][r] * LOG2E;
+    for (int r = 0; r < 4; ++r) m2[m][r] = mloc[m][r] * LOG2E - DT<T>::pshift;   // P stored as P * 2^pshift (fp16 range)
   for (int pass = first_pass; pass < 2; ++pass) {
     for (int p0 = lo; p0 < hi; p0 += KTN) {
       __syncthreads();                                   // every wave is done with the previous x tile
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
           const int qq = (it * 4 + wv) * 16 + li;
           const uint4 raw = xr[c][it];
           float v[8];
-          unpack16<bf16>(raw, v);
+          unpack16<T>(raw, v);
 #pragma unroll
           for (int e = 0; e < 8; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
           *reinterpret_cast<uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16) = raw;
@@ -305,8 +305,8 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
           for (int c = 0; c < NCH; ++c) {
             const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
-            mma16<bf16>(k0, A[0][c], Bf);
-            mma16<bf16>(k1, A[1][c], Bf);
+            mma16<T>(k0, A[0][c], Bf);
+            mma16<T>(k1, A[1][c], Bf);
           }
           if (p0 + qq < hi) {
             const float rinv = s_rinv[qq];
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
               for (int c = 0; c < NCH; ++c) {
                 const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) mma16<bf16>(acc[m], A[m][c], Bf);
+                for (int m = 0; m < 4; ++m) mma16<T>(acc[m], A[m][c], Bf);
               }
               const float rinv = s_rinv[qq], rinv2 = rinv * LOG2E;
               const int row = half * 16 + li;
@@ -348,9 +348,9 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
                   zs[m][r] += pv[r];
                 }
                 *reinterpret_cast<uint2*>(my_p + row * PROW + (16 * m + 4 * kq) * 2) =
-                    make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+                    make_uint2(pack2<T>(pv[0], pv[1]), pack2<T>(pv[2], pv[3]));
                 *reinterpret_cast<uint2*>(my_v + row * PROW + (16 * m + 4 * kq) * 2) =
-                    make_uint2(pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3]));
+                    make_uint2(pack2<T>(vv[0], vv[1]), pack2<T>(vv[2], vv[3]));
               }
             }
           };
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int et = 0; et < 2; ++et) mma16<bf16>(cacc[dt][et], Af[dt], Bf2[et]);
+            for (int et = 0; et < 2; ++et) mma16<T>(cacc[dt][et], Af[dt], Bf2[et]);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the strip is rewritten
         }
       }
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { mloc[m][r] = wave16_max(cmax[m][r]); m2[m][r] = mloc[m][r] * LOG2E; }
+        for (int r = 0; r < 4; ++r) { mloc[m][r] = wave16_max(cmax[m][r]); m2[m][r] = mloc[m][r] * LOG2E - DT<T>::pshift; }
     }
   }
   float* dst = a.ctx_part + (((size_t)b * a.heads + h) * a.nchunks + ck) * CTX_STRIDE;
@@ -406,18 +406,18 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 constexpr int LINOUT_TPB = 1;             // pixel tiles (of 128) per workgroup in linout_kernel (4 measured slower: fewer workgroups)
 
 struct LinOutArgs {
-  const bf16* x;
+  const void* x;
   const uint4* wq;       // [NCH][8][64] fragments of W_q (g*sqrt(C) folded in)
   const uint4* mfold;    // per batch: [4 k-steps][MT2][64] fragments of M_b in chained-operand order
   const float* bias;
   const float* g2;
-  bf16* out;
+  void* out;
   int n, C;
   float q_scale;
   const float* qshift;   // optional [4]: per head an upper bound of q (softmax_d shift): skips the max reduction
 };
 
-template <int NCH>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
   constexpr int NW = 2, NPT = 64 * NW, PLANE = NPT * 16, MT2 = 2 * NCH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kq = lane >> 4;
   const int n = a.n, C = a.C;
-  const bf16* xb = a.x + (size_t)b * n * C;
+  const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * n * C;
   // W_q and M_b are staged once per workgroup and reused for LINOUT_TPB consecutive pixel tiles
   for (int u = tid; u < NCH * 8 * 64; u += 256) *reinterpret_cast<uint4*>(s_wq + u * 16) = a.wq[u];
   const uint4* mf = a.mfold + (size_t)b * 4 * MT2 * 64;
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
       if (p < n) {
         raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * C + c * 32 + kq * 8);
         float v[8];
-        unpack16<bf16>(raw, v);
+        unpack16<T>(raw, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
       }
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
       const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
 #pragma unroll
       for (int m = 0; m < 8; ++m)
-        mma16<bf16>(q[m], *reinterpret_cast<const uint4*>(s_wq + (c * 8 + m) * 1024 + lane * 16), Bf);
+        mma16<T>(q[m], *reinterpret_cast<const uint4*>(s_wq + (c * 8 + m) * 1024 + lane * 16), Bf);
     }
     const float rinv2 = s_rinv[qq] * 1.4426950408889634f;  // softmax_d(q) = exp2(q*log2e - shift*log2e) / sum
     uint4 B2[4];
@@ -515,8 +515,8 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
       const float sc = a.q_scale * __builtin_amdgcn_rcpf(sum);
-      B2[hh] = make_uint4(pack_bf16x2(v0[0] * sc, v0[1] * sc), pack_bf16x2(v0[2] * sc, v0[3] * sc),
-                          pack_bf16x2(v1[0] * sc, v1[1] * sc), pack_bf16x2(v1[2] * sc, v1[3] * sc));
+      B2[hh] = make_uint4(pack2<T>(v0[0] * sc, v0[1] * sc), pack2<T>(v0[2] * sc, v0[3] * sc),
+                          pack2<T>(v1[0] * sc, v1[1] * sc), pack2<T>(v1[2] * sc, v1[3] * sc));
     }
     f32x4 o[MT2];
 #pragma unroll
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int m2 = 0; m2 < MT2; ++m2)
-        mma16<bf16>(o[m2], *reinterpret_cast<const uint4*>(s_mf + (s * MT2 + m2) * 1024 + lane * 16), B2[s]);
+        mma16<T>(o[m2], *reinterpret_cast<const uint4*>(s_mf + (s * MT2 + m2) * 1024 + lane * 16), B2[s]);
     float ss = 0.f;
     float y[MT2][4];
 #pragma unroll
@@ -545,45 +545,39 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
         const float4 gv = gvr[m2];
         // the residual x is already in the staging tile: channels co..co+3 = chunk m2/2, fragment 2*(m2&1) + kq/2
         float xr[4];
-        load4<bf16>(reinterpret_cast<const bf16*>(s_x + ((m2 >> 1) * 4 + (m2 & 1) * 2 + (kq >> 1)) * PLANE + qq * 16 + (kq & 1) * 8), xr);
+        load4<T>(reinterpret_cast<const T*>(s_x + ((m2 >> 1) * 4 + (m2 & 1) * 2 + (kq >> 1)) * PLANE + qq * 16 + (kq & 1) * 8), xr);
         float r4[4] = {y[m2][0] * inv * gv.x + xr[0], y[m2][1] * inv * gv.y + xr[1],
                        y[m2][2] * inv * gv.z + xr[2], y[m2][3] * inv * gv.w + xr[3]};
-        store4<bf16>(a.out + ((size_t)b * n + p) * C + co, r4);
+        store4<T>(reinterpret_cast<T*>(a.out) + ((size_t)b * n + p) * C + co, r4);
       }
     }
   }
   }  // tiles of this workgroup
 }
-}  // namespace
 
-extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const float* kshift, float* ctx_part, int B,
-                                int n, int C, int heads, int dim_head, int nchunks, int dtype, void* stream) {
-  LD_REQUIRE(x && wkv_packed && ctx_part && B > 0 && n > 0 && nchunks > 0, "ld_linattn_kvctx: bad args");
-  LD_REQUIRE(dtype == LD_BF16, "ld_linattn_kvctx: bf16 storage only (fp32 uses the unfused path)");
-  LD_REQUIRE(dim_head == 32 && (C == 32 || C == 64 || C == 128), "ld_linattn_kvctx: dim_head 32, C in {32,64,128}");
-  LD_REQUIRE(kshift == nullptr || heads == 4, "ld_linattn_kvctx: the single-sweep mode (kshift) needs heads == 4");
-  KvCtxArgs a{(const bf16*)x, (const uint4*)wkv_packed, ctx_part, n, C, heads, nchunks, kshift};
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int nch = C / 32;
+template <typename T>
+int kvctx_launch(const KvCtxArgs& a, int B, hipStream_t st) {
+  const int nch = a.C / 32, heads = a.heads, nchunks = a.nchunks;
+  const float* kshift = a.kshift;
   static const int no_wph = getenv("LD_KVCTX_V1") ? 1 : 0;
   if (heads == 4 && (!no_wph || kshift)) {               // wave-per-head schedule
     const size_t lds2 = (size_t)nch * 4 * KTN * 16 + KTN * sizeof(float) + 4 * 2 * SROW * PROW;
-    static bool ok2[5] = {false, false, false, false, false};
+    static bool ok4 = false;
     dim3 grid2(nchunks, B);
     if (nch == 1) {
-      if (kshift) LD_LAUNCH((kvctx_wph_kernel<1, true>), grid2, dim3(256), lds2, st, a);
-      else LD_LAUNCH((kvctx_wph_kernel<1, false>), grid2, dim3(256), lds2, st, a);
+      if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 1, true>), grid2, dim3(256), lds2, st, a);
+      else LD_LAUNCH((kvctx_wph_kernel<T, 1, false>), grid2, dim3(256), lds2, st, a);
     } else if (nch == 2) {
-      if (kshift) LD_LAUNCH((kvctx_wph_kernel<2, true>), grid2, dim3(256), lds2, st, a);
-      else LD_LAUNCH((kvctx_wph_kernel<2, false>), grid2, dim3(256), lds2, st, a);
+      if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 2, true>), grid2, dim3(256), lds2, st, a);
+      else LD_LAUNCH((kvctx_wph_kernel<T, 2, false>), grid2, dim3(256), lds2, st, a);
     } else {
-      if (!ok2[4]) {
-        LD_HIP(ld_allow_lds((kvctx_wph_kernel<4, true>), lds2));
-        LD_HIP(ld_allow_lds((kvctx_wph_kernel<4, false>), lds2));
-        ok2[4] = true;
+      if (!ok4) {
+        LD_HIP(ld_allow_lds((kvctx_wph_kernel<T, 4, true>), lds2));
+        LD_HIP(ld_allow_lds((kvctx_wph_kernel<T, 4, false>), lds2));
+        ok4 = true;
       }
-      if (kshift) LD_LAUNCH((kvctx_wph_kernel<4, true>), grid2, dim3(256), lds2, st, a);
-      else LD_LAUNCH((kvctx_wph_kernel<4, false>), grid2, dim3(256), lds2, st, a);
+      if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 4, true>), grid2, dim3(256), lds2, st, a);
+      else LD_LAUNCH((kvctx_wph_kernel<T, 4, false>), grid2, dim3(256), lds2, st, a);
     }
     LD_LAUNCH_CHECK("linattn_kvctx(wave-per-head)");
     return LD_OK;
@@ -592,38 +586,54 @@ extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const flo
   const size_t lds = (size_t)nch * 4 * KTN * 16 + 2 * KTN * PROW + KTN * sizeof(float) + 128 * sizeof(float);
   static bool allowed[5] = {false, false, false, false, false};
   if (nch == 1) {
-    LD_LAUNCH(kvctx_kernel<1>, grid, dim3(256), lds, st, a);
+    LD_LAUNCH((kvctx_kernel<T, 1>), grid, dim3(256), lds, st, a);
   } else if (nch == 2) {
-    if (!allowed[2]) { LD_HIP(ld_allow_lds(kvctx_kernel<2>, lds)); allowed[2] = true; }
-    LD_LAUNCH(kvctx_kernel<2>, grid, dim3(256), lds, st, a);
+    if (!allowed[2]) { LD_HIP(ld_allow_lds((kvctx_kernel<T, 2>), lds)); allowed[2] = true; }
+    LD_LAUNCH((kvctx_kernel<T, 2>), grid, dim3(256), lds, st, a);
   } else {
-    if (!allowed[4]) { LD_HIP(ld_allow_lds(kvctx_kernel<4>, lds)); allowed[4] = true; }
-    LD_LAUNCH(kvctx_kernel<4>, grid, dim3(256), lds, st, a);
+    if (!allowed[4]) { LD_HIP(ld_allow_lds((kvctx_kernel<T, 4>), lds)); allowed[4] = true; }
+    LD_LAUNCH((kvctx_kernel<T, 4>), grid, dim3(256), lds, st, a);
   }
   LD_LAUNCH_CHECK("linattn_kvctx");
   return LD_OK;
+}
+
+template <typename T>
+int linout_launch(const LinOutArgs& a, int B, hipStream_t st) {
+  const int n = a.n, nch = a.C / 32;
+  dim3 grid((n + 128 * LINOUT_TPB - 1) / (128 * LINOUT_TPB), B);
+  const size_t lds = (size_t)nch * 4 * 128 * 16 + (size_t)nch * 8 * 1024 + (size_t)4 * 2 * nch * 1024 + 128 * sizeof(float);
+  static bool allowed4 = false;
+  if (nch == 1) {
+    LD_LAUNCH((linout_kernel<T, 1>), grid, dim3(256), lds, st, a);
+  } else if (nch == 2) {
+    LD_LAUNCH((linout_kernel<T, 2>), grid, dim3(256), lds, st, a);
+  } else {
+    if (!allowed4) { LD_HIP(ld_allow_lds((linout_kernel<T, 4>), lds)); allowed4 = true; }
+    LD_LAUNCH((linout_kernel<T, 4>), grid, dim3(256), lds, st, a);
+  }
+  LD_LAUNCH_CHECK("linattn_out");
+  return LD_OK;
+}
+}  // namespace
+
+extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const float* kshift, float* ctx_part, int B,
+                                int n, int C, int heads, int dim_head, int nchunks, int dtype, void* stream) {
+  LD_REQUIRE(x && wkv_packed && ctx_part && B > 0 && n > 0 && nchunks > 0, "ld_linattn_kvctx: bad args");
+  LD_REQUIRE(ld_dtype_16(dtype), "ld_linattn_kvctx: 16-bit storage only (fp32 uses the unfused path)");
+  LD_REQUIRE(dim_head == 32 && (C == 32 || C == 64 || C == 128), "ld_linattn_kvctx: dim_head 32, C in {32,64,128}");
+  LD_REQUIRE(kshift == nullptr || heads == 4, "ld_linattn_kvctx: the single-sweep mode (kshift) needs heads == 4");
+  KvCtxArgs a{x, (const uint4*)wkv_packed, ctx_part, n, C, heads, nchunks, kshift};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return LD_DISPATCH16(dtype, kvctx_launch<T>(a, B, st));
 }
 
 extern "C" int ld_linattn_out(const void* x, const void* wq_packed, const float* qshift, const void* mfold,
                               const float* bias, const float* g2, void* out, int B, int n, int C, float q_scale,
                               int dtype, void* stream) {
   LD_REQUIRE(x && wq_packed && mfold && bias && g2 && out && B > 0 && n > 0, "ld_linattn_out: bad args");
-  LD_REQUIRE(dtype == LD_BF16, "ld_linattn_out: bf16 storage only (fp32 uses the unfused path)");
+  LD_REQUIRE(ld_dtype_16(dtype), "ld_linattn_out: 16-bit storage only (fp32 uses the unfused path)");
   LD_REQUIRE(C == 32 || C == 64 || C == 128, "ld_linattn_out: C in {32,64,128}");
-  LinOutArgs a{(const bf16*)x, (const uint4*)wq_packed, (const uint4*)mfold, bias, g2, (bf16*)out, n, C, q_scale, qshift};
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid((n + 128 * LINOUT_TPB - 1) / (128 * LINOUT_TPB), B);
-  const int nch = C / 32;
-  const size_t lds = (size_t)nch * 4 * 128 * 16 + (size_t)nch * 8 * 1024 + (size_t)4 * 2 * nch * 1024 + 128 * sizeof(float);
-  static bool allowed[5] = {false, false, false, false, false};
-  if (nch == 1) {
-    LD_LAUNCH(linout_kernel<1>, grid, dim3(256), lds, st, a);
-  } else if (nch == 2) {
-    LD_LAUNCH(linout_kernel<2>, grid, dim3(256), lds, st, a);
-  } else {
-    if (!allowed[4]) { LD_HIP(ld_allow_lds(linout_kernel<4>, lds)); allowed[4] = true; }
-    LD_LAUNCH(linout_kernel<4>, grid, dim3(256), lds, st, a);
-  }
-  LD_LAUNCH_CHECK("linattn_out");
-  return LD_OK;
+  LinOutArgs a{x, (const uint4*)wq_packed, (const uint4*)mfold, bias, g2, out, n, C, q_scale, qshift};
+  return LD_DISPATCH16(dtype, linout_launch<T>(a, B, reinterpret_cast<hipStream_t>(stream)));
 }

@@ -5,7 +5,7 @@
 //   k=1:  [chunk][mtile][kq][i][e]                         = W[16*mtile+i][chunk*CK+kq*E+e]
 // so that lane l = kq*16+i of a wave reads its A fragment (16 B) at byte offset 16*l of a 1 KiB
 // block: global->LDS staging is a linear copy and LDS fragment reads are conflict-free.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 template <typename T>
@@ -45,12 +45,11 @@ extern "C" int ld_pack_conv_weight(const float* w, const float* scale_in, void* 
   const int bs = 256;
   const unsigned grid = (unsigned)((total + bs - 1) / bs);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == LD_F32)
-    LD_LAUNCH(pack_kernel<float>, dim3(grid), dim3(bs), 0, st, w, scale_in, (float*)out, cout, cin, ksize, unshuffle);
-  else if (dtype == LD_BF16)
-    LD_LAUNCH(pack_kernel<bf16>, dim3(grid), dim3(bs), 0, st, w, scale_in, (bf16*)out, cout, cin, ksize, unshuffle);
-  else
-    return ld_fail(LD_EINVAL, "ld_pack_conv_weight: bad dtype %d", dtype);
+  LD_REQUIRE(ld_dtype_ok(dtype), "ld_pack_conv_weight: bad dtype %d", dtype);
+  LD_DISPATCH(dtype, [&] {
+    LD_LAUNCH(pack_kernel<T>, dim3(grid), dim3(bs), 0, st, w, scale_in, (T*)out, cout, cin, ksize, unshuffle);
+    return 0;
+  }());
   LD_LAUNCH_CHECK("pack_conv_weight");
   return LD_OK;
 }

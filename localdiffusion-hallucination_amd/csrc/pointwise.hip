@@ -1,7 +1,7 @@
 // Pointwise kernels of the reverse process (NCHW fp32 boundary tensors) and the final 1x1 conv.
 // All are HBM-streaming; the per-step coefficients come from a device schedule table indexed
 // through t_ptr so the whole step is HIP-graph replayable.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 constexpr int BS = 256;
@@ -155,8 +155,7 @@ __device__ __forceinline__ void final_conv_pixel(const T* xp, const float* s_w, 
     for (int q = 0; q < 4; ++q) {
       if (c0 + q * E >= Cin) break;
       float v[E];
-      if constexpr (sizeof(T) == 2) unpack16<bf16>(raw[q], v);
-      else unpack16<float>(raw[q], v);
+      unpack16<T>(raw[q], v);
 #pragma unroll
       for (int g = 0; g < E; g += 4) {
         const int c = c0 + q * E + g;
@@ -330,12 +329,11 @@ extern "C" int ld_final_conv(const void* x, const float* w, const float* b, floa
   LD_REQUIRE(x && w && b && out_nchw, "ld_final_conv: null pointer");
   LD_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 8 == 0, "ld_final_conv: Cout %d (1..4), Cin %d (multiple of 8)", Cout, Cin);
   const long npix = (long)B * H * W;
-  if (dtype == LD_F32)
-    LD_LAUNCH(final_conv_kernel<float>, dim3(nblocks(npix)), dim3(BS), Cin * Cout * sizeof(float), ST(stream), (const float*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
-  else if (dtype == LD_BF16)
-    LD_LAUNCH(final_conv_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), Cin * Cout * sizeof(float), ST(stream), (const bf16*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
-  else
-    return ld_fail(LD_EINVAL, "ld_final_conv: bad dtype %d", dtype);
+  LD_REQUIRE(ld_dtype_ok(dtype), "ld_final_conv: bad dtype %d", dtype);
+  LD_DISPATCH(dtype, [&] {
+    LD_LAUNCH(final_conv_kernel<T>, dim3(nblocks(npix)), dim3(BS), Cin * Cout * sizeof(float), ST(stream), (const T*)x, w, b, out_nchw, H * W, Cin, Cout, npix);
+    return 0;
+  }());
   LD_LAUNCH_CHECK("final_conv");
   return LD_OK;
 }
@@ -350,17 +348,15 @@ extern "C" int ld_final_step_at(const void* x, const float* w, const float* b, f
              (long)noise_first);
   LD_REQUIRE(Cout >= 1 && Cout <= 4 && Cin % 8 == 0, "ld_final_step: Cout %d (1..4), Cin %d (multiple of 8)", Cout, Cin);
   LD_REQUIRE(objective >= 0 && objective <= 2, "ld_final_step: objective %d", objective);
-  LD_REQUIRE(dtype == LD_F32 || dtype == LD_BF16, "ld_final_step: bad dtype %d", dtype);
+  LD_REQUIRE(ld_dtype_ok(dtype), "ld_final_step: bad dtype %d", dtype);
   const long npix = (long)B * H * W;
   const size_t lds = (size_t)Cin * Cout * sizeof(float);
-  if (dtype == LD_F32)
-    LD_LAUNCH(final_step_kernel<float>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const float*)x, w, b, model_out,
-                       x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_base, (long)noise_tmul,
-                       (long)noise_first, keep_mask, H * W, Cin, Cout, npix);
-  else
-    LD_LAUNCH(final_step_kernel<bf16>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const bf16*)x, w, b, model_out,
-                       x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_base, (long)noise_tmul,
-                       (long)noise_first, keep_mask, H * W, Cin, Cout, npix);
+  LD_DISPATCH(dtype, [&] {
+    LD_LAUNCH(final_step_kernel<T>, dim3(nblocks(npix)), dim3(BS), lds, ST(stream), (const T*)x, w, b, model_out,
+              x_t, x0_out, sched, t_ptr, lo, hi, objective, (unsigned long long)seed, (long)noise_base, (long)noise_tmul,
+              (long)noise_first, keep_mask, H * W, Cin, Cout, npix);
+    return 0;
+  }());
   LD_LAUNCH_CHECK("final_step");
   return LD_OK;
 }

@@ -1,5 +1,5 @@
 // Runtime plumbing of the C-ABI: error string, device info, HIP-graph capture, events.
-#include "common.cuh"
+#include "common.hip.h"
 
 static thread_local char g_err[512] = "";
 

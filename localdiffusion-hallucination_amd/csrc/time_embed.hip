@@ -3,7 +3,7 @@
 // Both depend only on t, so the host evaluates them ONCE for all T timesteps into tables
 // ([T, time_dim] and [T, 2C] per block) and the per-step kernels index the table through t_ptr.
 // One workgroup per timestep; tiny GEMVs, fp32 throughout.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 __global__ void time_mlp_kernel(const int* __restrict__ times, const float* __restrict__ freqs, int dim,

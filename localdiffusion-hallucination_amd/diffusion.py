@@ -71,7 +71,8 @@ class _SubBatches:
         cabi.check(lib.ld_final_step_at(xa.data_ptr(), wf.data_ptr(), bf.data_ptr(), sp.model_out.data_ptr(),
                                         sp.x_in.data_ptr(), None, gd._sched_table().data_ptr(), sp.t_dev.data_ptr(),
                                         lo, hi, cabi.OBJ[gd.objective], gd.noise_seed, base, -1,
-                                        0 if self.shared_noise else i * sp.x_in.numel(), cabi.ptr(self.masks.get(i)),
+                                        gd.noise_offset + (0 if self.shared_noise else i * sp.x_in.numel()),
+                                        cabi.ptr(self.masks.get(i)),
                                         B_, H_, W_, wf.shape[1], C_, sp.dt, st), "final_step")
         cabi.check(lib.ld_step_add(sp.t_dev.data_ptr(), -1, st), "step_add")
 
@@ -81,7 +82,7 @@ class _SubBatches:
         happen inside a capture)."""
         import ctypes as C
         lib, st = cabi.lib(), gs.cuda_stream
-        key = (i, float(lo), float(hi), base, self.gd.noise_seed)
+        key = (i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)
         if key in self.graphs:
             return 0
         ran = 0
@@ -101,7 +102,7 @@ class _SubBatches:
 
     def _trim(self, lo, hi, base):
         """Many different noise bases (a bench that wraps over samples) would pile up graphs: start over."""
-        if (0, float(lo), float(hi), base, self.gd.noise_seed) in self.graphs or len(self.graphs) < 8 * self.S:
+        if (0, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset) in self.graphs or len(self.graphs) < 8 * self.S:
             return
         torch.cuda.synchronize()
         for g in self.graphs.values():
@@ -127,7 +128,7 @@ class _SubBatches:
                     sp.run_cond(st)
                 sp.set_step(t_start)
                 todo[i] -= self._ensure_graph(i, gs, lo, hi, base)
-                ex[i] = self.graphs[(i, float(lo), float(hi), base, self.gd.noise_seed)]
+                ex[i] = self.graphs[(i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)]
         # interleave the launches so that neither hardware queue runs ahead of the other
         for k in range(max(todo)):
             for i, gs in enumerate(self.streams):
@@ -156,7 +157,7 @@ class _SubBatches:
         for i in range(1, self.S):
             with torch.cuda.stream(self.streams[i]):
                 self._ensure_graph(i, self.streams[i], lo, hi, base)
-            g = self.graphs[(i, float(lo), float(hi), base, self.gd.noise_seed)]
+            g = self.graphs[(i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)]
             for _ in range(n_steps + 2):
                 cabi.check(lib.ld_graph_launch(g, self.streams[i].cuda_stream), "graph_launch")
         sp, gs = self.plans[0], self.streams[0]
@@ -166,7 +167,7 @@ class _SubBatches:
             for k in range(n_steps):
                 sp.set_step(t_start - k)
                 sp.run_main_timed(st, acc)
-                cabi.check(lib.ld_randn_at(z.data_ptr(), z.numel(), 0, gd.noise_seed, base, -1, sp.t_dev.data_ptr(), st), "randn")
+                cabi.check(lib.ld_randn_at(z.data_ptr(), z.numel(), gd.noise_offset, gd.noise_seed, base, -1, sp.t_dev.data_ptr(), st), "randn")
                 if 0 in self.masks:
                     cabi.check(lib.ld_mask_out(sp.model_out.data_ptr(), self.masks[0].data_ptr(), lo, sp.x_in.shape[0],
                                                sp.x_in.shape[1], z.shape[2] * z.shape[3], st), "mask_out")
@@ -220,6 +221,10 @@ class GaussianDiffusion(nn.Module):
         self.noise_source = "device"
         self.fuse_final_step = os.environ.get("LD_NO_FUSED_FINAL") is None
         self.noise_seed = 10                      # torch.manual_seed(10), ddpm.py:934
+        # first element of this object's samples inside each draw of the run's noise stream: a rank that owns
+        # samples [lo, hi) of a sharded batch sets lo*C*H*W and then draws exactly the values the unsharded batch
+        # would have drawn for them (dist.py)
+        self.noise_offset = 0
         self.use_graph = False
         # concurrent sub-batches of the joint steps (see _SubBatches); 1 = one batch on the caller's stream
         self.sub_batches = int(os.environ.get("LD_SUB_BATCHES", "2"))
@@ -261,10 +266,10 @@ class GaussianDiffusion(nn.Module):
         if callable(src):
             buf.copy_(src(tuple(buf.shape), k).to(buf.device, torch.float32))
         elif src == "host":
-            buf.copy_(torch.from_numpy(rng.randn(tuple(buf.shape), self.noise_seed, k)))
+            buf.copy_(torch.from_numpy(rng.randn(tuple(buf.shape), self.noise_seed, k, self.noise_offset)))
         elif src == "device":
-            cabi.check(cabi.lib().ld_randn(buf.data_ptr(), buf.numel(), self.noise_seed, k, 0, None, self._st()),
-                       "randn")
+            cabi.check(cabi.lib().ld_randn_at(buf.data_ptr(), buf.numel(), self.noise_offset, self.noise_seed, k, 0,
+                                              None, self._st()), "randn")
         else:
             raise ValueError(f"noise_source {src!r}")
 
@@ -300,20 +305,43 @@ class GaussianDiffusion(nn.Module):
                                   return_all_outputs=return_all_outputs)
 
     @torch.inference_mode()
-    def p_sample(self, x, mask, min_max_val, cond_img, t: int, x_self_cond=None):
-        """One ancestral step, single branch (ddpm.py:841-860 non-branch arm): -> (x_{t-1}, x0)."""
+    def p_sample(self, x, mask, min_max_val, cond_img, t: int, x_self_cond=None, draw=None):
+        """One ancestral step, single branch (ddpm.py:841-860 non-branch arm): -> (x_{t-1}, x0).
+        ``draw``: index of this step's z in the run's noise stream (the reference calls torch.randn_like, i.e. the
+        next draw of the global generator); default = a per-object counter, so repeated calls use fresh noise."""
         lib, st = cabi.lib(), self._st()
         B, C, H, W = x.shape
         model_out = self.model(x, cond_img, torch.full((B,), t, device=x.device, dtype=torch.long))
         z = torch.empty_like(x)
         if t > 0:
-            self._noise(z, getattr(self, "_draw", 1))
+            if draw is None:
+                draw = self._p_sample_draw = getattr(self, "_p_sample_draw", 0) + 1
+            self._noise(z, int(draw))
         x_prev, x0 = torch.empty_like(x), torch.empty_like(x)
         row = self._sched_table()[t:t + 1].contiguous()
         cabi.check(lib.ld_ddpm_step(x.data_ptr(), model_out.data_ptr(), z.data_ptr(), x_prev.data_ptr(),
                                     x0.data_ptr(), row.data_ptr(), None, float(min_max_val[0]),
                                     float(min_max_val[1]), cabi.OBJ[self.objective], x.numel(), st), "ddpm_step")
         return x_prev, x0
+
+    def _sync_model(self):
+        """Captured HIP graphs and sub-batch runners hold raw pointers into the denoiser's plans and packed weights:
+        when the model dropped those (Unet.invalidate: load_state_dict, .to(), set_compute_dtype) they are destroyed
+        here, so a recycled ``id()`` / device pointer can never replay a stale graph and old plans are not pinned."""
+        v = getattr(self.model, "_version", 0)
+        if v == getattr(self, "_model_version", None):
+            return
+        self._model_version = v
+        if self._graphs or self._subs:
+            torch.cuda.synchronize()
+        for g in self._graphs.values():
+            cabi.lib().ld_graph_destroy(g)
+        self._graphs = {}
+        for sub in self._subs.values():
+            for g in sub.graphs.values():
+                cabi.lib().ld_graph_destroy(g)
+            sub.graphs = {}
+        self._subs = {}
 
     def _sub_streams(self, S):
         """The S side streams of the sub-batch runners (shared by all of them: HIP maps streams onto a few
@@ -336,6 +364,7 @@ class GaussianDiffusion(nn.Module):
         ``jp.x_in`` and is updated in place; the conditioning features must already be encoded).
         One step = denoiser evaluation (ddpm.py:716) + x0 clamp + posterior mean + sigma*z
         (ddpm.py:817-838, 857-858).  Returns the next draw index.  Used by p_sample_loop and bench.py."""
+        self._sync_model()
         lib, st = cabi.lib(), self._st()
         sched = self._sched_table()
         obj = cabi.OBJ[self.objective]
@@ -366,10 +395,10 @@ class GaussianDiffusion(nn.Module):
                 jp.set_step(t)
                 jp.run_main(st, skip_final=True)
                 k = draw if t > 0 else 0
-                cabi.check(lib.ld_final_step(xa.data_ptr(), wf.data_ptr(), bf.data_ptr(), jp.model_out.data_ptr(),
-                                             jp.x_in.data_ptr(), cabi.ptr(x0_buf), sched.data_ptr(), jp.t_dev.data_ptr(),
-                                             lo, hi, obj, self.noise_seed, k, B_, H_, W_, wf.shape[1], C_, jp.dt, st),
-                           "final_step")
+                cabi.check(lib.ld_final_step_at(xa.data_ptr(), wf.data_ptr(), bf.data_ptr(), jp.model_out.data_ptr(),
+                                                jp.x_in.data_ptr(), cabi.ptr(x0_buf), sched.data_ptr(), jp.t_dev.data_ptr(),
+                                                lo, hi, obj, self.noise_seed, k, 0, self.noise_offset, None,
+                                                B_, H_, W_, wf.shape[1], C_, jp.dt, st), "final_step")
                 if t > 0:
                     draw += 1
                 if after is not None:
@@ -403,7 +432,7 @@ class GaussianDiffusion(nn.Module):
         obj = cabi.OBJ[self.objective]
         n = jp.x_in.numel()
         base = draw + t_start                       # noise stream index of step t is base - t
-        key = (id(jp), float(lo), float(hi), obj, base, z.data_ptr())
+        key = (id(jp), float(lo), float(hi), obj, base, z.data_ptr(), self.noise_seed, self.noise_offset)
         cur = torch.cuda.current_stream()
         if getattr(self, "_gstream", None) is None:
             self._gstream = torch.cuda.Stream()
@@ -417,7 +446,7 @@ class GaussianDiffusion(nn.Module):
                 # one eager step first (lazy hipFuncSetAttribute calls etc. must not happen in capture)
                 jp.set_step(t)
                 jp.run_main(st)
-                cabi.check(lib.ld_randn(z.data_ptr(), n, self.noise_seed, base, -1, jp.t_dev.data_ptr(), st), "randn")
+                cabi.check(lib.ld_randn_at(z.data_ptr(), n, self.noise_offset, self.noise_seed, base, -1, jp.t_dev.data_ptr(), st), "randn")
                 cabi.check(lib.ld_ddpm_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(),
                                             None, sched.data_ptr(), jp.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
                 t -= 1
@@ -426,7 +455,7 @@ class GaussianDiffusion(nn.Module):
                 cabi.check(lib.ld_graph_begin(st), "graph_begin")
                 try:
                     jp.run_main(st)
-                    cabi.check(lib.ld_randn(z.data_ptr(), n, self.noise_seed, base, -1, jp.t_dev.data_ptr(), st), "randn")
+                    cabi.check(lib.ld_randn_at(z.data_ptr(), n, self.noise_offset, self.noise_seed, base, -1, jp.t_dev.data_ptr(), st), "randn")
                     cabi.check(lib.ld_ddpm_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), z.data_ptr(),
                                                 jp.x_in.data_ptr(), None, sched.data_ptr(), jp.t_dev.data_ptr(),
                                                 lo, hi, obj, n, st), "ddpm_step")
@@ -448,6 +477,7 @@ class GaussianDiffusion(nn.Module):
     @torch.inference_mode()
     def p_sample_loop(self, cond_img, mask, min_max_val, shape, return_all_timesteps=False,
                       return_all_outputs=False):
+        self._sync_model()
         lib, st, dev = cabi.lib(), self._st(), self.device
         B, C, H, W = shape
         HW, n = H * W, B * C * H * W
@@ -471,7 +501,13 @@ class GaussianDiffusion(nn.Module):
             start_t = t0 - 1
         z = torch.empty(shape, dtype=torch.float32, device=dev)
         x0_buf = torch.empty(shape, dtype=torch.float32, device=dev) if return_all_outputs else None
+        if return_all_timesteps and branch:
+            # ddpm.py:963 stacks `imgs`, which holds [x_out, x_in] lists for every branch step (:865): torch.stack
+            # raises on them in the reference as well
+            raise TypeError("return_all_timesteps is only defined for the single-branch reverse process "
+                            "(the reference's torch.stack(imgs) fails on the per-branch lists, ddpm.py:865,963)")
         hist_x, hist_x0 = [x_T.clone()] if return_all_timesteps else None, []
+        x0_pair = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(2)] if (return_all_outputs and branch) else None
         draw = 1
         t = start_t
         xs = None
@@ -548,9 +584,12 @@ class GaussianDiffusion(nn.Module):
                     branch = False
                     break
                 plan.set_step(t)
-                for xv, mv in ((x_out_view, mo_out), (x_in_view, mo_in)):
-                    cabi.check(lib.ld_ddpm_step(xv.data_ptr(), mv.data_ptr(), z.data_ptr(), xv.data_ptr(), None,
+                for bi, (xv, mv) in enumerate(((x_out_view, mo_out), (x_in_view, mo_in))):
+                    cabi.check(lib.ld_ddpm_step(xv.data_ptr(), mv.data_ptr(), z.data_ptr(), xv.data_ptr(),
+                                                cabi.ptr(x0_pair[bi]) if x0_pair else None,
                                                 sched.data_ptr(), plan.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+                if return_all_outputs:                     # branching_out(), ddpm.py:869
+                    hist_x0.append([x0_pair[0].cpu(), x0_pair[1].cpu()])
                 t -= 1
             if branch:                                     # never fused
                 xs = [x_out_view.clone(), x_in_view.clone()]
@@ -694,6 +733,11 @@ class GaussianDiffusion(nn.Module):
 
         draw, idx = 1, 0
         xs = None
+        if return_all_timesteps and branch:
+            # ddpm.py:1072 stacks `imgs`, which holds [x_out, x_in] lists for the branch steps (:1043,1069)
+            raise TypeError("return_all_timesteps is only defined for the single-branch reverse process "
+                            "(the reference's torch.stack(imgs) fails on the per-branch lists, ddpm.py:1069-1072)")
+        hist = [x_T.clone()] if return_all_timesteps else None      # imgs = [img], ddpm.py:993
         if branch:
             assert self.objective == "pred_x0" and mask is not None
             if mask_x:
@@ -758,6 +802,8 @@ class GaussianDiffusion(nn.Module):
                     self._noise(z, draw)
                     draw += 1
                 step(jp.x_in, jp.model_out, t, t_next, z if t_next >= 0 else None)
+                if hist is not None:
+                    hist.append(jp.x_in.clone())
                 idx += 1
-            return jp.x_in.clone()
+            return torch.stack(hist, dim=1) if hist is not None else jp.x_in.clone()      # ddpm.py:1072
         return xs

@@ -3,8 +3,10 @@
 with the authors' script.
 
 * MNIST idx(.gz) reader (the reference uses ``idx2numpy``; files under ``MNIST/raw``);
-* ``MNIST.__getitem__`` LR/HR pair (/root/reference/data.py:808-829): HR = 2x/255, LR = every other
-  pixel (``img[:, ::2, ::2]``), bilinear x2 back to 28x28 (align_corners=False), then 2*/255;
+* ``MNIST.__getitem__`` LR/HR pair (/root/reference/data.py:808-829): HR = 2x/255; LR: the reference indexes the
+  [1,1,28,28] image with ``img[:, ::2, ::2]`` -- dims 0, 1, 2 -- so only the ROWS are decimated (-> [1,1,14,28]),
+  then bilinear resize back to 28x28 (align_corners=False: rows x2, columns unchanged), then 2*/255.  Pinned by
+  tests/golden/g4_cfg1_mnist.npz, whose ``cond`` comes from the reference's own dataset class;
 * the hand-drawn OOD mask of the released script (columns 0..6 = 1, /root/reference/test.py:379-381) and
   the soft mask derived from a thresholded anomaly map (/root/reference/test.py:259-262);
 * the evaluation loop: one ``sample()`` per image (batch size 1, test.py:108,190,393), MSE of the last
@@ -49,7 +51,8 @@ def select_digits(images, labels, digits, max_n=None):
 def mnist_pairs(images_u8):
     """uint8 [N,28,28] -> (hr, lr) float32 [N,1,28,28] in [0, 2]  (data.py:808-829)."""
     x = torch.from_numpy(np.ascontiguousarray(images_u8).astype(np.float32))[:, None]
-    lr = F.interpolate(x[:, :, ::2, ::2], size=(x.shape[-1], x.shape[-1]), mode="bilinear", align_corners=False)
+    # data.py:817 slices dims (0, 1, 2) of the [1,1,H,W] tensor: rows only
+    lr = F.interpolate(x[:, :, ::2, :], size=(x.shape[-2], x.shape[-1]), mode="bilinear", align_corners=False)
     return 2.0 * (x / 255.0), 2.0 * (lr / 255.0)
 
 

@@ -56,10 +56,11 @@ def _hash(seed, stream, n, offset=0):
         return mix64(base + idx * _GOLD)
 
 
-def randn(shape, seed, stream):
-    """Standard normals, float32, C-order over ``shape``."""
+def randn(shape, seed, stream, offset=0):
+    """Standard normals, float32, C-order over ``shape``: elements [offset, offset + prod(shape)) of the draw's
+    sequence (a rank that owns a slice of a batch generates exactly the slice's values)."""
     n = int(np.prod(shape))
-    h = _hash(seed, stream, n)
+    h = _hash(seed, stream, n, int(offset))
     u1 = ((h >> np.uint64(40)).astype(np.float64) + 1.0) * (2.0 ** -24)
     u2 = ((h >> np.uint64(16)) & np.uint64(0xFFFFFF)).astype(np.float64) * (2.0 ** -24)
     z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)

@@ -25,7 +25,8 @@ from torch import nn
 from . import _cabi as cabi
 from .weights import UnetConfig, unet_param_shapes
 
-_TORCH_DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+_TORCH_DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+_LOWP = ("bf16", "fp16")          # 16-bit storage: fused linear attention, MFMA stem, folded conv_fusion
 
 
 def _register(root: nn.Module, dotted: str, tensor: torch.Tensor):
@@ -57,7 +58,7 @@ class Unet(nn.Module):
         if attn_dim_head != 32:
             raise ValueError("attn_dim_head must be 32 (MFMA tile of the attention kernels)")
         if compute_dtype not in _TORCH_DT:
-            raise ValueError(f"compute_dtype {compute_dtype!r} (fp32 | bf16)")
+            raise ValueError(f"compute_dtype {compute_dtype!r} (fp32 | bf16 | fp16)")
         full_attn = tuple(full_attn) if isinstance(full_attn, (tuple, list)) else (full_attn,) * len(dim_mults)
         assert len(full_attn) == len(dim_mults)
         init_dim = dim if init_dim is None else init_dim
@@ -89,6 +90,7 @@ class Unet(nn.Module):
         self._packed = None
         self._packed_key = None
         self._plans = {}
+        self._version = 0
 
     # ------------------------------------------------------------------ reference attributes
     @property
@@ -109,6 +111,7 @@ class Unet(nn.Module):
     def invalidate(self):
         """Drop packed weights and plans (call after changing parameters in place)."""
         self._packed, self._packed_key, self._plans = None, None, {}
+        self._version = getattr(self, "_version", 0) + 1      # samplers drop graphs / sub-batch runners built on old plans
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
@@ -165,7 +168,7 @@ class Unet(nn.Module):
             else:
                 pack(name, k)
         P["wq"], P["wkv"], P["kshift"], P["qshift"] = {}, {}, {}, {}
-        if self.compute_dtype == "bf16":
+        if self.compute_dtype in _LOWP:
             hid, heads = self.cfg.hidden, self.cfg.attn_heads
             for name, w in sd.items():
                 if not name.endswith(".to_qkv.weight") or (name[:-len(".to_qkv.weight")] + ".to_out.1.g") not in sd:
@@ -195,15 +198,18 @@ class Unet(nn.Module):
                 # exp(k - bound) could underflow in fp32: fall back to the exact two-sweep maximum (None).
                 wk = (w[hid:2 * hid, :, 0, 0].float() * scale[None, :]).to(tdt).float()
                 bound = wk.norm(dim=1) * 1.01
-                P["kshift"][base] = bound.contiguous() if float(bound.max()) <= 40.0 else None
+                # fp16 stores P = exp(k - bound) * 2^10 with a normal range of 2^-14: a true maximum 2*bound below
+                # the bound must stay inside it, so the single sweep is only used for bounds <= 8 there
+                kmax_ok = 40.0 if self.compute_dtype == "bf16" else 8.0
+                P["kshift"][base] = bound.contiguous() if float(bound.max()) <= kmax_ok else None
                 wqn = (w[:hid, :, 0, 0].float() * scale[None, :]).to(tdt).float().norm(dim=1) * 1.01
                 qb = wqn.reshape(heads, 32).amax(dim=1)          # softmax_d(q) shift per head (same bound, max over d)
                 P["qshift"][base] = qb.contiguous() if float(qb.max()) <= 40.0 else None
                 P["keep"].append(scale)
-        if self.compute_dtype == "bf16" and "conv_fusion.res_conv.weight" in sd:
+        if self.compute_dtype in _LOWP and "conv_fusion.res_conv.weight" in sd:
             # conv_fusion sees cat(trunk, conditioning features) (ddpm.py:434-436) and the second half does not change
             # between reverse steps: its weights are packed per half so that the conditioning half of block1.proj and
-            # res_conv can be evaluated once per sample (bf16 storage only: fp32 keeps the reference's summation order)
+            # res_conv can be evaluated once per sample (16-bit storage only: fp32 keeps the reference's summation order)
             for nm, k in (("conv_fusion.block1.proj.weight", 3), ("conv_fusion.res_conv.weight", 1)):
                 wfull = sd[nm]
                 half = wfull.shape[1] // 2
@@ -214,7 +220,7 @@ class Unet(nn.Module):
                                                        k, 0, dt, st), "pack " + nm + tag)
                     P["w"][nm + tag] = out
                     P.setdefault("keep", []).append(part)
-        if self.compute_dtype == "bf16" and self.cfg.init_dim == 32:
+        if self.compute_dtype in _LOWP and self.cfg.init_dim == 32:
             wi = sd["init_conv.weight"].contiguous()
             stem = torch.empty(int(lib.ld_stem_packed_bytes()), dtype=torch.uint8, device=dev)
             cabi.check(lib.ld_pack_stem_weight(wi.data_ptr(), stem.data_ptr(), wi.shape[1], st), "pack init_conv")
@@ -375,7 +381,7 @@ class _Plan:
         npx = self.B * h * w
         mt4 = cout % 64 == 0 and ((w + 15) // 16) * ((h + 7) // 8) * (cout // 64) * self.B >= 256
         big = ((w + 15) // 16) * ((h + 15) // 16) * (cout // (64 if mt4 else 32)) * self.B >= 512 and h >= 16 and not mt4
-        fam = f"conv3x3<{'f32' if self.dt == cabi.LD_F32 else 'bf16'},{4 if mt4 else 2},{4 if big else 2}>"
+        fam = f"conv3x3<{ {cabi.LD_F32: 'f32', cabi.LD_BF16: 'bf16', cabi.LD_F16: 'f16'}[self.dt] },{4 if mt4 else 2},{4 if big else 2}>"
         in_el = sum(s.C * (npx // 4 if s.upsample else npx) for s in srcs)
         self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname,
                    dict(family=fam, bytes=(in_el + npx * cout + 9 * cin * cout) * self.esize + 4 * cout,
@@ -495,7 +501,7 @@ class _Plan:
         return out
 
     def linear_attention_fused(self, ops, p, x, c, h, w):
-        """bf16: q/k/v never materialised (csrc/linattn_fused.hip)."""
+        """bf16 / fp16: q/k/v never materialised (csrc/linattn_fused.hip)."""
         f, cfg, lib = self.f32, self.cfg, self.lib
         n, hid, B, heads, dt, es = h * w, cfg.hidden, self.B, cfg.attn_heads, self.dt, self.esize
         # one workgroup per (batch, chunk) with a wave per head: 512-pixel chunks give >= 1024 workgroups at 256^2
@@ -529,7 +535,7 @@ class _Plan:
 
     def linear_attention(self, ops, p, x, c, h, w):
         """ddpm.py:214-251 (+ residual of the caller, :425/:444)."""
-        if self.dt == cabi.LD_BF16 and c in (32, 64, 128) and p in self.P["wq"]:
+        if self.dt != cabi.LD_F32 and c in (32, 64, 128) and p in self.P["wq"]:
             return self.linear_attention_fused(ops, p, x, c, h, w)
         f, cfg, lib = self.f32, self.cfg, self.lib
         n, hid, B = h * w, cfg.hidden, self.B
@@ -622,11 +628,11 @@ class _Plan:
         H, W = self.H, self.W
         r = self.buf(H, W, cfg.init_dim)
         wi, bi = f["init_conv.weight"], f["init_conv.bias"]
-        if self.dt == cabi.LD_BF16 and cfg.init_dim == 32:       # implicit GEMM on MFMA (hi/lo split: fp32-accurate)
+        if self.dt != cabi.LD_F32 and cfg.init_dim == 32:        # implicit GEMM on MFMA (hi/lo split: fp32-accurate)
             wstem = self.P["stem"]
             self.keep.append(wstem)
             self._raw(ops, lambda st: cabi.check(lib.ld_conv_stem(
-                self.x_in.data_ptr(), wstem.data_ptr(), bi.data_ptr(), r.data_ptr(), B, cfg.channels, H, W, st),
+                self.x_in.data_ptr(), wstem.data_ptr(), bi.data_ptr(), r.data_ptr(), B, cfg.channels, H, W, self.dt, st),
                 "init_conv"), "conv_image7x7",
                 nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W)
         else:

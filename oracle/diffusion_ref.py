@@ -93,6 +93,8 @@ class SamplerOptions:
     ood_AD: bool = False
     ood_confidence: bool = False
     classifier: bool = False          # config['classifier']: gate the fused sample with a classifier (ddpm.py:883-916)
+    use_gt: bool = False              # config['use_gt']: start from q_sample(hr, use_gt_timestep) (ddpm.py:937-944)
+    use_gt_timestep: int = 100
     seed: int = 10
 
 
@@ -200,21 +202,33 @@ class RefSampler:
         z = noise(x.shape) if t > 0 else 0.0
         return mean + sigma * z, x0, [xo, xi]
 
-    def p_sample_loop(self, cond, mask, lohi, shape, noise, branch, fuse, mask_x, record=None):
-        """-> final tensor.  ``record(t, x)`` (optional) sees x_{t-1} after every step."""
+    def p_sample_loop(self, cond, mask, lohi, shape, noise, branch, fuse, mask_x, record=None, hr=None,
+                      return_all_timesteps=False, return_all_outputs=False):
+        """-> final tensor (ddpm.py:930-977).  ``record(t, x)`` (optional) sees x_{t-1} after every step.
+        ``return_all_timesteps``: torch.stack(imgs, dim=1) with imgs = [x_T, x_{T-1}, ..., x_0] (:946,877-879,963);
+        ``return_all_outputs``: (ret, x_start_lst, []) with one x0 per step -- an [out, in] pair for branch steps
+        (:869), the fused / single x0 otherwise (:879,922) (:971-972)."""
         o = self.o
         x = noise(shape)
+        T = self.T
+        if o.start_intermediate and o.use_gt:                # ddpm.py:937-944 (gate: self.start_intermediate, :1099-1102)
+            t0 = int(o.use_gt_timestep)
+            x = self._c("sqrt_alphas_cumprod", t0) * hr + self._c("sqrt_one_minus_alphas_cumprod", t0) * x   # q_sample, :1148-1154
+            T = t0
+        imgs, x_start_lst = [x], []
         joint = not branch
         xs = None
         x_branchout = None            # masked branch states kept by the fusion step (ddpm.py:799)
-        for t in range(self.T - 1, -1, -1):
+        for t in range(T - 1, -1, -1):
             sigma = (0.5 * self._c("posterior_log_variance_clipped", t)).exp()
             if not joint:
                 if xs is None:
                     xs = [x, x]
                 if fuse and t <= o.start_timestep:
-                    x, _, x_branchout = self._fuse_step(xs, cond, mask, t, lohi, mask_x, noise, sigma)
+                    x, x0f, x_branchout = self._fuse_step(xs, cond, mask, t, lohi, mask_x, noise, sigma)
                     joint, xs = True, None          # (fusion() only does bookkeeping for this step: branch_cnt == 1, :877)
+                    imgs.append(x)
+                    x_start_lst.append(x0f)
                     if record:
                         record(t, x)
                     continue
@@ -224,6 +238,8 @@ class RefSampler:
                 z = noise(xs[0].shape) if t > 0 else 0.0
                 xs = [self.posterior_mean(x0o, xs[0], t) + sigma * z,
                       self.posterior_mean(x0i, xs[1], t) + sigma * z]
+                imgs.append(xs)                      # branching_out(), :865,869
+                x_start_lst.append([x0o, x0i])
                 if record:
                     record(t, xs)
             else:
@@ -243,16 +259,22 @@ class RefSampler:
                         self.classifier_flag = 1
                     else:
                         mask_x = True
-                        x, _, x_branchout = self._fuse_step(x_branchout, cond, mask, t, lohi, mask_x, noise, sigma)
+                        x, x0, x_branchout = self._fuse_step(x_branchout, cond, mask, t, lohi, mask_x, noise, sigma)
+                imgs.append(x)
+                x_start_lst.append(x0)
                 if record:
                     record(t, x)
         ret = xs if xs is not None else x
+        if return_all_timesteps:
+            ret = torch.stack(imgs, dim=1)                   # raises on the [out, in] lists of branch steps, as :963 does
         if (not o.start_intermediate) and o.branch_out:      # ddpm.py:964-970
             ret = torch.stack(ret, dim=0) if isinstance(ret, list) else torch.stack((ret, ret), dim=0)
+        if return_all_outputs:
+            return ret, x_start_lst, []
         return ret
 
     # --- DDIM (ddpm.py:980-1075) ---
-    def ddim_sample(self, cond, mask, lohi, shape, noise, branch, fuse, mask_x):
+    def ddim_sample(self, cond, mask, lohi, shape, noise, branch, fuse, mask_x, return_all_timesteps=False):
         o = self.o
         times = torch.linspace(-1, self.T - 1, steps=self.S + 1)
         times = list(reversed(times.int().tolist()))
@@ -261,6 +283,7 @@ class RefSampler:
         eta = o.ddim_sampling_eta
         abar = self.buf["alphas_cumprod"]
         x = noise(shape)
+        imgs = [x, x] if branch else [x]                      # ddpm.py:990-993
         joint = not branch
         xs = None
         for t, t_next in pairs:
@@ -270,6 +293,7 @@ class RefSampler:
                 (eo, x0o), (ei, x0i) = self.predict_branches(xs[0], xs[1], cond, mask, t, lohi, True, mask_x)
                 if t_next < 0:
                     xs = [x0o, x0i]
+                    imgs.append(xs)
                     continue
                 a, an = abar[t], abar[t_next]
                 sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
@@ -283,24 +307,30 @@ class RefSampler:
                     eps = torch.where(po == 0.0, pi, po)
                     x = x0 * an.sqrt() + c * eps + sigma * z
                     joint, xs = True, None
+                    imgs.append(x)
                 else:
                     xs = [x0o * an.sqrt() + c * eo + sigma * z, x0i * an.sqrt() + c * ei + sigma * z]
+                    imgs.append(xs)
             else:
                 eps, x0 = self.predict_single(x, cond, t, lohi, True)
                 if o.branch_out:
                     x0 = x0.clamp(lohi[0], lohi[1])
                 if t_next < 0:
                     x = x0
+                    imgs.append(x)
                     continue
                 a, an = abar[t], abar[t_next]
                 sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
                 c = (1 - an - sigma ** 2).sqrt()
                 z = noise(x.shape)
                 x = x0 * an.sqrt() + c * eps + sigma * z
+                imgs.append(x)
+        if return_all_timesteps:
+            return torch.stack(imgs, dim=1)                   # ddpm.py:1072 (raises on per-branch lists, as there)
         return xs if xs is not None else x
 
     # --- dispatcher (ddpm.py:1078-1125) ---
-    def sample(self, cond, mask, lohi, batch_size, noise):
+    def sample(self, cond, mask, lohi, batch_size, noise, gt=None, return_all_timesteps=False, return_all_outputs=False):
         o = self.o
         branch, fuse = o.branch_out, o.start_intermediate
         mask_x = o.mask_x or o.ood_AD or o.ood_confidence
@@ -310,8 +340,10 @@ class RefSampler:
                 branch, fuse, mask_x = False, False, False
         shape = (batch_size, self.channels, self.image_size, self.image_size)
         if self.S < self.T:
-            return self.ddim_sample(cond, mask, lohi, shape, noise, branch, fuse, mask_x)
-        return self.p_sample_loop(cond, mask, lohi, shape, noise, branch, fuse, mask_x)
+            return self.ddim_sample(cond, mask, lohi, shape, noise, branch, fuse, mask_x,
+                                    return_all_timesteps=return_all_timesteps)
+        return self.p_sample_loop(cond, mask, lohi, shape, noise, branch, fuse, mask_x, hr=gt,
+                                  return_all_timesteps=return_all_timesteps, return_all_outputs=return_all_outputs)
 
 
 def make_model_fn(sd, cfg):

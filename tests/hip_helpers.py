@@ -9,9 +9,9 @@ from localdiffusion_hallucination_amd import _cabi as cabi
 from localdiffusion_hallucination_amd import rng
 
 DEV = "cuda"
-TDT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+TDT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 # max-abs tolerance relative to the reference tensor's max-abs, per storage dtype
-RTOL = {"fp32": 2e-5, "bf16": 3e-2}
+RTOL = {"fp32": 2e-5, "bf16": 3e-2, "fp16": 4e-3}      # 16-bit: ~8 half-ulps (2^-8 / 2^-11) of the largest value
 
 
 def st():

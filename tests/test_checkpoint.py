@@ -44,6 +44,40 @@ def test_ema_copy_is_preferred_and_bare_dicts_work():
     assert torch.equal(net.state_dict()["final_conv.bias"], src.state_dict()["model.final_conv.bias"])
 
 
+def test_written_file_has_the_layout_the_reference_trainer_writes(tmp_path):
+    """Manifest (every key, shape, dtype) of a file written here == manifest of the file the reference's own
+    Trainer.save wrote for the same model in the build container (tools/make_goldens.py g12)."""
+    import json
+    import os
+    import conftest
+    want = json.load(open(os.path.join(conftest.GOLDEN, "g12_trainer_save_manifest.json")))
+
+    def walk(d):
+        return {k: ([list(v.shape), str(v.dtype)] if torch.is_tensor(v) else walk(v) if isinstance(v, dict) else type(v).__name__)
+                for k, v in d.items()}
+    path = tmp_path / "model-best2900.pt"
+    checkpoint.save_reference_checkpoint(_model(3), str(path), step=2900)
+    data = torch.load(str(path), map_location="cpu", weights_only=True)
+    got = {k: (walk(v) if isinstance(v, dict) else type(v).__name__) for k, v in data.items()}
+    got["opt"] = "dict"
+    assert got == want
+
+
+def test_unsafe_pickles_are_refused_unless_trusted(tmp_path):
+    """A file the restricted unpickler rejects is not silently retried with the full one."""
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("arbitrary code ran",))
+    path = tmp_path / "evil.pt"
+    torch.save({"model": {}, "payload": Evil()}, str(path))
+    with pytest.raises(RuntimeError, match="restricted unpickler"):
+        checkpoint.load_reference_checkpoint(str(path), _model(9))
+    with pytest.raises(FileNotFoundError):                # I/O errors are not masked by a retry
+        checkpoint.load_reference_checkpoint(str(tmp_path / "missing.pt"), _model(9))
+
+
 def test_mismatch_is_an_error():
     dst = _model(8)
     wrong = ldh.Unet(dim=32, init_dim=32, mode="mri")

@@ -1,0 +1,73 @@
+"""Chain-level parity of the 16-bit storage modes (bf16, fp16) -- the modes bench.py runs -- against golden vectors
+generated from the real reference (fp32 CPU): the full T=1000 DDPM chain of BASELINE.json configs[1] (G5, one 128x128
+patch) and the S=50-of-1000 DDIM branch + fusion run (G7), with the fixtures' noise stream.
+
+The north star's 1e-3 max-abs gate is stated for fp32 and met there (tests/test_hip_sampler.py).  16-bit storage
+cannot meet it, so each mode has its OWN stated bounds (also quoted in DESIGN.md section 2), in units of the image
+range [0, 2]:
+
+  * up to t = 100 (900 of the 1000 steps) the chain is well conditioned and the bounds are tight;
+  * over the last 100 steps this random-init network amplifies ANY perturbation by two orders of magnitude -- the
+    fp32 HIP path itself goes from 1.5e-6 (t=100) to 4.4e-4 (t=0) against the reference, and the reference's own fp32
+    code with nothing but its denoiser OUTPUT rounded to 16 bits once per step (fixture G11, made by
+    tools/make_goldens.py from the real reference) goes from 5e-5 to 3.8e-3 mean-abs (bf16).  The final-state bounds
+    are therefore stated twice: absolutely, and as "the HIP path's error growth over the last 100 steps is no worse
+    than 2x the growth of that reference-derived run", which separates kernel accuracy from chain conditioning."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from localdiffusion_hallucination_amd import rng                  # noqa: E402
+from test_hip_sampler import make, run                            # noqa: E402
+
+RECORDS = (999, 750, 500, 250, 100, 10, 0)
+# (max-abs, mean-abs); measured on MI355X (round 2): bf16 t=100 2.9e-2 / 3.2e-3, final 1.98 / 0.128;
+#                                                    fp16 t=100 3.9e-3 / 4.6e-4, final 0.95 / 2.0e-2
+BOUND_T100 = {"bf16": (6e-2, 6e-3), "fp16": (8e-3, 1e-3)}
+BOUND_FINAL_MEAN = {"bf16": 0.2, "fp16": 4e-2}
+# DDIM S=50 of 1000 (G7, 64x64, branch + fusion at times[-4]): measured bf16 0.33 / 1.8e-2, fp16 0.54 / 8.3e-3
+BOUND_G7_MEAN = {"bf16": 4e-2, "fp16": 2e-2}
+
+
+def err(got, ref):
+    d = np.abs(got - ref)
+    return float(d.max()), float(d.mean())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_cfg2_chain_16bit_vs_reference_golden(golden, dtype):
+    g, floor = golden("g5_cfg2_mri128"), golden("g11_cfg2_output_rounded")
+    cond = torch.from_numpy(rng.uniform((1, 1, 128, 128), 5, 1, 0.0, 2.0))
+    gd = make(dict(mode="mri"), dict(data="mri"), 128, 1000, dtype=dtype)
+    hist = gd.sample(cond.cuda(), None, batch_size=1, min_max_val=(0.0, 2.0), return_all_timesteps=True).cpu().numpy()
+    assert hist.shape == (1, 1001, 1, 128, 128) and np.isfinite(hist).all()
+    e, f = {}, {}
+    for t in RECORDS:
+        ref = g[f"x_after_t{t}"]
+        e[t] = err(hist[:, 1000 - t], ref)
+        f[t] = err(floor[f"{dtype}_x_after_t{t}"], ref)
+        print(f"G5 cfg2 {dtype} x after t={t:3d}: HIP max-abs {e[t][0]:.3e} mean-abs {e[t][1]:.3e} | reference with its "
+              f"output rounded to {dtype}: max-abs {f[t][0]:.3e} mean-abs {f[t][1]:.3e}")
+    for t in (999, 750, 500, 250, 100):
+        assert e[t][0] <= BOUND_T100[dtype][0] and e[t][1] <= BOUND_T100[dtype][1], (dtype, t, e[t])
+    assert e[0][1] <= BOUND_FINAL_MEAN[dtype], (dtype, e[0])
+    growth_hip, growth_ref = e[0][1] / e[100][1], f[0][1] / f[100][1]
+    print(f"G5 cfg2 {dtype}: mean-abs growth over the last 100 steps: HIP x{growth_hip:.0f}, output-rounded reference x{growth_ref:.0f}")
+    assert growth_hip <= 2.0 * growth_ref, (dtype, growth_hip, growth_ref)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_g7_ddim_chain_16bit_vs_reference_golden(golden, dtype):
+    g = golden("g7_ddim")
+    cond = torch.from_numpy(rng.uniform((1, 1, 64, 64), 7, 1, 0.0, 2.0))
+    mask = torch.from_numpy(g["mask"])
+    kw = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True)
+    mx, mean = err(run(make(dict(mode="mri"), kw, 64, 1000, 50, dtype=dtype), cond, mask, 1), g["fused_final"])
+    print(f"G7 DDIM S=50 of 1000, branch + fusion, {dtype}: max-abs {mx:.3e} mean-abs {mean:.3e}")
+    assert mean <= BOUND_G7_MEAN[dtype], (dtype, mx, mean)
+    kw = dict(data="mri", branch_out=True, start_intermediate=False, mask_x=True)
+    mx, mean = err(run(make(dict(mode="mri"), kw, 64, 50, 10, dtype=dtype), cond, mask, 1), g["nofuse_final"])
+    print(f"G7 DDIM S=10 of 50, branches kept apart, {dtype}: max-abs {mx:.3e} mean-abs {mean:.3e}")
+    assert mean <= BOUND_G7_MEAN[dtype], (dtype, mx, mean)

@@ -1,5 +1,5 @@
 """Per-kernel parity: each C-ABI op against the same op in plain PyTorch fp32 on the CPU
-(the building blocks of oracle/unet_ref.py), on seeded inputs, fp32 and bf16 storage."""
+(the building blocks of oracle/unet_ref.py), on seeded inputs, fp32, bf16 and fp16 storage."""
 import ctypes as C
 import math
 
@@ -15,7 +15,8 @@ from localdiffusion_hallucination_amd import rng, schedule        # noqa: E402
 from oracle import unet_ref                                        # noqa: E402
 import hip_helpers as hh                                           # noqa: E402
 
-DTYPES = ["fp32", "bf16"]
+DTYPES = ["fp32", "bf16", "fp16"]
+LOWP = ["bf16", "fp16"]
 
 
 def _q(x, dtype):
@@ -115,7 +116,7 @@ def test_qkv_epilogues(dtype, c, H, W):
     qs = q.reshape(B, 4, 32, H * W).softmax(dim=-2).reshape(B, hid, H, W) * 32 ** -0.5
     wp = hh.pack(w, dtype, 1, scale_in=g.flatten() * math.sqrt(c))
     out = hh.conv1x1([hh.make_src(hh.nhwc(x, dtype), c)], wp, B, H, W, 3 * hid, dtype, epi=cabi.EPI_QKV_LINEAR, rms_in=1)
-    tol = hh.RTOL[dtype] * (3 if dtype == "bf16" else 5)
+    tol = hh.RTOL[dtype] * (3 if dtype != "fp32" else 5)
     assert hh.rel_err(hh.nchw(out), torch.cat([qs, k, v], 1)) < tol
     out = hh.conv1x1([hh.make_src(hh.nhwc(x, dtype), c)], wp, B, H, W, 3 * hid, dtype, epi=cabi.EPI_QKV_FULL, rms_in=1)
     assert hh.rel_err(hh.nchw(out), torch.cat([q * 32 ** -0.5, k, v], 1)) < tol
@@ -158,10 +159,12 @@ def test_conv_image(dtype, cin, ks, H, W):
     assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, 16)) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", LOWP)
 @pytest.mark.parametrize("cin,H,W", [(3, 64, 48), (1, 28, 28), (3, 40, 33), (3, 256, 256)])
-def test_conv_stem_mfma_bf16(cin, H, W):
-    """init_conv 7x7 for bf16 storage as an im2col MFMA GEMM (hi/lo split of image and weights): equal to the fp32
-    reference up to the bf16 rounding of the stored output, and to the fp32-FMA kernel's bf16 output within one ulp."""
+def test_conv_stem_mfma_16bit(dtype, cin, H, W):
+    """init_conv 7x7 for 16-bit storage as an im2col MFMA GEMM (bf16 hi/lo split of image and weights): equal to the
+    fp32 reference up to the rounding of the stored output, and to the fp32-FMA kernel's 16-bit output within one ulp."""
+    ulp = 2.0 ** -8 if dtype == "bf16" else 2.0 ** -11        # half an ulp, relative
     B = 2
     x, w, b = hh.rand((B, cin, H, W), 43, -1.5, 1.5), hh.rand((32, cin, 7, 7), 44, -0.2, 0.2), hh.rand((32,), 45)
     ref = F.conv2d(x, w, b, padding=3)
@@ -169,16 +172,18 @@ def test_conv_stem_mfma_bf16(cin, H, W):
     xd, wd, bd = x.to(hh.DEV), w.to(hh.DEV).contiguous(), b.to(hh.DEV)
     wp = torch.empty(int(lib.ld_stem_packed_bytes()), dtype=torch.uint8, device=hh.DEV)
     cabi.check(lib.ld_pack_stem_weight(wd.data_ptr(), wp.data_ptr(), cin, hh.st()), "pack_stem")
-    out = torch.empty(B, H, W, 32, dtype=torch.bfloat16, device=hh.DEV)
-    cabi.check(lib.ld_conv_stem(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), B, cin, H, W, hh.st()), "conv_stem")
+    out = torch.empty(B, H, W, 32, dtype=hh.TDT[dtype], device=hh.DEV)
+    cabi.check(lib.ld_conv_stem(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), out.data_ptr(), B, cin, H, W,
+                                cabi.dtype_code(dtype), hh.st()), "conv_stem")
     got = hh.nchw(out)
-    assert hh.rel_err(got, ref) < hh.RTOL["bf16"]
-    # the split products keep fp32-level accuracy: the only error left is the final bf16 rounding (half an ulp <= 2^-8)
-    assert float(((got - ref).abs() / ref.abs().clamp_min(0.25)).max()) < 2.0 ** -8 * 1.02
+    assert hh.rel_err(got, ref) < hh.RTOL[dtype]
+    # the split products keep ~2^-16 relative accuracy: what is left is the final rounding of the stored value
+    # (half an ulp) plus, for fp16, that 2^-16 of the largest product
+    assert float(((got - ref).abs() / ref.abs().clamp_min(0.25)).max()) < ulp * 1.02 + (0 if dtype == "bf16" else 2.0 ** -13)
     out2 = torch.empty_like(out)
     cabi.check(lib.ld_conv_image(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out2.data_ptr(), None, 0, B, cin, H, W, 7,
-                                 cabi.LD_BF16, hh.st()), "conv_image")
-    assert float((got - hh.nchw(out2)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+                                 cabi.dtype_code(dtype), hh.st()), "conv_image")
+    assert float((got - hh.nchw(out2)).abs().max()) <= 2 * ulp * float(ref.abs().max())
 
 
 # ------------------------------------------------------------------------------ gn_apply
@@ -428,12 +433,13 @@ def test_final_conv(dtype):
     assert hh.rel_err(out.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", LOWP)
 @pytest.mark.parametrize("single_sweep", [False, True])
 @pytest.mark.parametrize("c,H,W", [(32, 28, 28), (64, 14, 14), (32, 64, 96), (128, 32, 32)])
-def test_linear_attention_fused_bf16(c, H, W, single_sweep):
-    """The fused bf16 path (q/k/v recomputed from x, never stored) against the oracle block; with the exact
+def test_linear_attention_fused_16bit(dtype, c, H, W, single_sweep):
+    """The fused 16-bit path (q/k/v recomputed from x, never stored) against the oracle block; with the exact
     two-sweep k maximum and with the single-sweep Cauchy-Schwarz shift + the fused reduce/fold launch."""
-    dtype = "bf16"
+    f = 1.0 if dtype == "bf16" else 0.25                    # fp16 carries 3 more mantissa bits; fp32 parts (Z, softmax) do not shrink
     B, hid, n = 2, 128, H * W
     x = _q(hh.rand((B, c, H, W), 170, -2, 2), dtype)
     sd = {"a.norm.g": hh.rand((1, c, 1, 1), 171, 0.5, 1.5),
@@ -466,12 +472,12 @@ def test_linear_attention_fused_bf16(c, H, W, single_sweep):
     if single_sweep:
         assert float((k_.reshape(B, hid, n).amax(-1) - kshift.cpu()[None]).max()) <= 1e-3      # the bound holds
     cref = torch.einsum("bhdn,bhen->bhde", k_.softmax(dim=-1), v_)
-    assert hh.rel_err(ctxn.cpu(), cref) < 2e-2
+    assert hh.rel_err(ctxn.cpu(), cref) < 2e-2 * f
     cabi.check(lib.ld_linattn_fold(ctxn.data_ptr(), wout.data_ptr(), wfold.data_ptr(), B, c, 4, 32, 1, dt, hh.st()), "fold")
     if single_sweep:   # one launch for reduce + fold: identical packed M_b
         wfold2 = torch.zeros_like(wfold)
         cabi.check(lib.ld_linattn_ctxfold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold2.data_ptr(), B, c, 4, 32, 1, dt, hh.st()), "ctxfold")
-        assert hh.rel_err(wfold2.float().cpu(), wfold.float().cpu()) < 1e-2
+        assert hh.rel_err(wfold2.float().cpu(), wfold.float().cpu()) < 1e-2 * f
         wfold = wfold2
     out = torch.empty(B, H, W, c, dtype=hh.TDT[dtype], device=hh.DEV)
     bias, g2 = sd["a.to_out.0.bias"].to(hh.DEV), (sd["a.to_out.1.g"].flatten() * math.sqrt(c)).to(hh.DEV)
@@ -480,7 +486,7 @@ def test_linear_attention_fused_bf16(c, H, W, single_sweep):
         qshift = (w[:hid, :, 0, 0] * scale[None, :]).norm(dim=1).reshape(4, 32).amax(dim=1).contiguous().to(hh.DEV)
     cabi.check(lib.ld_linattn_out(xd.data_ptr(), wq.data_ptr(), None if qshift is None else qshift.data_ptr(), wfold.data_ptr(),
                                   bias.data_ptr(), g2.data_ptr(), out.data_ptr(), B, n, c, 32 ** -0.5, dt, hh.st()), "linattn_out")
-    assert hh.rel_err(hh.nchw(out), ref) < 6e-2
+    assert hh.rel_err(hh.nchw(out), ref) < 6e-2 * f
 
 
 # ------------------------------------------------------------------------------ persistent C=32 conv (conv3x3_c32.hip)
@@ -509,7 +515,7 @@ def test_conv3x3_c32_persistent_path(dtype):
     assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
     # 64 -> 32 in two K-chunks: upsampled 32 ch ++ 32 ch, statistics + prologue on the second source, on a
     # multiple-of-16 width and a ragged one
-    for Wr in ((256, 250) if dtype == "bf16" else ()):
+    for Wr in ((256, 250) if dtype != "fp32" else ()):
         x1, x2 = _q(hh.rand((B, 32, H // 2, Wr // 2), 207), dtype), _q(hh.rand((B, 32, H, Wr), 208), dtype)
         w2 = _q(hh.rand((cout, 64, 3, 3), 209, -0.1, 0.1), dtype)
         y2 = F.silu(F.group_norm(x2, 8, gamma, beta, eps=1e-5))

@@ -62,11 +62,18 @@ def test_cfg1_mnist(golden):
 
 
 def test_cfg2_mri128_full(golden):
-    """BASELINE.json configs[1]: one 128x128 1-ch patch, T=1000, fp32 -- the 1e-3 parity gate."""
+    """BASELINE.json configs[1]: one 128x128 1-ch patch, T=1000, fp32 -- the 1e-3 parity gate, checked on the final
+    image AND on every intermediate state the golden holds (x_t after t = 999, 750, 500, 250, 100, 10, 0), so the
+    error growth along the chain is on record."""
     g = golden("g5_cfg2_mri128")
     cond = torch.from_numpy(rng.uniform((1, 1, 128, 128), 5, 1, 0.0, 2.0))
     gd = make(dict(mode="mri"), dict(data="mri"), 128, 1000)
-    check("G5 cfg2", run(gd, cond, None, 1), g["final"])
+    hist = gd.sample(cond.cuda(), None, batch_size=1, min_max_val=(0.0, 2.0), return_all_timesteps=True).cpu().numpy()
+    assert hist.shape == (1, 1001, 1, 128, 128)              # x_T, then x_{t-1} after every step t = 999 .. 0
+    for t in (999, 750, 500, 250, 100, 10, 0):
+        check(f"G5 cfg2 x after t={t}", hist[:, 1000 - t], g[f"x_after_t{t}"])
+    check("G5 cfg2 final", hist[:, -1], g["final"])
+    check("G5 cfg2 (plain call)", run(gd, cond, None, 1), g["final"])
 
 
 def test_branch_fusion(golden):
@@ -97,6 +104,37 @@ def test_fallback_and_objectives(golden):
     check("G8 all-ones", run(make(MNIST, kw, 28, 20), cond, torch.ones(2, 1, 28, 28), 2), g["allones_final"])
     for obj in ("pred_noise", "pred_v"):
         check("G8 " + obj, run(make(MNIST, dict(data="mnist"), 28, 20, objective=obj), cond, None, 2), g[obj + "_final"])
+
+
+def test_use_gt_start_and_return_all(golden):
+    """The use_gt start (q_sample of the HR image at use_gt_timestep, ddpm.py:937-944) and the history returns
+    (return_all_timesteps: every x_t stacked on dim 1; return_all_outputs: (ret, x0 per step, [])), DDPM and DDIM,
+    against the real reference called with the same flags (G10)."""
+    g = golden("g10_use_gt_return_all")
+    gd = make(MNIST, dict(data="mnist", start_intermediate=True, use_gt=True, use_gt_timestep=20), 28, 50)
+    ret, x0s, cm = gd.sample(torch.from_numpy(g["a_cond"]).cuda(), torch.from_numpy(g["a_hr"]).cuda(), batch_size=2,
+                             min_max_val=(0.0, 2.0), return_all_timesteps=True, return_all_outputs=True)
+    assert cm == [] and len(x0s) == 20 and all(not e.is_cuda for e in x0s)
+    check("G10a x_t history (use_gt, T=50 from t0=20)", ret.cpu().numpy(), g["a_hist"])
+    check("G10a x0 history", np.stack([e.numpy() for e in x0s]), g["a_x0"])
+    gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True,
+                                     use_gt=True, use_gt_timestep=12), 32, 40)
+    ret, x0s, _ = gd.sample(torch.from_numpy(g["b_cond"]).cuda(), torch.from_numpy(g["b_hr"]).cuda(), batch_size=2,
+                            mask=torch.from_numpy(g["b_mask"]).cuda(), min_max_val=(0.0, 2.0), return_all_outputs=True)
+    check("G10b final (use_gt + branch + fusion)", ret.cpu().numpy(), g["b_final"])
+    pairs = [np.stack([e[0].numpy(), e[1].numpy()]) for e in x0s if isinstance(e, (list, tuple))]
+    singles = [e.numpy() for e in x0s if not isinstance(e, (list, tuple))]
+    assert [isinstance(e, (list, tuple)) for e in x0s] == [True] * 8 + [False] * 4     # t = 11..4 | 3 (fusion), 2..0
+    check("G10b x0 history, branch steps", np.stack(pairs), g["b_x0_pairs"])
+    check("G10b x0 history, fused + joint steps", np.stack(singles), g["b_x0_single"])
+    gd = make(MNIST, dict(data="mnist"), 28, 50, 10)
+    ret = gd.sample(torch.from_numpy(g["c_cond"]).cuda(), None, batch_size=2, min_max_val=(0.0, 2.0), return_all_timesteps=True)
+    check("G10c DDIM x_t history", ret.cpu().numpy(), g["c_hist"])
+    for S in (None, 10):                   # per-branch lists cannot be stacked: the reference raises TypeError as well
+        gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True), 32, 40, S)
+        with pytest.raises(TypeError):
+            gd.sample(torch.from_numpy(g["b_cond"]).cuda(), None, batch_size=2, mask=torch.from_numpy(g["b_mask"]).cuda(),
+                      min_max_val=(0.0, 2.0), return_all_timesteps=True)
 
 
 class StubClassifier:
@@ -140,7 +178,7 @@ def test_device_noise_runs_and_is_deterministic():
     assert float(np.abs(a - c).max()) < 1e-3      # device Box-Muller is fp32, host fp64
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_fused_final_step_is_bitwise_the_three_launches(dtype):
     """ld_final_step (final_conv + posterior update + in-place noise) vs ld_final_conv, ld_randn, ld_ddpm_step."""
     cond = torch.from_numpy(rng.uniform((2, 1, 28, 28), 8, 1, 0.0, 2.0))
@@ -167,7 +205,7 @@ def test_graph_replay_matches_eager():
     assert np.array_equal(graph, again)
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2), ("fp16", 1e-2)])
 def test_concurrent_sub_batches_match_the_single_batch(dtype, tol):
     """The joint steps of 8 patches as two sub-batches of 4 on two streams (replayed HIP graphs, sliced noise
     stream) give the samples of the single batch: same noise, same per-patch arithmetic up to the summation
@@ -190,7 +228,7 @@ def test_concurrent_sub_batches_match_the_single_batch(dtype, tol):
 
 
 @pytest.mark.parametrize("fuse", [True, False])
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2), ("fp16", 1e-2)])
 def test_branch_phase_as_concurrent_sub_batches(dtype, tol, fuse):
     """The branch steps before the fusion time with the OOD and the IND branch as two concurrent sub-batches
     (one shared draw per step, mask_x folded into the OOD branch's final step) == the batched eager branch loop."""
@@ -293,6 +331,26 @@ def test_cfg5_shape_ddim_branch_fusion_matches_oracle():
     d = np.abs(run(gd16, cond, mask, 1) - got)
     print(f"cfg5 shape, bf16 vs fp32 storage: mean-abs {d.mean():.3e}  max-abs {d.max():.3e}")
     assert d.mean() <= 2e-2 and d.max() <= 0.3
+
+
+def test_checkpoint_round_trip_reproduces_cfg1_golden(golden, tmp_path):
+    """SURVEY 8f-1 on the GPU: a model saved in the reference's Trainer.save layout, loaded into a FRESH model through
+    the EMA prefix path, repacked for the kernels and sampled == the reference's cfg1 output (G4)."""
+    from localdiffusion_hallucination_amd import checkpoint
+    g = golden("g4_cfg1_mnist")
+    kw = dict(data="mnist", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True, ood_AD=True)
+    src = make(MNIST, kw, 28, 100)
+    path = tmp_path / "model-best2900.pt"
+    checkpoint.save_reference_checkpoint(src, str(path), step=2900)
+    net = ldh.Unet(dim=32, init_dim=32, **MNIST)           # its own random initialisation, NOT the procedural weights
+    dst = ldh.GaussianDiffusion(dict(src.config), net, image_size=28, timesteps=100, beta_schedule="sigmoid",
+                                objective="pred_x0").to("cuda")
+    dst.noise_source = "host"
+    before = run(dst, torch.from_numpy(g["cond"]), torch.from_numpy(g["mask"]), 4)
+    assert float(np.abs(before - g["final"]).max()) > 1e-2          # the fresh weights give something else
+    info = checkpoint.load_reference_checkpoint(str(path), dst)
+    assert info["source"] == "ema" and info["step"] == 2900 and not info["missing"] and not info["unexpected"]
+    check("G4 cfg1 from a loaded checkpoint", run(dst, torch.from_numpy(g["cond"]), torch.from_numpy(g["mask"]), 4), g["final"])
 
 
 def test_eval_driver_matches_cfg1_golden(golden, tmp_path):

@@ -78,12 +78,14 @@ def test_forward_fp32_at_baseline_sizes_matches_oracle(kw, B, H, what):
     assert err < 2e-4 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("dtype,tol", [("bf16", 5e-2), ("fp16", 8e-3)])
 @pytest.mark.parametrize("tag", list(CASES))
-def test_forward_bf16_within_tolerance(tag):
-    """bf16 storage / fp32 accumulate: relative max error of the output vs the fp32 oracle < 5 %
-    of the output range (the north star's 1e-3 gate is stated for fp32 only)."""
+def test_forward_16bit_within_tolerance(tag, dtype, tol):
+    """bf16 / fp16 storage, fp32 accumulate: relative max error of ONE forward's output vs the fp32 oracle < 5 % (bf16:
+    8 mantissa bits) / 0.8 % (fp16: 11 bits) of the output range.  The chained error over a whole sampling run is
+    bounded in tests/test_hip_lowp_chain.py (the north star's 1e-3 gate is stated for fp32 only)."""
     kw, B, H = CASES[tag]
-    net, sd = build(kw, "bf16")
+    net, sd = build(kw, dtype)
     cfg = net.cfg
     x = torch.from_numpy(rng.randn((B, cfg.channels, H, H), 1, 100))
     cond = torch.from_numpy(rng.uniform((B, cfg.cond_in_channels, H, H), 1, 101, 0.0, 2.0))
@@ -95,30 +97,31 @@ def test_forward_bf16_within_tolerance(tag):
     rows = tap_table(net, net.plan(B, H, H), taps)
     print("\n".join(f"  {n:24s} err {e:.3e}  (ref max {m:.3e})" for n, e, m in rows))
     rel = float((y - y_ref).abs().max()) / float(y_ref.abs().max())
-    print(f"{tag} bf16: out rel err {rel:.3e}")
-    assert rel < 5e-2
+    print(f"{tag} {dtype}: out rel err {rel:.3e}")
+    assert rel < tol
 
 
-def test_conv_fusion_fold_matches_the_concatenated_block(monkeypatch):
-    """bf16: conv_fusion with the conditioning halves of block1.proj / res_conv precomputed once per sample vs the
-    same block evaluated on cat(trunk, conditioning features) every step: same tap and output up to bf16 rounding."""
+@pytest.mark.parametrize("dtype,f", [("bf16", 1.0), ("fp16", 0.125)])
+def test_conv_fusion_fold_matches_the_concatenated_block(monkeypatch, dtype, f):
+    """16-bit storage: conv_fusion with the conditioning halves of block1.proj / res_conv precomputed once per sample vs the
+    same block evaluated on cat(trunk, conditioning features) every step: same tap and output up to storage rounding."""
     kw, B, H = CASES["mri64"]
     cfg_x = torch.from_numpy(rng.randn((B, 1, H, H), 1, 100))
     cond = torch.from_numpy(rng.uniform((B, 1, H, H), 1, 101, 0.0, 2.0))
     tv = torch.full((B,), 7, dtype=torch.long)
-    net, _ = build(kw, "bf16")
+    net, _ = build(kw, dtype)
     y_fold = net(cfg_x.cuda(), cond.cuda(), tv.cuda()).cpu()
     plan = net.plan(B, H, H)
     assert plan.fusion_const is not None
     tap_fold = plan.named["conv_fusion"].float().cpu()
     monkeypatch.setenv("LD_NO_FUSION_FOLD", "1")
-    net2, _ = build(kw, "bf16")
+    net2, _ = build(kw, dtype)
     y_cat = net2(cfg_x.cuda(), cond.cuda(), tv.cuda()).cpu()
     plan2 = net2.plan(B, H, H)
     assert plan2.fusion_const is None
     tap_cat = plan2.named["conv_fusion"].float().cpu()
-    assert float((tap_fold - tap_cat).abs().max()) <= 3e-2 * float(tap_cat.abs().max())
-    assert float((y_fold - y_cat).abs().max()) <= 2e-2 * float(y_cat.abs().max())
+    assert float((tap_fold - tap_cat).abs().max()) <= 3e-2 * f * float(tap_cat.abs().max())
+    assert float((y_fold - y_cat).abs().max()) <= 2e-2 * f * float(y_cat.abs().max())
 
 
 def test_per_sample_timesteps_and_state_dict_names():

@@ -162,3 +162,42 @@ def test_classifier_gated_rebranching(golden, tag, cfg, H, data, key):
         out = smp.sample(cond, mask, (0.0, 2.0), 2, Noise())
     assert smp.classifier.calls == calls
     assert float(np.abs(out.numpy() - g[tag + "_final"]).max()) <= 1e-6
+
+
+def _x0_arrays(lst):
+    pairs = [np.stack([e[0].numpy(), e[1].numpy()]) for e in lst if isinstance(e, (list, tuple))]
+    singles = [e.numpy() for e in lst if not isinstance(e, (list, tuple))]
+    return pairs, singles
+
+
+def test_use_gt_start_and_return_all(golden):
+    """use_gt start (ddpm.py:937-944) + return_all_timesteps / return_all_outputs (:946, 959-977, 1072):
+    golden = the real reference called with those flags."""
+    g = golden("g10_use_gt_return_all")
+
+    def smp(cfg, H, T, S=None, **kw):
+        o = diffusion_ref.SamplerOptions(timesteps=T, sampling_timesteps=S, **kw)
+        return diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(cfg), cfg), o, cfg.channels, H)
+    with torch.no_grad():
+        ret, x0s, cm = smp(CFG_MNIST, 28, 50, data="mnist", start_intermediate=True, use_gt=True, use_gt_timestep=20).sample(
+            torch.from_numpy(g["a_cond"]), None, (0.0, 2.0), 2, Noise(), gt=torch.from_numpy(g["a_hr"]),
+            return_all_timesteps=True, return_all_outputs=True)
+    assert cm == [] and len(x0s) == 20
+    np.testing.assert_allclose(ret.numpy(), g["a_hist"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(np.stack([e.numpy() for e in x0s]), g["a_x0"], atol=1e-6, rtol=0)
+    with torch.no_grad():
+        ret, x0s, _ = smp(CFG_MRI, 32, 40, data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True,
+                          use_gt=True, use_gt_timestep=12).sample(
+            torch.from_numpy(g["b_cond"]), torch.from_numpy(g["b_mask"]), (0.0, 2.0), 2, Noise(),
+            gt=torch.from_numpy(g["b_hr"]), return_all_outputs=True)
+    pairs, singles = _x0_arrays(x0s)
+    np.testing.assert_allclose(ret.numpy(), g["b_final"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(np.stack(pairs), g["b_x0_pairs"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(np.stack(singles), g["b_x0_single"], atol=1e-6, rtol=0)
+    with torch.no_grad():
+        ret = smp(CFG_MNIST, 28, 50, 10, data="mnist").sample(torch.from_numpy(g["c_cond"]), None, (0.0, 2.0), 2, Noise(),
+                                                              return_all_timesteps=True)
+    np.testing.assert_allclose(ret.numpy(), g["c_hist"], atol=1e-6, rtol=0)
+    with pytest.raises(TypeError):         # per-branch [out, in] lists cannot be stacked: the reference raises here too
+        smp(CFG_MRI, 32, 40, data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True).sample(
+            torch.from_numpy(g["b_cond"]), torch.from_numpy(g["b_mask"]), (0.0, 2.0), 2, Noise(), return_all_timesteps=True)

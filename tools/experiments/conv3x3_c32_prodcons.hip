@@ -13,13 +13,13 @@
 //     each block [kq 0..3][pixel 0..15][16 B] = 1 KiB = ONE global_load_lds_dwordx4: lane l = kq*16 + p reads
 //     fragment kq of pixel p (16 pixels x 64 B contiguous in HBM), and a fragment read of 16 consecutive
 //     pixels hits 16 distinct 16-B slots (conflict-free for every tap);
-//   * waves 8-9 are PRODUCERS: all they ever issue is LDS-DMA (inline asm, common.cuh; out-of-image lanes read a
+//   * waves 8-9 are PRODUCERS: all they ever issue is LDS-DMA (inline asm, common.hip.h; out-of-image lanes read a
 //     clamped in-image address so every item is a fixed number of instructions) and exact counted vmcnt waits;
 //     waves 0-7 are CONSUMERS: in-place GroupNorm/FiLM/SiLU + zero padding of the NEXT item, MFMAs of the
 //     current one, 16-byte NHWC stores -- they never wait on vmcnt.  One workgroup barrier per item; R-3 items
 //     (63 KiB per CU) stay in flight across it.  Keeping the DMAs out of the storing waves' in-order
 //     vector-memory queues is the point: see the measurement next to the ring fill.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 namespace {

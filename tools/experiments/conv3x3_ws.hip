@@ -18,7 +18,7 @@
 //     consumers' epilogue overlaps the next tile's DMA;
 //   * GroupNorm statistics: per-wave partials go to a parity-double-buffered LDS slot and are flushed (fp64
 //     sum, one striped atomic per group) by consumer wave 0 behind the next barrier.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 namespace {

@@ -136,7 +136,8 @@ def opts_from(config, T, S=None, objective="pred_x0", sched="sigmoid"):
         timesteps=T, sampling_timesteps=S, objective=objective, beta_schedule=sched,
         branch_out=config["branch_out"], start_intermediate=config["start_intermediate"],
         start_timestep=config["start_timestep"], data=config["data"], mask_x=config["mask_x"],
-        ood_AD=config["ood_AD"], ood_confidence=config["ood_confidence"], classifier=bool(config.get("classifier", False)))
+        ood_AD=config["ood_AD"], ood_confidence=config["ood_confidence"], classifier=bool(config.get("classifier", False)),
+        use_gt=bool(config.get("use_gt", False)), use_gt_timestep=int(config.get("use_gt_timestep", 100)))
 
 
 def maxdiff(a, b):
@@ -166,13 +167,63 @@ def mnist_digits(n=4, label=3):
     return imgs[idx].copy()
 
 
-def mnist_lr_hr(digits):
-    """data.py:808-829 (MNIST.__getitem__): HR = 2x/255; LR = 2x-subsampled then bilinear x2."""
-    x = torch.from_numpy(digits.astype(np.float32))[:, None]
-    hr = 2.0 * x / 255.0
-    lr = torch.nn.functional.interpolate(x[:, :, ::2, ::2], scale_factor=2, mode="bilinear",
-                                         align_corners=False)
-    return 2.0 * lr / 255.0, hr
+def import_reference_dataset():
+    """The reference's real ``data.py`` (its MNIST dataset class), loaded under another module name: the name
+    ``data`` is a stub while ``ddpm`` is imported.  torchvision is absent here, so ``transforms.Compose`` -- the only
+    torchvision symbol MNIST.__getitem__ reaches in test mode, with an empty list (data.py:792-795) -- is given its
+    defining behaviour (apply the listed transforms in order)."""
+    import importlib.util
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = list(ts)
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+    for n in ("torchvision.transforms",):
+        sys.modules[n].Compose = Compose
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    # data.py:17,29 only takes a user-agent string from `datasets` (for an image downloader far from this path); the
+    # installed package refuses to import beside the torchvision stub, so it is stubbed for the load as well
+    saved = {n: sys.modules.get(n) for n in ("datasets", "datasets.utils", "datasets.utils.file_utils")}
+    for n in saved:
+        m = types.ModuleType(n)
+        m.__path__ = []
+        m.get_datasets_user_agent = lambda *a, **k: "stub"
+        sys.modules[n] = m
+    spec = importlib.util.spec_from_file_location("ref_data_real", os.path.join(REF, "data.py"))
+    mod = importlib.util.module_from_spec(spec)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            spec.loader.exec_module(mod)
+        finally:
+            for n, m in saved.items():
+                if m is None:
+                    sys.modules.pop(n, None)
+                else:
+                    sys.modules[n] = m
+    return mod
+
+
+def mnist_lr_hr(digits, labels=None):
+    """LR / HR pairs from the reference's OWN dataset code (MNIST.__getitem__, data.py:808-829), test mode.
+    NB the reference indexes the [1,1,28,28] image with ``img[:, ::2, ::2]``, which decimates dims 0-2, i.e. only
+    the ROWS (-> [1,1,14,28]) before the bilinear resize back to 28x28; the product's evalio.mnist_pairs follows
+    that and is pinned by this fixture."""
+    ref_data = import_reference_dataset()
+    labels = np.full(len(digits), 3, dtype=np.uint8) if labels is None else labels
+    ds = ref_data.MNIST({"augmentations": False}, digits, labels, train=False, num=[int(v) for v in set(labels.tolist())])
+    assert len(ds) == len(digits)
+    hr, lr = [], []
+    for i in range(len(ds)):
+        img, img_down, _ = ds[i]
+        hr.append(img)
+        lr.append(img_down)
+    return torch.stack(lr), torch.stack(hr)
 
 
 # ----------------------------------------------------------------------------- G1 schedules
@@ -480,6 +531,175 @@ def g9(ddpm):
     save("g9_classifier_gate", **out)
 
 
+def g10(ddpm):
+    print("G10 use_gt start (ddpm.py:937-944) and return_all_timesteps / return_all_outputs (:946,959-977,1072)")
+    out = {}
+
+    def both(cfg, H, config, T, S, B, cond, mask, hr, rat, rao):
+        sd = sd_torch(cfg)
+        ref_model = build_reference_unet(ddpm, cfg, sd)
+        gd = _ref_diffusion(ddpm, dict(config), ref_model, H, T, "sigmoid", "pred_x0", S).eval()
+        with reference_run(PortableNoise(10)):
+            with torch.inference_mode():
+                ref = gd.sample(cond.clone(), None if hr is None else hr.clone(), batch_size=B,
+                                mask=None if mask is None else mask.clone(), min_max_val=(0.0, 2.0),
+                                return_all_timesteps=rat, return_all_outputs=rao)
+        o = opts_from(config, T, S)
+        smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd, cfg), o, cfg.channels, H)
+        with torch.no_grad():
+            orc = smp.sample(cond, mask, (0.0, 2.0), B, PortableNoise(10), gt=hr, return_all_timesteps=rat,
+                             return_all_outputs=rao)
+        return ref, orc
+
+    def flat_x0(lst):
+        """x_start_lst -> one array [steps, (2,) B, C, H, W] per homogeneous run of entries"""
+        pairs = [np.stack([e[0].numpy(), e[1].numpy()]) for e in lst if isinstance(e, (list, tuple))]
+        singles = [e.numpy() for e in lst if not isinstance(e, (list, tuple))]
+        return (np.stack(pairs) if pairs else np.zeros((0,), np.float32)), (np.stack(singles) if singles else np.zeros((0,), np.float32))
+
+    # (a) single-branch, use_gt start at t0 = 20 of T = 50, every x_t and every x0 returned
+    B, H, T = 2, 28, 50
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 10, 1, 0.0, 2.0))
+    hr = torch.from_numpy(rng.uniform((B, 1, H, H), 10, 2, 0.0, 2.0))
+    kw = base_config(data="mnist", start_intermediate=True, use_gt=True, use_gt_timestep=20)
+    (r_ret, r_x0, r_cm), (o_ret, o_x0, o_cm) = both(CFG_MNIST, H, kw, T, None, B, cond, None, hr, True, True)
+    compare("G10a x_t history", r_ret, o_ret, 2e-5)
+    assert tuple(r_ret.shape) == (B, 21, 1, H, H) and len(r_x0) == len(o_x0) == 20 and r_cm == [] and o_cm == []
+    for a, b in zip(r_x0, o_x0):
+        assert maxdiff(a, b) <= 2e-5
+    out["a_cond"], out["a_hr"], out["a_hist"] = cond.numpy(), hr.numpy(), to_np(r_ret)
+    out["a_x0"] = np.stack([e.numpy() for e in r_x0])
+    # (b) branch + fusion from a use_gt start, x0 history (pairs for the branch steps, then fused / joint x0)
+    B, H, T = 2, 32, 40
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 10, 3, 0.0, 2.0))
+    hr = torch.from_numpy(rng.uniform((B, 1, H, H), 10, 4, 0.0, 2.0))
+    mask = band_mask(B, H, H // 4)
+    kw = base_config(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True, use_gt=True,
+                     use_gt_timestep=12)
+    (r_ret, r_x0, _), (o_ret, o_x0, _) = both(CFG_MRI, H, kw, T, None, B, cond, mask, hr, False, True)
+    compare("G10b final", r_ret, o_ret, 2e-5)
+    assert len(r_x0) == len(o_x0) == 12
+    for a, b in zip(r_x0, o_x0):
+        assert isinstance(a, (list, tuple)) == isinstance(b, (list, tuple))
+        assert maxdiff(torch.from_numpy(to_np(a)), torch.from_numpy(to_np(b))) <= 2e-5
+    out["b_cond"], out["b_hr"], out["b_mask"], out["b_final"] = cond.numpy(), hr.numpy(), mask.numpy(), to_np(r_ret)
+    out["b_x0_pairs"], out["b_x0_single"] = flat_x0(r_x0)
+    assert out["b_x0_pairs"].shape[0] == 8 and out["b_x0_single"].shape[0] == 4      # t = 11..4 branch, 3 fusion, 2..0 joint
+    # (c) DDIM, single branch, every x_t returned
+    B, H, T, S = 2, 28, 50, 10
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 10, 5, 0.0, 2.0))
+    kw = base_config(data="mnist")
+    r_ret, o_ret = both(CFG_MNIST, H, kw, T, S, B, cond, None, None, True, False)
+    compare("G10c DDIM x_t history", r_ret, o_ret, 2e-5)
+    assert tuple(r_ret.shape) == (B, S + 1, 1, H, H)
+    out["c_cond"], out["c_hist"] = cond.numpy(), to_np(r_ret)
+    # (d) return_all_timesteps with branches: the reference's torch.stack raises; record the exception type
+    kw = base_config(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True)
+    for S_ in (None, 10):
+        try:
+            both(CFG_MRI, 32, kw, 40, S_, 2, torch.from_numpy(rng.uniform((2, 1, 32, 32), 10, 3, 0.0, 2.0)), band_mask(2, 32, 8), None, True, False)
+            raise AssertionError("expected the reference to fail")
+        except TypeError as e:
+            print(f"    branch + return_all_timesteps (S={S_}): reference raises TypeError ({str(e)[:60]}...)")
+    save("g10_use_gt_return_all", **out)
+
+
+def g11(ddpm):
+    """The floor of ANY 16-bit-storage implementation on cfg2: the reference's own fp32 code with nothing but its
+    denoiser OUTPUT rounded to bf16 / fp16 once per step (an implementation that stores activations in 16 bits rounds
+    hundreds of tensors per step).  The distance of these runs from the fp32 golden G5 is the yardstick the
+    16-bit chain tests price the HIP path against (tests/test_hip_lowp_chain.py)."""
+    print("G11 cfg2 with the reference's denoiser output rounded to 16 bits once per step  (several minutes)")
+    cfg, H, B, T = CFG_MRI, 128, 1, 1000
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 5, 1, 0.0, 2.0))
+    g5_ = np.load(os.path.join(GOLD, "g5_cfg2_mri128.npz"))
+    out = {}
+    keep = (999, 750, 500, 250, 100, 10, 0)
+    for tag, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        sd = sd_torch(cfg)
+        ref_model = build_reference_unet(ddpm, cfg, sd)
+        inner = ref_model.forward
+        ref_model.forward = lambda *a, _f=inner, _dt=dt, **k: _f(*a, **k).to(_dt).to(torch.float32)
+        gd = _ref_diffusion(ddpm, base_config(data="mri"), ref_model, H, T, "sigmoid", "pred_x0", None).eval()
+        t0 = time.time()
+        with reference_run(PortableNoise(10)):
+            with torch.inference_mode():
+                hist = gd.sample(cond.clone(), None, batch_size=B, mask=None, min_max_val=(0.0, 2.0), return_all_timesteps=True)
+        hist = hist.numpy()
+        print(f"  {tag}: reference sample() wall {time.time()-t0:.1f}s")
+        for t in keep:
+            d = np.abs(hist[:, T - t] - g5_[f"x_after_t{t}"])
+            print(f"    output rounded to {tag}: x after t={t}: max-abs {d.max():.3e} mean-abs {d.mean():.3e}")
+            out[f"{tag}_x_after_t{t}"] = hist[:, T - t]
+    save("g11_cfg2_output_rounded", **out)
+
+
+def g12(ddpm):
+    """Checkpoint format pinned to what the reference's own Trainer.save writes (ddpm.py:1495-1507) and
+    Trainer.load reads (:1509-1527).  Both methods are called unbound on a minimal trainer object holding a real
+    accelerate.Accelerator, the reference GaussianDiffusion, an Adam optimiser and an EMA wrapper (ema_pytorch is
+    absent from this image: the stand-in has the package's state_dict layout -- online_model.*, ema_model.*,
+    initted, step).  The file is ~40 MB of procedural weights, so what is committed is its MANIFEST (every key with
+    shape and dtype); tests rebuild the file with checkpoint.save_reference_checkpoint and compare manifests."""
+    import copy
+    import json
+    import pathlib
+    from accelerate import Accelerator
+    from localdiffusion_hallucination_amd import checkpoint
+    print("G12 Trainer.save / Trainer.load checkpoint format")
+    cfg, H, T = CFG_MNIST, 28, 100
+    sd = sd_torch(cfg, 3)
+    ref_model = build_reference_unet(ddpm, cfg, sd)
+    kw = base_config(data="mnist", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True)
+    gd = _ref_diffusion(ddpm, kw, ref_model, H, T, "sigmoid", "pred_x0", None)
+
+    class EMA(torch.nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.online_model = model
+            self.ema_model = copy.deepcopy(model)
+            self.register_buffer("initted", torch.tensor(True))
+            self.register_buffer("step", torch.tensor(0))
+
+    def manifest(data):
+        def walk(d):
+            return {k: ([list(v.shape), str(v.dtype)] if torch.is_tensor(v) else walk(v) if isinstance(v, dict) else type(v).__name__)
+                    for k, v in d.items()}
+        m = {k: (walk(v) if isinstance(v, dict) else type(v).__name__) for k, v in data.items()}
+        m["opt"] = "dict"                      # optimiser state is training-side, not read by the sampling path
+        return m
+
+    with tempfile.TemporaryDirectory() as d:
+        tr = types.SimpleNamespace(accelerator=Accelerator(cpu=True), model=gd, opt=torch.optim.Adam(gd.parameters(), lr=1e-4),
+                                   ema=EMA(gd), step=2900, results_folder=pathlib.Path(d))
+        ddpm.Trainer.save(tr, "best2900")                     # the reference's own writer
+        path = os.path.join(d, "model-best2900.pt")
+        data = torch.load(path, map_location="cpu", weights_only=True)      # loads under the safe unpickler
+        man = manifest(data)
+        # the product reads what the reference wrote ...
+        net = ldh.Unet(dim=32, init_dim=32, dim_mults=cfg.dim_mults, full_attn=cfg.full_attn, mode=cfg.mode)
+        mine = ldh.GaussianDiffusion(dict(kw), net, image_size=H, timesteps=T, objective="pred_x0")
+        info = checkpoint.load_reference_checkpoint(path, mine)
+        assert info == {"step": 2900, "source": "ema", "missing": [], "unexpected": []}, info
+        for k, v in gd.state_dict().items():
+            assert torch.equal(mine.state_dict()[k], v), k
+        # ... and the reference reads what the product writes (Trainer.load on a second trainer object)
+        path2 = os.path.join(d, "model-mine.pt")
+        checkpoint.save_reference_checkpoint(mine, path2, step=2900)
+        assert manifest(torch.load(path2, map_location="cpu", weights_only=True)) == man
+        gd2 = _ref_diffusion(ddpm, kw, build_reference_unet(ddpm, cfg, sd_torch(cfg, 4)), H, T, "sigmoid", "pred_x0", None)
+        tr2 = types.SimpleNamespace(accelerator=Accelerator(cpu=True), model=gd2, opt=torch.optim.Adam(gd2.parameters(), lr=1e-4),
+                                    ema=EMA(gd2), step=0, results_folder=pathlib.Path(d))
+        with contextlib.redirect_stdout(io.StringIO()):
+            ddpm.Trainer.load(tr2, "mine")
+        assert tr2.step == 2900
+        for k, v in gd.state_dict().items():
+            assert torch.equal(gd2.state_dict()[k], v), k
+    with open(os.path.join(GOLD, "g12_trainer_save_manifest.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print(f"  wrote tests/golden/g12_trainer_save_manifest.json ({len(man['model'])} model keys, {len(man['ema'])} ema keys)")
+
+
 def g0_inventory(ddpm):
     print("G0 parameter inventory")
     lines = []
@@ -502,12 +722,12 @@ def main():
     ddpm = import_reference()
     os.makedirs(GOLD, exist_ok=True)
     todo = [("G0", g0_inventory), ("G1", g1), ("G2", g2), ("G3", g3), ("G4", g4), ("G6", g6),
-            ("G7", g7), ("G8", g8), ("G9", g9), ("G5", g5)]
+            ("G7", g7), ("G8", g8), ("G9", g9), ("G10", g10), ("G12", g12), ("G5", g5), ("G11", g11)]
     only = set(filter(None, a.only.split(",")))
     for name, fn in todo:
         if only and name not in only:
             continue
-        if a.skip_long and name == "G5":
+        if a.skip_long and name in ("G5", "G11"):
             continue
         t0 = time.time()
         fn(ddpm)
