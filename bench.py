@@ -17,8 +17,14 @@ The conditioning encoder runs once per sample in the product (its input is const
 one encoder evaluation is executed INSIDE the timed region.
 
 Prints ONE JSON line on rank 0 (see the task contract), including
-  roofline     -- dominant kernel family: algorithmic bytes / live HIP-event time vs 8 TB/s
+  roofline     -- dominant kernel family: algorithmic bytes (or flops) per launch / live per-launch HIP-event time,
+                  with the per-family table (launches per step, bytes and flops per launch, average duration) that
+                  the fraction can be recomputed from, by hand or from profiles/*_kernel_stats.csv
   cpu_baseline -- the oracle (plain PyTorch fp32 CPU port of the reference) on this box's cores.
+
+N > 1: under torch.distributed.run (WORLD_SIZE set) every process is one rank; called plainly as
+`python bench.py --gpus N` the script starts N rank processes itself (before anything touches the GPU) and relays
+rank 0's JSON line; it exits non-zero if a rank fails or fewer than N GPUs are visible.
 """
 import argparse
 import json
@@ -42,8 +48,8 @@ ALGO_TB_PER_PATCH = 0.7036       # algorithmic bytes per 3x256x256
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--patches", type=int, default=8, help="local patches per GPU (K masks of one image)")
@@ -51,6 +57,45 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the reverse step from a captured HIP graph (default: eager launches)")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process has made no GPU
+    call and makes none), wait for all of them, relay rank 0's stdout.  Non-zero exit if any rank failed."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
+    if n_dev < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def band_masks(K, H):
@@ -102,15 +147,132 @@ def cpu_baseline(cfg, sd, H, seconds_budget=15.0):
                 break
         dt = (time.time() - t0) / n
     return dict(value=1.0 / (T_STEPS * dt), unit="patches/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} consecutive reverse steps of 1 patch ({cfg.channels}x{H}x{H}, fp32, oracle/unet_ref.py), "
+                host_logical_cpus=os.cpu_count(), host_cpu=cpu_model(),
+                sample=f"{n} consecutive reverse steps of 1 patch ({cfg.channels}x{H}x{H}, fp32, oracle/unet_ref.py) on "
+                       f"{torch.get_num_threads()} threads (fastest of 8/16/32/64; the box has {os.cpu_count()} logical CPUs), "
                        f"{dt*1e3:.1f} ms/step, extrapolated to T={T_STEPS}")
+
+
+def _family_table(acc, plan, nsteps):
+    """Per-launch HIP-event times of ``nsteps`` reverse steps -> per kernel family:
+    launches_per_step, bytes_per_launch, flops_per_launch (algorithmic, SURVEY 8d, averaged over the family's launches),
+    avg_us (average launch duration) and ms_per_step.  frac of a family = bytes_per_launch / avg_us / peak."""
+    fam, per_op = {}, []
+    for i, (ms, cnt) in sorted(acc.items()):
+        m = plan.meta.get(i, {})
+        name = m.get("family", m.get("what", "other").split(" ")[0])
+        f = fam.setdefault(name, dict(ms=0.0, launches=0, bytes=0, flops=0))
+        f["ms"] += ms
+        f["launches"] += cnt
+        f["bytes"] += m.get("bytes", 0) * cnt
+        f["flops"] += m.get("flops", 0) * cnt
+        per_op.append((i, m, 1e3 * ms / max(cnt, 1)))
+    table = {}
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+        n = max(1, f["launches"])
+        table[name] = {"launches_per_step": f["launches"] / nsteps, "bytes_per_launch": round(f["bytes"] / n),
+                       "flops_per_launch": round(f["flops"] / n), "avg_us": round(1e3 * f["ms"] / n, 3),
+                       "ms_per_step": round(f["ms"] / nsteps, 4)}
+    return table, per_op
+
+
+def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5):
+    """Per-launch timing (hipExtLaunchKernelGGL start/stop events on the launch stream = rocprofv3's kernel
+    durations) of a few reverse steps, in two regimes:
+      solo    -- the whole local batch as ONE batch on one stream: every launch has the chip to itself.  This is what
+                 `frac` prices (a roofline fraction is a statement about one kernel and the whole machine), and what
+                 `rocprofv3 --kernel-trace --stats` of `LD_SUB_BATCHES=1 python bench.py` reproduces
+                 (profiles/*_s1_kernel_stats.csv);
+      in_situ -- the regime of the timed region: the batch as concurrent sub-batches on two streams; sub-batch 0 is
+                 timed while the other one's kernels share the chip (launches are slower, the step is faster)."""
+    torch.cuda.synchronize()
+    peak_tf = MFMA_PEAK_TF[dtype]
+    legs = {}
+    split = gd.timed_plan(jp) is not jp
+    for leg in (("solo", "in_situ") if split else ("solo",)):
+        acc = {}
+        keep = gd.sub_batches
+        if leg == "solo":
+            gd.sub_batches = 1
+        try:
+            gd.run_joint_steps(jp, 500, nsteps, lo, hi, z, 1, timers=acc)
+            plan = gd.timed_plan(jp) if leg == "in_situ" else jp
+        finally:
+            gd.sub_batches = keep
+        torch.cuda.synchronize()
+        table, per_op = _family_table(acc, plan, nsteps)
+        legs[leg] = (table, per_op, plan)
+    table, per_op, plan = legs["solo"]
+    if os.environ.get("LD_BENCH_OPS"):
+        with open(os.environ["LD_BENCH_OPS"], "w") as f:
+            for leg, (_, ops, _) in legs.items():
+                f.write(f"# {leg}\n")
+                for i, m, us in ops:
+                    f.write(f"{i:4d} {m.get('family', '?'):22s} {m.get('what', '?'):38s} {m.get('shape', ''):20s} "
+                            f"{us:9.1f} us  {m.get('bytes', 0) / max(us, 1e-9) / 1e3:8.1f} GB/s  "
+                            f"{m.get('flops', 0) / max(us, 1e-9) / 1e6:8.1f} TF/s\n")
+
+    def price(row):
+        gbs = row["bytes_per_launch"] / max(row["avg_us"], 1e-9) / 1e3
+        tfs = row["flops_per_launch"] / max(row["avg_us"], 1e-9) / 1e6
+        hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / peak_tf
+        if mfma_frac > hbm_frac:        # a kernel is priced against the roofline that bounds it
+            return {"bound": "mfma", "achieved": tfs, "peak": peak_tf, "unit": "TFLOP/s", "frac": mfma_frac}, gbs, tfs
+        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}, gbs, tfs
+
+    def conv_path(ops):
+        # the north star's "ResBlock conv path": the C=32 3x3 convolutions at full resolution (SURVEY 8a census,
+        # first two lines), priced against the HBM roofline with their algorithmic bytes
+        sel = [(m, us) for _, m, us in ops if m.get("family", "").startswith("conv3x3") and m.get("shape", "").endswith(f"@{H}x{H}")]
+        us_total, b_total = sum(us for _, us in sel), sum(m.get("bytes", 0) for m, _ in sel)
+        return {"launches_per_step": len(sel), "ms_per_step": round(us_total / 1e3, 4), "bytes_per_step": b_total,
+                "algorithmic_GBps": b_total / max(us_total, 1e-9) / 1e3,
+                "hbm_frac": b_total / max(us_total, 1e-9) / 1e3 / HBM_PEAK_GBS}
+
+    name = next(iter(table))                                 # the family with the most time per step
+    roof, gbs, tfs = price(table[name])
+    step_ms = sum(r["ms_per_step"] for r in table.values())
+    traffic, traffic_src = None, None
+    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_s1_pmc_traffic.json")), reverse=True):
+        try:                                                 # committed rocprofv3 --pmc passes of the solo regime, not live
+            traffic = json.load(open(os.path.join(ROOT, "profiles", cand))).get(name, {}).get("hbm_bytes_per_launch")
+            traffic_src = "profiles/" + cand
+        except Exception:
+            traffic = None
+        if traffic is not None:
+            break
+    roof.update({"kernel": name, "regime": "solo: one batch of %d on one stream" % int(jp.x_in.shape[0]),
+                 "launch_batch": int(jp.x_in.shape[0]), "traffic": traffic, "traffic_source": traffic_src,
+                 "avg_launch_us": table[name]["avg_us"], "bytes_per_launch": table[name]["bytes_per_launch"],
+                 "flops_per_launch": table[name]["flops_per_launch"], "launches_per_step": table[name]["launches_per_step"],
+                 "algorithmic_GBps": gbs, "algorithmic_TFLOPps": tfs, "share_of_step": table[name]["ms_per_step"] / max(step_ms, 1e-9),
+                 "step_ms_sum_of_kernels": round(step_ms, 4),
+                 # whole path (SURVEY 8d): 0.7036 TB of algorithmic traffic per 256^2 patch over T=1000 -- still divided
+                 # by the figure that INCLUDES the conditioning encoder (34 MB per forward), which the product evaluates
+                 # once per sample instead of once per step
+                 "path_frac": tp_value * ALGO_TB_PER_PATCH * 1e3 / HBM_PEAK_GBS,
+                 "resblock_conv_path": conv_path(per_op), "families": table})
+    if "in_situ" in legs:
+        t2, ops2, plan2 = legs["in_situ"]
+        r2, g2, f2 = price(t2[name]) if name in t2 else ({"frac": None}, 0, 0)
+        roof["in_situ"] = {"regime": "%d concurrent sub-batches of %d, sub-batch 0 timed" % (gd.sub_batches, int(plan2.x_in.shape[0])),
+                           "launch_batch": int(plan2.x_in.shape[0]), "frac": r2["frac"],
+                           "avg_launch_us": t2.get(name, {}).get("avg_us"), "resblock_conv_path": conv_path(ops2),
+                           "step_ms_sum_of_kernels": round(sum(r["ms_per_step"] for r in t2.values()), 4), "families": t2}
+    return roof
+
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -130,6 +292,7 @@ def main():
     gd = ldh.GaussianDiffusion(config, net, image_size=H, timesteps=T_STEPS, objective="pred_x0",
                                beta_schedule="sigmoid").to(dev)
     gd.noise_source = "device"
+    gd.noise_offset = rank * a.patches * 3 * a.size * a.size     # every rank draws its own slice of the job's noise stream
     gd.use_graph = a.graph == 1          # HIP-graph replay of the reverse step (measured: no gain, the step is GPU-bound)
 
     masks = band_masks(P, H)
@@ -197,69 +360,7 @@ def main():
     }
 
     if rank == 0 and not a.no_roofline:
-        # dominant kernel family: live HIP events around every launch, on the launch stream
-        acc = {}
-        torch.cuda.synchronize()
-        gd.run_joint_steps(jp, 500, 5, lo, hi, z, 1, timers=acc)
-        tp = gd.timed_plan(jp)            # sub-batch 0 (timed beside the other sub-batch) when the step runs split
-        fam = {}
-        total_ms = 0.0
-        for i, (ms, cnt) in acc.items():
-            m = tp.meta.get(i, {})
-            total_ms += ms
-            f = fam.setdefault(m.get("family", m.get("what", "other").split(" ")[0]), dict(ms=0.0, launches=0, bytes=0, flops=0))
-            f["ms"] += ms
-            f["launches"] += cnt
-            f["bytes"] += m.get("bytes", 0) * cnt
-            f["flops"] += m.get("flops", 0) * cnt
-        if os.environ.get("LD_BENCH_OPS"):
-            with open(os.environ["LD_BENCH_OPS"], "w") as f:
-                for i in sorted(acc):
-                    ms, cnt = acc[i]
-                    m = tp.meta.get(i, {})
-                    us = 1e3 * ms / cnt
-                    f.write(f"{i:4d} {m.get('family', '?'):22s} {m.get('what', '?'):38s} {m.get('shape', ''):20s} "
-                            f"{us:9.1f} us  {m.get('bytes', 0) / max(us, 1e-9) / 1e3:8.1f} GB/s  "
-                            f"{m.get('flops', 0) / max(us, 1e-9) / 1e6:8.1f} TF/s\n")
-        # the north star's "ResBlock conv path": the C=32 3x3 convolutions at full resolution (SURVEY 8a census, first
-        # two lines), priced against the HBM roofline with their algorithmic bytes
-        rb_ms = rb_bytes = rb_n = 0
-        for i, (ms, cnt) in acc.items():
-            m = tp.meta.get(i, {})
-            if m.get("family", "").startswith("conv3x3") and m.get("shape", "").endswith(f"@{H}x{H}"):
-                rb_ms += ms
-                rb_bytes += m.get("bytes", 0) * cnt
-                rb_n += cnt
-        name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
-        sec = d["ms"] * 1e-3
-        gbs = d["bytes"] / sec / 1e9 if d["bytes"] else 0.0
-        tfs = d["flops"] / sec / 1e12 if d["flops"] else 0.0
-        peak_tf = MFMA_PEAK_TF[a.dtype]
-        hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / peak_tf
-        # a kernel is priced against the roofline that bounds it: the larger of the two fractions
-        if mfma_frac > hbm_frac:
-            roof = {"bound": "mfma", "achieved": tfs, "peak": peak_tf, "unit": "TFLOP/s", "frac": mfma_frac}
-        else:
-            roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # committed PMC pass (rocprofv3 --pmc), not live
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roof.update({"kernel": name, "launch_batch": int(tp.x_in.shape[0]),
-                     # launches of that many independent sub-batches share the GPU while this one is timed
-                     "concurrent_streams": (gd.sub_batches if tp is not jp else 1), "traffic": traffic, "avg_launch_us": 1e3 * d["ms"] / max(1, d["launches"]),
-                     "algorithmic_GBps": gbs, "algorithmic_TFLOPps": tfs,
-                     "share_of_step": d["ms"] / max(total_ms, 1e-9),
-                     # whole path: 0.7036 TB of algorithmic traffic per 256^2 bf16 patch over T=1000
-                     "path_frac": value / world * ALGO_TB_PER_PATCH * 1e3 / HBM_PEAK_GBS,
-                     "resblock_conv_path": {"launches_per_step": rb_n // 5, "ms_per_step": round(rb_ms / 5, 4),
-                                            "algorithmic_GBps": rb_bytes / max(rb_ms, 1e-9) / 1e6,
-                                            "hbm_frac": rb_bytes / max(rb_ms, 1e-9) / 1e6 / HBM_PEAK_GBS},
-                     "families_ms_per_step": {k: round(v["ms"] / 5, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}})
-        out["roofline"] = roof
+        out["roofline"] = roofline_leg(gd, jp, tp_value=value / world, dtype=a.dtype, H=H, lo=lo, hi=hi, z=z)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:        # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(net.cfg, sd, H)
     if rank == 0:

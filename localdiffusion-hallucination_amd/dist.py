@@ -72,14 +72,64 @@ def recompose(patches, masks):
     return out
 
 
+def _sample_shard(diffusion, lo, hi, per_sample_elems, call):
+    """Run ``call()`` with the diffusion object's noise stream positioned at sample ``lo`` of the global batch, so
+    that the shard draws exactly the x_T and z_t values the unsharded batch would draw for samples [lo, hi): the
+    sharded result equals the single-GPU result sample for sample."""
+    keep = getattr(diffusion, "noise_offset", 0)
+    diffusion.noise_offset = keep + lo * per_sample_elems
+    try:
+        return call()
+    finally:
+        diffusion.noise_offset = keep
+
+
 def sample_patches_sharded(diffusion, conds, min_max_val, n_images, k_masks, masks):
-    """Run ``diffusion.sample`` on this rank's shard of the [n_images*k_masks] patch list, gather,
-    recompose.  conds: [n_images*k_masks, Cc, H, W] (already masked per patch), identical on all ranks."""
+    """Independent local patches: run ``diffusion.sample`` on this rank's contiguous shard
+    of the [n_images*k_masks] patch list with no traffic inside the T-loop, ONE all-gather, recomposition by the
+    masks.  conds: [n_images*k_masks, Cc, H, W] (already masked per patch), identical on all ranks.
+    Returns the recomposed images [n_images, C, H, W] on every rank."""
     P = n_images * k_masks
-    local = shard_patches(conds)
-    if local.shape[0] > 0:
-        x = diffusion.sample(local, None, batch_size=local.shape[0], mask=None, min_max_val=min_max_val)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_bounds(P, world, rank)
+    C, H = diffusion.channels, diffusion.image_size
+    if hi > lo:
+        x = _sample_shard(diffusion, lo, hi, C * H * H, lambda: diffusion.sample(
+            conds[lo:hi], None, batch_size=hi - lo, mask=None, min_max_val=min_max_val))
     else:                                                    # more ranks than patches: replicas idle
-        x = conds.new_zeros((0, diffusion.channels, diffusion.image_size, diffusion.image_size))
+        x = conds.new_zeros((0, C, H, H), dtype=torch.float32)
     allx = gather_patches(x.to(torch.float32), P)
     return recompose(allx.reshape(n_images, k_masks, *allx.shape[1:]), masks)
+
+
+def sample_images_sharded(diffusion, cond_img, gt, masks, min_max_val, **sample_kw):
+    """The reference's own branch -> fusion -> joint path (ddpm.py:779-810, 955-970; cfg5) across ranks: the unit is
+    the IMAGE, so the OOD and the IND branch of an image stay on one rank through the fusion step and the joint
+    steps, and no collective is needed until the samples are complete.  Rank r runs
+    ``diffusion.sample(cond_img[lo:hi], gt[lo:hi], mask=masks[lo:hi])`` on its contiguous block of images with the
+    noise stream positioned at image ``lo``, then ONE all-gather returns the full batch on every rank:
+    [n, C, H, W] (fused), [2, n, C, H, W] (branches kept apart, ddpm.py:965-970) or a list of two [n, C, H, W]
+    tensors (DDIM without fusion, :1069-1075) -- whatever ``sample`` returns for the unsharded batch."""
+    n = cond_img.shape[0]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_bounds(n, world, rank)
+    C, H = diffusion.channels, diffusion.image_size
+    out = None
+    if hi > lo:
+        out = _sample_shard(diffusion, lo, hi, C * H * H, lambda: diffusion.sample(
+            cond_img[lo:hi], None if gt is None else gt[lo:hi], batch_size=hi - lo,
+            mask=None if masks is None else masks[lo:hi], min_max_val=min_max_val, **sample_kw))
+    # the layout of the result is a function of the flags, not of the shard: every rank (also an idle one) derives it
+    branch, fuse, _ = diffusion._flags(masks)
+    as_list = diffusion.is_ddim_sampling and branch and not fuse
+    stacked = (not diffusion.is_ddim_sampling) and (not fuse) and diffusion.branch_out
+    dev = cond_img.device
+    if out is None:
+        out = torch.zeros((2, 0, C, H, H) if (as_list or stacked) else (0, C, H, H), dtype=torch.float32, device=dev)
+    elif isinstance(out, (list, tuple)):
+        out = torch.stack(list(out), 0)
+    out = out.to(torch.float32)
+    if out.dim() == 5:                                       # [2, n_loc, ...]: gather along the image axis
+        full = gather_patches(out.transpose(0, 1).contiguous(), n).transpose(0, 1).contiguous()
+        return [full[0], full[1]] if as_list else full
+    return gather_patches(out, n)

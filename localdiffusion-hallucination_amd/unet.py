@@ -381,7 +381,13 @@ class _Plan:
         npx = self.B * h * w
         mt4 = cout % 64 == 0 and ((w + 15) // 16) * ((h + 7) // 8) * (cout // 64) * self.B >= 256
         big = ((w + 15) // 16) * ((h + 15) // 16) * (cout // (64 if mt4 else 32)) * self.B >= 512 and h >= 16 and not mt4
-        fam = f"conv3x3<{ {cabi.LD_F32: 'f32', cabi.LD_BF16: 'bf16', cabi.LD_F16: 'f16'}[self.dt] },{4 if mt4 else 2},{4 if big else 2}>"
+        dname = {cabi.LD_F32: "f32", cabi.LD_BF16: "bf16", cabi.LD_F16: "f16"}[self.dt]
+        fam = f"conv3x3<{dname},{4 if mt4 else 2},{4 if big else 2}>"
+        ck = 16 if self.dt == cabi.LD_F32 else 32
+        if (cout == 32 and len(srcs) == 1 and cin == ck and addend is None and h >= 32 and w >= 32 and h % 16 == 0
+                and w % 16 == 0 and (w // 16) * (h // 16) * self.B >= int(os.environ.get("LD_CONV_C32_MIN_TILES", "2048"))
+                and not os.environ.get("LD_CONV_NO_C32")):
+            fam = f"conv3x3_c32<{dname}>"              # the persistent LDS-DMA kernel takes it (conv3x3_c32.hip)
         in_el = sum(s.C * (npx // 4 if s.upsample else npx) for s in srcs)
         self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname,
                    dict(family=fam, bytes=(in_el + npx * cout + 9 * cin * cout) * self.esize + 4 * cout,

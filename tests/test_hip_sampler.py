@@ -331,6 +331,42 @@ def test_cfg5_shape_ddim_branch_fusion_matches_oracle():
     d = np.abs(run(gd16, cond, mask, 1) - got)
     print(f"cfg5 shape, bf16 vs fp32 storage: mean-abs {d.mean():.3e}  max-abs {d.max():.3e}")
     assert d.mean() <= 2e-2 and d.max() <= 0.3
+    # fp16 storage (the dtype BASELINE.json configs[4] names) against the ORACLE: 3 DDIM steps do not reach the
+    # chaotic tail of the chain, so the bound is the 16-bit forward tolerance
+    netf = ldh.Unet(dim=32, init_dim=32, compute_dtype="fp16", **kw)
+    netf.load_state_dict(sd)
+    gdf = ldh.GaussianDiffusion(conf, netf, image_size=H, timesteps=T, beta_schedule="sigmoid", objective="pred_x0",
+                                auto_normalize=False, sampling_timesteps=S).to("cuda")
+    gdf.noise_source = "host"
+    d = np.abs(run(gdf, cond, mask, 1) - ref)
+    print(f"cfg5 shape, fp16 storage vs oracle: mean-abs {d.mean():.3e}  max-abs {d.max():.3e}")
+    assert d.mean() <= 3e-3 and d.max() <= 6e-2
+
+
+def test_cfg5_as_stated_fp16_ddim50_branch_fusion():
+    """BASELINE.json configs[4] AS STATED on one GPU: 1x512x512, T=1000 strided to S=50 DDIM steps (eta 0), OOD / IND
+    branches with a circular OOD mask of radius 64 at the centre, fusion at times[-4], fp16 storage (full attention
+    over 4,096 tokens, fused linear attention).  The 50-step oracle run would take ~10 minutes of host time, so the
+    oracle comparison is the 3-step test above; here the stated run is compared with the SAME run in fp32 storage on
+    the HIP path (which that test pins to the oracle), and checked for the size-independent properties of the path:
+    fused output in the clamped range, replay determinism."""
+    H, T, S = 512, 1000, 50
+    kw = dict(mode="mri")
+    yy, xx = np.mgrid[0:H, 0:H]
+    mask = torch.from_numpy((((yy - H / 2) ** 2 + (xx - H / 2) ** 2) <= 64 ** 2).astype(np.float32))[None, None]
+    cond = torch.from_numpy(rng.uniform((1, 1, H, H), 12, 1, 0.0, 2.0))
+    conf = dict(branch_out=True, start_intermediate=True, start_timestep=2, data="mri", mask_x=True)
+    out = {}
+    for dtype in ("fp32", "fp16"):
+        gd = make(kw, conf, H, T, S, dtype=dtype)
+        out[dtype] = run(gd, cond, mask, 1)
+        assert out[dtype].shape == (1, 1, H, H) and np.isfinite(out[dtype]).all()
+        assert out[dtype].min() >= 0.0 and out[dtype].max() <= 2.0
+        if dtype == "fp16":
+            assert np.array_equal(run(gd, cond, mask, 1), out[dtype])          # replay: bitwise
+    d = np.abs(out["fp16"] - out["fp32"])
+    print(f"cfg5 as stated (512^2, S=50, branch + fusion at times[-4]): fp16 vs fp32 storage mean-abs {d.mean():.3e} max-abs {d.max():.3e}")
+    assert d.mean() <= 3e-2
 
 
 def test_checkpoint_round_trip_reproduces_cfg1_golden(golden, tmp_path):
