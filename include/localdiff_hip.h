@@ -330,6 +330,18 @@ int ld_mask_out(float* model_out, const float* mask, float min_val, int B, int C
 int ld_fuse_ddpm(const float* x_out, const float* x_in, const float* x0_out, const float* x0_in,
                  const float* mask, float* x, float* x0, float lo, float hi, int B, int C, int HW,
                  void* stream);
+/* K-mask generalisation of the two calls above (the reference has K = 2).  masks [B,K,HW]; branch 0
+ * is the OOD-style branch, branches 1..K-1 IND-style:
+ *   cond_k[0] = cond*(m_0>=1),  cond_k[k] = cond*clip((m_k>=1), lo_clip, 1)            -> cond_k [K,B,C,HW]
+ *   x0 = clamp(sum_{k>=1} clamp(x0_k)*(m_k>=1) + clamp(x0_0)),  x = first non-zero of x_k*(m_k>=1), k = 0..K-1
+ * x_rest / x0_rest hold branches 1..K-1 contiguously ([K-1,B,C,HW]); branch 0 has its own pointers (its state and
+ * prediction may live outside the denoiser's batch, ddpm.py:704-708).  With K = 2 and m_1 = 1-(m_0>=1) the results
+ * are bitwise those of ld_branch_conditions / ld_fuse_ddpm. */
+int ld_branch_conditions_k(const float* cond, const float* masks, float* cond_k, float lo_clip, int B, int C, int K,
+                           int HW, void* stream);
+int ld_fuse_ddpm_k(const float* x_first, const float* x_rest, const float* x0_first, const float* x0_rest,
+                   const float* masks, float* x, float* x0, float lo, float hi, int B, int C, int K, int HW,
+                   void* stream);
 /* posterior step from an already-formed x0 (fusion step, ddpm.py:809 + :858) */
 int ld_posterior_step(const float* x_t, const float* x0, const float* noise, float* x_prev,
                       const float* sched, const int32_t* t_ptr, int64_t n, void* stream);

@@ -97,6 +97,8 @@ _SIGS = {
     "ld_branch_conditions": (C.c_int, [vp, vp, vp, vp, f32, C.c_int, C.c_int, C.c_int, vp]),
     "ld_mask_out": (C.c_int, [vp, vp, f32, C.c_int, C.c_int, C.c_int, vp]),
     "ld_fuse_ddpm": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_branch_conditions_k": (C.c_int, [vp, vp, vp, f32, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_fuse_ddpm_k": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_fuse_ddim": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, C.c_int,
                                C.c_int, C.c_int, vp]),
     "ld_q_sample": (C.c_int, [vp, vp, vp, f32, f32, i64, vp]),

@@ -108,6 +108,37 @@ __global__ void fuse_ddpm_kernel(const float* xo, const float* xi, const float* 
     x[i] = (a == 0.0f) ? c : a;
   }
 }
+// K-mask generalisation: branch 0 = OOD-style, branches 1..K-1 = IND-style; masks [B,K,HW]
+__global__ void branch_cond_k_kernel(const float* cond, const float* masks, float* out, float lo_clip, int B, int C,
+                                     int K, int HW, long n) {
+  GRID_STRIDE(i, n) {                       // i over [B, C, HW]
+    const long bc = i / HW, p = i - bc * HW, b = bc / C;
+    const float c = cond[i];
+    for (int k = 0; k < K; ++k) {
+      const float bin = masks[((size_t)b * K + k) * HW + p] >= 1.0f ? 1.0f : 0.0f;
+      out[(size_t)k * n + i] = c * (k == 0 ? bin : clampf(bin, lo_clip, 1.0f));
+    }
+  }
+}
+__global__ void fuse_ddpm_k_kernel(const float* x_first, const float* x_rest, const float* x0_first, const float* x0_rest,
+                                   const float* masks, float* x, float* x0, float lo, float hi, int C, int K, int HW, long n) {
+  GRID_STRIDE(i, n) {
+    const long bc = i / HW, p = i - bc * HW, b = bc / C;
+    const float* mrow = masks + (size_t)b * K * HW + p;
+    // x0 = clamp(sum_{k>=1} clamp(x0_k) m_k + clamp(x0_0));  x = first non-zero of x_k m_k  (ddpm.py:784-804 per branch)
+    float m = mrow[HW] >= 1.0f ? 1.0f : 0.0f;
+    float acc = clampf(x0_rest[i], lo, hi) * m;
+    const float a0 = x_first[i] * (mrow[0] >= 1.0f ? 1.0f : 0.0f);
+    float xv = (a0 == 0.0f) ? x_rest[i] * m : a0;
+    for (int k = 2; k < K; ++k) {
+      m = mrow[(size_t)k * HW] >= 1.0f ? 1.0f : 0.0f;
+      acc += clampf(x0_rest[(size_t)(k - 1) * n + i], lo, hi) * m;
+      if (xv == 0.0f) xv = x_rest[(size_t)(k - 1) * n + i] * m;
+    }
+    x0[i] = clampf(acc + clampf(x0_first[i], lo, hi), lo, hi);
+    x[i] = xv;
+  }
+}
 struct FuseDdimK { float sr, srm1, san, c, sigma, lo, hi; };
 __global__ void fuse_ddim_kernel(const float* xo, const float* xi, const float* x0o, const float* x0i,
                                  const float* mask, const float* z, float* xn, FuseDdimK k, int C, int HW, long n) {
@@ -296,6 +327,24 @@ extern "C" int ld_fuse_ddpm(const float* x_out, const float* x_in, const float* 
   const long n = (long)B * C * HW;
   LD_LAUNCH(fuse_ddpm_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_out, x_in, x0_out, x0_in, mask, x, x0, lo, hi, C, HW, n);
   LD_LAUNCH_CHECK("fuse_ddpm");
+  return LD_OK;
+}
+extern "C" int ld_branch_conditions_k(const float* cond, const float* masks, float* cond_k, float lo_clip, int B, int C,
+                                      int K, int HW, void* stream) {
+  LD_REQUIRE(cond && masks && cond_k && K >= 2, "ld_branch_conditions_k: bad args (K >= 2)");
+  const long n = (long)B * C * HW;
+  LD_LAUNCH(branch_cond_k_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), cond, masks, cond_k, lo_clip, B, C, K, HW, n);
+  LD_LAUNCH_CHECK("branch_conditions_k");
+  return LD_OK;
+}
+extern "C" int ld_fuse_ddpm_k(const float* x_first, const float* x_rest, const float* x0_first, const float* x0_rest,
+                              const float* masks, float* x, float* x0, float lo, float hi, int B, int C, int K, int HW,
+                              void* stream) {
+  LD_REQUIRE(x_first && x_rest && x0_first && x0_rest && masks && x && x0 && K >= 2, "ld_fuse_ddpm_k: bad args (K >= 2)");
+  const long n = (long)B * C * HW;
+  LD_LAUNCH(fuse_ddpm_k_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_first, x_rest, x0_first, x0_rest, masks, x, x0,
+            lo, hi, C, K, HW, n);
+  LD_LAUNCH_CHECK("fuse_ddpm_k");
   return LD_OK;
 }
 extern "C" int ld_fuse_ddim(const float* x_out, const float* x_in, const float* x0_out, const float* x0_in,

@@ -280,7 +280,7 @@ class GaussianDiffusion(nn.Module):
         branch = bool(c["branch_out"]) or self.branch_out
         fuse = bool(c["start_intermediate"]) or self.start_intermediate
         mask_x = bool(c.get("mask_x", False)) or bool(c.get("ood_AD", False)) or bool(c.get("ood_confidence", False))
-        if branch and mask is not None:
+        if branch and mask is not None and mask.shape[1] == 1:
             u = torch.unique(mask)
             if len(u) == 1 and float(u[0]) == 1.0:        # "Original reverse process as AD is low"
                 branch, fuse, mask_x = False, False, False
@@ -500,6 +500,11 @@ class GaussianDiffusion(nn.Module):
                                        float(self.sqrt_one_minus_alphas_cumprod[t0]), n, st), "q_sample")
             start_t = t0 - 1
         z = torch.empty(shape, dtype=torch.float32, device=dev)
+        if branch and mask is not None and mask.shape[1] > 1:        # K-mask generalisation
+            if return_all_timesteps or return_all_outputs or (bool(self.config.get("classifier", False)) and fuse):
+                raise NotImplementedError("K-mask branching: history returns and the classifier gate exist for the "
+                                          "reference's two-branch form only")
+            return self._p_sample_loop_kmask(cond, mask, lo, hi, shape, x_T, z, start_t, fuse, mask_x)
         x0_buf = torch.empty(shape, dtype=torch.float32, device=dev) if return_all_outputs else None
         if return_all_timesteps and branch:
             # ddpm.py:963 stacks `imgs`, which holds [x_out, x_in] lists for every branch step (:865): torch.stack
@@ -624,6 +629,73 @@ class GaussianDiffusion(nn.Module):
         if return_all_outputs:
             return ret, hist_x0, []
         return ret
+
+    def _p_sample_loop_kmask(self, cond, masks, lo, hi, shape, x_T, z, start_t, fuse, mask_x):
+        """Branch -> fusion -> joint with K >= 2 masks [B,K,H,W] (the reference's loop, ddpm.py:672-708,
+        769-810, 852-858, has K = 2).  Branch 0 is the OOD-style branch (hard-masked conditioning; with mask_x its
+        prediction is replaced by the range minimum outside m_0, or by its conditioning for the datasets of :704-708),
+        branches 1..K-1 are IND-style (conditioning floored at 0.95 / 0.5).  All branches share each step's draw; at
+        t <= start_timestep they are recomposed (x0 = clamp(sum_k x0_k m_k), x_t = first non-zero of x_t,k m_k) and the
+        remaining steps run on the fused image.  Without fusion the K branch states come back as [K,B,C,H,W].
+        oracle/diffusion_ref.py::p_sample_loop_kmask is the restatement; for K = 2 and m_1 = 1 - (m_0 >= 1) both are
+        bitwise the two-branch path."""
+        lib, st, dev = cabi.lib(), self._st(), self.device
+        B, C, H, W = shape
+        K, HW, n = masks.shape[1], H * W, B * C * H * W
+        assert self.objective == "pred_x0", "branch mode exists only for pred_x0 (ddpm.py:739-749)"
+        sched, obj = self._sched_table(), cabi.OBJ[self.objective]
+        masks = masks.to(dev, torch.float32).contiguous()
+        m0 = masks[:, 0:1].contiguous()
+        if mask_x:
+            assert len(torch.unique((m0 >= 1.0).float())) == 2, "mask should be binary"   # ddpm.py:698
+        lo_clip = 0.5 if self.config["data"] == "mnist" else 0.95
+        cond_k = torch.empty((K,) + tuple(cond.shape), dtype=torch.float32, device=dev)
+        cabi.check(lib.ld_branch_conditions_k(cond.data_ptr(), masks.data_ptr(), cond_k.data_ptr(), lo_clip, B,
+                                              cond.shape[1], K, HW, st), "branch_conditions_k")
+        replaced = self._replaced_out(mask_x)
+        nb = (K - 1) * B if replaced else K * B
+        plan = self.model.plan(nb, H, W, table_T=self.num_timesteps_ori)
+        plan.cond_in.copy_((cond_k[1:] if replaced else cond_k).reshape(nb, *cond.shape[1:]))
+        plan.run_cond(st)
+        x_first = torch.empty(shape, dtype=torch.float32, device=dev) if replaced else plan.x_in[:B]
+        x_rest = plan.x_in if replaced else plan.x_in[B:]
+        mo_first = cond_k[0] if replaced else plan.model_out[:B]
+        mo_rest = plan.model_out if replaced else plan.model_out[B:]
+        x_first.copy_(x_T)
+        x_rest.copy_(x_T.repeat(K - 1, 1, 1, 1))
+        t, draw = start_t, 1
+        fused = False
+        while t >= 0:
+            plan.set_step(t)
+            plan.run_main(st)
+            if mask_x and not replaced:
+                cabi.check(lib.ld_mask_out(mo_first.data_ptr(), m0.data_ptr(), lo, B, C, HW, st), "mask_out")
+            if t > 0:
+                self._noise(z, draw)
+                draw += 1
+            if fuse and t <= int(self.config["start_timestep"]):
+                jp = self.model.plan(B, H, W, table_T=self.num_timesteps_ori)
+                x0f = torch.empty(shape, dtype=torch.float32, device=dev)
+                cabi.check(lib.ld_fuse_ddpm_k(x_first.data_ptr(), x_rest.data_ptr(), mo_first.data_ptr(), mo_rest.data_ptr(),
+                                              masks.data_ptr(), jp.x_in.data_ptr(), x0f.data_ptr(), lo, hi, B, C, K, HW, st),
+                           "fuse_ddpm_k")
+                jp.set_step(t)
+                cabi.check(lib.ld_posterior_step(jp.x_in.data_ptr(), x0f.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(),
+                                                 sched.data_ptr(), jp.t_dev.data_ptr(), n, st), "posterior_step")
+                t -= 1
+                fused = True
+                break
+            views = [(x_first, mo_first)] + [(x_rest[(k - 1) * B:k * B], mo_rest[(k - 1) * B:k * B]) for k in range(1, K)]
+            for xv, mv in views:                               # one shared draw for every branch (ddpm.py:852-858)
+                cabi.check(lib.ld_ddpm_step(xv.data_ptr(), mv.data_ptr(), z.data_ptr(), xv.data_ptr(), None,
+                                            sched.data_ptr(), plan.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+            t -= 1
+        if not fused:
+            return torch.cat([x_first.reshape(1, *shape), x_rest.reshape(K - 1, *shape)], 0).clone()
+        jp.cond_in.copy_(cond)
+        jp.run_cond(st)
+        self.run_joint_steps(jp, t, t + 1, lo, hi, z, draw)
+        return jp.x_in.clone()
 
     def _gated_joint_steps(self, jp, t, lo, hi, z, draw, x0_buf, x_branchout, cond, cond_out, cond_in, mask,
                            mask_x, after):

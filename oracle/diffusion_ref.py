@@ -273,6 +273,81 @@ class RefSampler:
             return ret, x_start_lst, []
         return ret
 
+    # --- K-mask generalisation of the branch -> fusion -> joint loop (NOT in the reference, which has two
+    #     branches).  Branch 0 is the OOD-style branch (hard-masked conditioning, mask_x on its prediction), branches
+    #     1..K-1 are IND-style (conditioning floored at lo_clip).  Every formula is the reference's with "in" read as
+    #     "each further branch": for K = 2 and masks [m, 1 - (m >= 1)] the arithmetic below is operation for operation
+    #     that of predict_branches / _fuse_step / p_sample_loop, and tests assert it reproduces the reference goldens
+    #     bit for bit.
+    def kmask_conditions(self, cond, masks):
+        """masks [B,K,H,W] -> (binary masks, [cond_0 .. cond_{K-1}])  (ddpm.py:672-690 per branch)."""
+        lo = 0.5 if self.o.data == "mnist" else 0.95
+        binary = (masks >= 1.0).float()
+        conds = [(cond * binary[:, 0:1]).float()]
+        for k in range(1, masks.shape[1]):
+            conds.append((cond * torch.clip(binary[:, k:k + 1], lo, 1.0)).float())
+        return binary, conds
+
+    def kmask_predict(self, xs, cond, masks, t, lohi, mask_x):
+        assert self.o.objective == "pred_x0", "branch mode exists only for pred_x0 (ddpm.py:739-749)"
+        binary, conds = self.kmask_conditions(cond, masks)
+        tv = self._tvec(xs[0].shape[0], t)
+        replaced = mask_x and any(k in self.o.data for k in _REPLACE_OUT) and "mri" not in self.o.data
+        outs = [None] + [self.f(xs[k], conds[k], tv) for k in range(1, len(xs))]
+        b0 = binary[:, 0:1]
+        if replaced:                                             # ddpm.py:704-708
+            outs[0] = conds[0].clone()
+        else:
+            outs[0] = self.f(xs[0], conds[0], tv)
+            if mask_x:                                           # ddpm.py:700-703
+                outs[0] = outs[0] * b0
+                outs[0] = torch.where(b0 == 0.0, torch.tensor(float(lohi[0])), outs[0])
+        return binary, [o.clamp(lohi[0], lohi[1]) for o in outs]   # p_mean_variance clamps every branch (:775-776)
+
+    def kmask_fuse(self, xs, x0s, binary, lohi):
+        """ddpm.py:784-804 for K branches: x0 = clamp(sum_{k>=1} x0_k m_k + x0_0); x = first non-zero of x_k m_k."""
+        acc = x0s[1] * binary[:, 1:2]
+        for k in range(2, len(xs)):
+            acc = acc + x0s[k] * binary[:, k:k + 1]
+        x0 = (acc + x0s[0]).clamp(lohi[0], lohi[1])
+        parts = [xs[k] * binary[:, k:k + 1] for k in range(len(xs))]
+        x = parts[0]
+        for k in range(1, len(xs)):
+            x = torch.where(x == 0.0, parts[k], x)
+        return x, x0
+
+    def p_sample_loop_kmask(self, cond, masks, lohi, shape, noise, fuse, mask_x, record=None):
+        """K branches with a shared draw per step (ddpm.py:852-858), fused at t <= start_timestep when ``fuse``, joint
+        single-branch steps afterwards; without ``fuse`` returns the K branch states stacked [K,B,C,H,W]."""
+        o, K = self.o, masks.shape[1]
+        x = noise(shape)
+        xs = [x] * K
+        joint = False
+        for t in range(self.T - 1, -1, -1):
+            sigma = (0.5 * self._c("posterior_log_variance_clipped", t)).exp()
+            if not joint:
+                binary, x0s = self.kmask_predict(xs, cond, masks, t, lohi, mask_x)
+                if fuse and t <= o.start_timestep:
+                    x, x0 = self.kmask_fuse(xs, x0s, binary, lohi)
+                    z = noise(x.shape) if t > 0 else 0.0
+                    x = self.posterior_mean(x0, x, t) + sigma * z
+                    joint, xs = True, None
+                    if record:
+                        record(t, x)
+                    continue
+                z = noise(xs[0].shape) if t > 0 else 0.0
+                xs = [self.posterior_mean(x0s[k], xs[k], t) + sigma * z for k in range(K)]
+                if record:
+                    record(t, xs)
+            else:
+                _, x0 = self.predict_single(x, cond, t, lohi, False)
+                x0 = x0.clamp(lohi[0], lohi[1])
+                z = noise(x.shape) if t > 0 else 0.0
+                x = self.posterior_mean(x0, x, t) + sigma * z
+                if record:
+                    record(t, x)
+        return x if joint else torch.stack(xs, dim=0)
+
     # --- DDIM (ddpm.py:980-1075) ---
     def ddim_sample(self, cond, mask, lohi, shape, noise, branch, fuse, mask_x, return_all_timesteps=False):
         o = self.o

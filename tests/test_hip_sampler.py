@@ -137,6 +137,47 @@ def test_use_gt_start_and_return_all(golden):
                       min_max_val=(0.0, 2.0), return_all_timesteps=True)
 
 
+@pytest.mark.parametrize("data,kw,H", [("mri", dict(mode="mri"), 32), ("mnist", MNIST, 28)])
+def test_kmask_branching_k2_is_the_reference_path(golden, data, kw, H):
+    """the K-mask loop with K = 2 and masks [m, 1 - (m >= 1)] against the reference's two-branch golden
+    (G6) -- and bit for bit against the two-branch HIP path, since ld_branch_conditions_k / ld_fuse_ddpm_k perform the
+    same operations as ld_branch_conditions / ld_fuse_ddpm."""
+    g = golden("g6_branch_fusion")
+    cond = torch.from_numpy(rng.uniform((2, 1, H, H), 6, 1, 0.0, 2.0))
+    mask = torch.zeros(2, 1, H, H)
+    mask[:, :, :, :H // 4] = 1.0
+    masks = torch.cat([mask, 1.0 - (mask >= 1.0).float()], 1)
+    gd = make(kw, dict(data=data, branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True), H, 50)
+    two = run(gd, cond, mask, 2)
+    k2 = run(gd, cond, masks, 2)
+    check(f"K-mask loop, K=2, {data}{H}", k2, g[f"{data}{H}_final"])
+    assert np.array_equal(k2, two)
+
+
+def test_kmask_branching_k4_matches_oracle():
+    """K = 4 masks (one OOD band + three IND bands partitioning the image), fusion at t <= 3 of T = 14, and the same
+    without fusion ([K,B,C,H,W]), against the oracle's K-mask restatement on the host."""
+    from oracle import diffusion_ref
+    H, B, T, K = 32, 2, 14, 4
+    kw = dict(mode="mri")
+    masks = torch.zeros(B, K, H, H)
+    for k in range(K):
+        masks[:, k, :, k * (H // K):(k + 1) * (H // K)] = 1.0
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 44, 1, 0.0, 2.0))
+    for fuse in (True, False):
+        gd = make(kw, dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=3, mask_x=True), H, T)
+        got = run(gd, cond, masks, B)
+        sd = {k: v.detach().cpu() for k, v in gd.model.state_dict().items()}
+        o = diffusion_ref.SamplerOptions(timesteps=T, branch_out=True, start_intermediate=fuse, start_timestep=3, data="mri", mask_x=True)
+        smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd, gd.model.cfg), o, 1, H)
+        ns = rng.NoiseStream(10)
+        with torch.no_grad():
+            ref = smp.p_sample_loop_kmask(cond, masks, (0.0, 2.0), (B, 1, H, H), lambda s: torch.from_numpy(ns.next(tuple(s))),
+                                          fuse, True).numpy()
+        assert got.shape == ((B, 1, H, H) if fuse else (K, B, 1, H, H))
+        check(f"K-mask loop, K=4, fuse={fuse} vs oracle", got, ref)
+
+
 class StubClassifier:
     """Same stand-in as tools/make_goldens.py: score -1 for the first ``reject`` calls, +1 afterwards."""
     def __init__(self, reject):

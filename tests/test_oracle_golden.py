@@ -201,3 +201,30 @@ def test_use_gt_start_and_return_all(golden):
     with pytest.raises(TypeError):         # per-branch [out, in] lists cannot be stacked: the reference raises here too
         smp(CFG_MRI, 32, 40, data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True).sample(
             torch.from_numpy(g["b_cond"]), torch.from_numpy(g["b_mask"]), (0.0, 2.0), 2, Noise(), return_all_timesteps=True)
+
+
+def test_kmask_generalisation_reduces_to_the_reference_for_two_branches(golden):
+    """the K-mask branch -> fusion loop of the oracle, run with K = 2 and masks [m, 1 - (m >= 1)], must
+    give the reference's two-branch goldens BIT FOR BIT (G6: fusion at t <= 2, mri = OOD prediction kept, mnist = OOD
+    prediction replaced by cond_out; G3: branches kept apart)."""
+    g = golden("g6_branch_fusion")
+    for tag, cfg, H, data in [("mri32", CFG_MRI, 32, "mri"), ("mnist28", CFG_MNIST, 28, "mnist")]:
+        cond = torch.from_numpy(rng.uniform((2, 1, H, H), 6, 1, 0.0, 2.0))
+        mask = torch.zeros(2, 1, H, H)
+        mask[:, :, :, :H // 4] = 1.0
+        masks = torch.cat([mask, 1.0 - (mask >= 1.0).float()], 1)
+        o = diffusion_ref.SamplerOptions(timesteps=50, branch_out=True, start_intermediate=True, start_timestep=2, data=data, mask_x=True)
+        smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(cfg), cfg), o, 1, H)
+        with torch.no_grad():
+            out = smp.p_sample_loop_kmask(cond, masks, (0.0, 2.0), (2, 1, H, H), Noise(), True, True)
+            two = smp.sample(cond, mask, (0.0, 2.0), 2, Noise())
+        assert torch.equal(out, two), tag                                  # same operations: bit-equal to the 2-branch oracle
+        np.testing.assert_allclose(out.numpy(), g[tag + "_final"], atol=1e-6, rtol=0)    # and that is the reference golden
+    g3 = golden("g3_three_step")
+    cond, mask = torch.from_numpy(g3["cond"]), torch.from_numpy(g3["mask"])
+    masks = torch.cat([mask, 1.0 - (mask >= 1.0).float()], 1)
+    o = diffusion_ref.SamplerOptions(timesteps=3, branch_out=True, start_intermediate=False, data="mri", mask_x=True)
+    smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(CFG_MNIST), CFG_MNIST), o, 1, 28)
+    with torch.no_grad():
+        out = smp.p_sample_loop_kmask(cond, masks, (0.0, 2.0), (2, 1, 28, 28), Noise(), False, True)
+    np.testing.assert_allclose(out.numpy(), g3["branch_nofuse"], atol=1e-6, rtol=0)
