@@ -70,9 +70,13 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
   constexpr int NST = MT * NW;                                                              // store instructions per wave per tile
   constexpr bool P = DT<T>::precise;
 
+  // Single-chunk launches (32 -> 32) keep the wave's 18 weight fragments in REGISTERS for the whole launch: every wave
+  // re-reading them from LDS for every tile was 144 of the 240 KB of LDS operand traffic per item (1,100 of ~1,900
+  // LDS-bandwidth cycles per item against 1,150 cycles of MFMA), and it frees 18 KB of LDS.
+  constexpr bool WREG = NCH == 1;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  char* s_w = smem;                                   // [NCH][9][MT][1 KiB]
-  char* s_x = smem + NCH * WCH;                       // [R slots][NBLK][kq][16 px][16 B]
+  char* s_w = smem;                                   // [NCH][9][MT][1 KiB]  (WREG: not allocated)
+  char* s_x = smem + (WREG ? 0 : NCH * WCH);          // [R slots][NBLK][kq][16 px][16 B]
   float* s_coef = reinterpret_cast<float*>(s_x + R * XBUF);
   double* s_stat = reinterpret_cast<double*>(s_x);    // [8 waves][2][32] / coefficient scratch (before / after the ring)
 
@@ -91,9 +95,17 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
   if (tracing) tr_t[0] = __builtin_readcyclecounter();
 
   // ---- one-time setup: weights -> LDS, bias -> registers, GroupNorm coefficients -> LDS
+  uint4 Areg[WREG ? 9 : 1][MT];
   {
     const uint4* wg = reinterpret_cast<const uint4*>(a.w);
-    for (int u = tid; u < NCH * 9 * MT * 64; u += 512) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[u];
+    if constexpr (WREG) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) Areg[tap][m] = wg[(tap * MT + m) * 64 + lane];
+    } else {
+      for (int u = tid; u < NCH * 9 * MT * 64; u += 512) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[u];
+    }
   }
   float4 bias[MT];
 #pragma unroll
@@ -116,6 +128,13 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
   // would drain the whole ring on every tile.
 #pragma unroll
   for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(bias[m].x), "v"(bias[m].y), "v"(bias[m].z), "v"(bias[m].w));
+  if constexpr (WREG) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        asm volatile("" ::"v"(Areg[tap][m].x), "v"(Areg[tap][m].y), "v"(Areg[tap][m].z), "v"(Areg[tap][m].w));
+  }
 
   if (tracing) tr_t[1] = __builtin_readcyclecounter();
   // tile-independent halo coordinates of the ring blocks this thread loads and post-processes
@@ -246,12 +265,14 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
       if (!(DBG & 4)) {
         const char* xb = s_x + slot * XBUF + kq * 256;
         const char* wb = s_w + cur.ch * WCH + lane * 16;
-        uint4 A[2][3][MT], Bq[2][NW + 2];
+        uint4 A[WREG ? 1 : 2][WREG ? 1 : 3][MT], Bq[2][NW + 2];
         auto load_frags = [&](int dx, int set) {
+          if constexpr (!WREG) {
 #pragma unroll
-          for (int dy = 0; dy < 3; ++dy)
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) A[set][dy][m] = *reinterpret_cast<const uint4*>(wb + ((dy * 3 + dx) * MT + m) * 1024);
+              for (int m = 0; m < MT; ++m) A[set][dy][m] = *reinterpret_cast<const uint4*>(wb + ((dy * 3 + dx) * MT + m) * 1024);
+          }
 #pragma unroll
           for (int rr = 0; rr < NW + 2; ++rr) {
             const int q = (wv * NW + rr) * HC + dx + px;
@@ -269,7 +290,10 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
               const int j = rr - dy;
               if (j >= 0 && j < NW) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[dx & 1][dy][m], Bq[dx & 1][rr]);
+                for (int m = 0; m < MT; ++m) {
+                  if constexpr (WREG) mma16<T>(acc[m][j], Areg[dy * 3 + dx][m], Bq[dx & 1][rr]);
+                  else mma16<T>(acc[m][j], A[dx & 1][dy][m], Bq[dx & 1][rr]);
+                }
               }
             }
           }
@@ -378,7 +402,7 @@ int launch_c32(const C32Dev& a0, hipStream_t st) {
   a.tiles_x = a.W / 16;
   a.ntiles = a.tiles_x * (a.H / 16);
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
-  const size_t lds = (size_t)NCH * 9 * 2 * 1024 + (size_t)R * 21 * 1024 + 2 * ctot * sizeof(float);
+  const size_t lds = (NCH == 1 ? 0 : (size_t)NCH * 9 * 2 * 1024) + (size_t)R * 21 * 1024 + 2 * ctot * sizeof(float);
   static const int cus = getenv("LD_CONV_C32_CUS") ? atoi(getenv("LD_CONV_C32_CUS")) : 256;
   int G = (cus + a.B - 1) / a.B;                       // one workgroup per CU over the whole launch
   if (G > a.ntiles) G = a.ntiles;
@@ -434,13 +458,12 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   a.dbg = dbg;
   static const int ring = getenv("LD_CONV_C32_R") ? atoi(getenv("LD_CONV_C32_R")) : 6;   // experiment: ring depth
   int rc;
-  (void)ring;
   if (p->dtype == LD_F32) rc = launch_c32<float, 1, 6>(a, st);
-  else if (p->dtype == LD_F16) rc = launch_c32<f16, 1, 6>(a, st);
+  else if (p->dtype == LD_F16) rc = ring == 4 ? launch_c32<f16, 1, 4>(a, st) : launch_c32<f16, 1, 6>(a, st);
+  else if (ring == 4) rc = launch_c32<bf16, 1, 4>(a, st);
 #ifdef LD_DEBUG_VARIANTS
   else if (ring == 2) rc = launch_c32<bf16, 1, 2>(a, st);
   else if (ring == 3) rc = launch_c32<bf16, 1, 3>(a, st);
-  else if (ring == 4) rc = launch_c32<bf16, 1, 4>(a, st);
 #endif
   else rc = launch_c32<bf16, 1, 6>(a, st);
   return rc == LD_OK ? 1 : rc;
