@@ -1,10 +1,24 @@
 #!/bin/bash
-# Build liblocaldiff_hip.so for gfx950 (cross-compiles without a GPU).  Usage: ./build.sh [-j N]
+# Build liblocaldiff_hip.so for gfx950 (cross-compiles without a GPU).
+#   ./build.sh                   incremental: recompile the sources that are newer than their objects
+#   ./build.sh --clean           remove build/ and the library first (what __graft_entry__.build() does by default)
+#   ./build.sh --debug-variants  also instantiate the LD_CONV_DEBUG ablation / trace kernels (-DLD_DEBUG_VARIANTS);
+#                                the flag is recorded in build/.flags, so switching it rebuilds everything
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off"
+CLEAN=0
+for arg in "$@"; do
+  case "$arg" in
+    --clean) CLEAN=1 ;;
+    --debug-variants) FLAGS="$FLAGS -DLD_DEBUG_VARIANTS" ;;
+    *) echo "build.sh: unknown option $arg" >&2; exit 2 ;;
+  esac
+done
+if [ $CLEAN = 1 ]; then rm -rf build liblocaldiff_hip.so; fi
 mkdir -p build
+if [ "$(cat build/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f build/*.o; echo "$FLAGS" > build/.flags; fi
 pids=()
 for f in runtime pack conv3x3 conv3x3_c32 conv1x1 conv_image gn_apply linattn linattn_fused attention time_embed pointwise; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.hip.h -nt build/$f.o ] || [ ../../include/localdiff_hip.h -nt build/$f.o ]; then

@@ -1,0 +1,454 @@
+// SHELVED EXPERIMENT (round 2): conv1x1 with the whole K extent staged before the MFMAs (FULLK).  Correct (all op tests pass),
+// not faster: 384->256 @32^2 +tail 19.8 -> 22.0 us solo / 20.3 -> 17.9 in situ, to_qkv 256->384 14.3 -> 19.9 solo, downsample
+// 256->128 11.2 -> 7.6; whole step 1.609 -> 1.622 ms.  The K loop of the small-map 1x1 convolutions is not a chain of exposed round
+// trips (co-resident workgroups already overlap them); kept for the record, not built.
+// 1x1 convolution = GEMM over channels on MFMA, NHWC, gfx950, with the attention plumbing of the
+// reference fused in as prologues / epilogues:
+//   - input: channel concat of two tensors (res_conv over torch.cat, ddpm.py:198,439-443),
+//            pixel-unshuffle gather (Downsample, ddpm.py:120-124),
+//            RMSNorm on the input (ddpm.py:131-132,237,274): the per-pixel 1/max(||x||,1e-12) is
+//            accumulated while the tile is staged and applied to the output column; g*sqrt(C) is
+//            folded into the packed weight;
+//   - output: bias; q-softmax over each head's 32 channels * dim_head^-0.5 (ddpm.py:242,245);
+//            RMSNorm over the output channels + residual (ddpm.py:229-232,425,444);
+//            residual add (ddpm.py:425,431,444);
+//   - per-batch weights (weight_bstride) so that linear attention's  to_out(ctx^T q)  is one GEMM
+//     with M_b = W_out (ctx_b/Z_b)^T  (see linattn.hip).
+//
+// Tiling: 256 threads = 4 waves; tile = 64*NW consecutive pixels of one image x 16*MT output
+// channels; wave w owns pixel tiles [w*NW,(w+1)*NW) and all MT channel tiles.
+#include "common.hip.h"
+#include <stdlib.h>
+
+namespace {
+
+struct Conv1Dev {
+  SrcDev s[2];
+  int nsrc, unshuffle, rms_in;
+  const void* w;
+  long w_bstride;
+  const float* bias;
+  int epi, hidden;
+  float q_scale;
+  const float* g2;
+  const void* res;
+  void* out;
+  unsigned* kmax;
+  SrcDev tail;          // LD_EPI_GN_TAIL operand
+  int B, H, W, Cout;
+  int fullk;            // host decision: stage the whole K extent first (small maps)
+};
+
+// EPI (the epilogue kind) is a template parameter: as a runtime switch inside the store loop it kept every
+// epilogue's registers and branches alive in every launch.
+// FULLK (small maps): the K loop of the plain variant is one dependent global round trip per 64-byte channel chunk
+// (load -> LDS -> barrier -> MT*NW MFMAs: 12-16 round trips for the 384- and 512-channel inputs of the 32^2 / 64^2
+// stages, 15-20 us for a megabyte of data).  Here the WHOLE K extent of the tile (<= 16 chunks) is staged first, in
+// groups of FG chunks whose loads are all in flight together, then one barrier, then every MFMA: 2 round trips.
+constexpr int FG = 8;                                                // chunks per load group of the FULLK variant
+template <typename T, int MT, int NW, int EPI, bool FULLK = false>
+__global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
+  constexpr int E = DT<T>::E, CK = DT<T>::CK;
+  constexpr int NPT = 64 * NW, PLANE = NPT * 16;
+  constexpr int XCH = 4 * PLANE, WCHB = MT * 1024;                    // bytes of one staged chunk: tile, weights
+
+  // K-chunk bookkeeping: plain = chunks of src0 then src1; unshuffle = 4 sub-pixels x chunks of src0
+  const int nc0 = a.s[0].C / CK;
+  const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_x = smem;                                                  // FULLK: [nch][4][PLANE]
+  char* s_w = smem + (FULLK ? nch : 1) * XCH;                        // FULLK: [nch][MT][1 KiB]
+  float* s_rinv = reinterpret_cast<float*>(s_w + (FULLK ? nch : 1) * WCHB);
+  float* s_tcoef = s_rinv + NPT;                                   // [2*Cout] GN_TAIL coefficients, then 64 doubles scratch
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
+  const int b = blockIdx.z, m0 = blockIdx.y * MT;
+  const int HW = a.H * a.W, p0 = blockIdx.x * NPT;
+  const int mt_total = a.Cout / 16;
+
+  if (EPI == LD_EPI_GN_TAIL)
+    build_gn_coef(a.tail, b, 0, (long)HW, s_tcoef, reinterpret_cast<double*>(s_tcoef + 2 * a.Cout), tid, 256);
+
+  f32x4 acc[MT][NW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float rs[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) rs[i] = 0.f;
+
+  // The epilogue's second operand (residual / GroupNorm-tail input) does not depend on the GEMM: request it now,
+  // so its global round trip overlaps the K loop instead of following it.
+  constexpr bool HAS_OP2 = EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES || EPI == LD_EPI_GN_TAIL;
+  float op2[HAS_OP2 ? MT : 1][HAS_OP2 ? NW : 1][4];
+  if constexpr (HAS_OP2) {
+    const T* src2 = reinterpret_cast<const T*>(EPI == LD_EPI_GN_TAIL ? a.tail.data : a.res);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int p = p0 + (wv * NW + j) * 16 + px;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        if (p < HW) load4<T>(src2 + ((size_t)b * HW + p) * a.Cout + (m0 + m) * 16 + kq * 4, op2[m][j]);
+        else op2[m][j][0] = op2[m][j][1] = op2[m][j][2] = op2[m][j][3] = 0.f;
+      }
+    }
+  }
+
+  const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)b * a.w_bstride);
+
+  // global address of this thread's fragment of chunk `ch` for tile pixel slot `it` (nullptr: past the image)
+  auto frag_ptr = [&](int ch, int it) -> const uint4* {
+    int si = 0, c0, p1 = 0, p2 = 0;
+    if (a.unshuffle) {
+      const int pp = ch / nc0;
+      c0 = (ch - pp * nc0) * CK;
+      p1 = pp >> 1; p2 = pp & 1;
+    } else {
+      si = ch >= nc0 ? 1 : 0;
+      c0 = (ch - si * nc0) * CK;
+    }
+    const T* sdata = reinterpret_cast<const T*>(si ? a.s[1].data : a.s[0].data);
+    const int Cs = si ? a.s[1].ld : a.s[0].ld;   // pixel stride in elements
+    const int p = p0 + (it * 4 + wv) * 16 + px;
+    if (p >= HW) return nullptr;
+    size_t pix;
+    if (a.unshuffle) {
+      const int y = p / a.W, x = p - y * a.W;
+      pix = ((size_t)b * (2 * a.H) + 2 * y + p1) * (2 * a.W) + 2 * x + p2;
+    } else {
+      pix = (size_t)b * HW + p;
+    }
+    return reinterpret_cast<const uint4*>(sdata + pix * Cs + c0 + kq * E);
+  };
+  auto stage = [&](const uint4& raw, int it, char* xdst) {             // tile fragment -> LDS (+ RMSNorm sum of squares)
+    if (a.rms_in) {
+      float v[E];
+      unpack16<T>(raw, v);
+#pragma unroll
+      for (int e = 0; e < E; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
+    }
+    *reinterpret_cast<uint4*>(xdst + kq * PLANE + ((it * 4 + wv) * 16 + px) * 16) = raw;
+  };
+  auto mfma_chunk = [&](const char* xsrc, const char* wsrc) {
+    uint4 A[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) A[m] = *reinterpret_cast<const uint4*>(wsrc + m * 1024 + lane * 16);
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const uint4 Bf = *reinterpret_cast<const uint4*>(xsrc + kq * PLANE + ((wv * NW + j) * 16 + px) * 16);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[m], Bf);
+    }
+  };
+  constexpr int WPT = (MT * 64 + 255) / 256;                           // weight fragments per thread and chunk
+  if constexpr (FULLK) {
+    for (int c0 = 0; c0 < nch; c0 += FG) {
+      uint4 raw[FG][NW], wr[FG][WPT];
+#pragma unroll
+      for (int g = 0; g < FG; ++g) {
+        if (c0 + g < nch) {                                            // uniform
+#pragma unroll
+          for (int it = 0; it < NW; ++it) {
+            const uint4* gp = frag_ptr(c0 + g, it);
+            raw[g][it] = gp ? *gp : make_uint4(0u, 0u, 0u, 0u);
+          }
+#pragma unroll
+          for (int k = 0; k < WPT; ++k) {
+            const int u = k * 256 + tid;
+            wr[g][k] = u < MT * 64 ? wg[((size_t)(c0 + g) * mt_total + m0) * 64 + u] : make_uint4(0u, 0u, 0u, 0u);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < FG; ++g) {
+        if (c0 + g < nch) {
+#pragma unroll
+          for (int it = 0; it < NW; ++it) stage(raw[g][it], it, s_x + (size_t)(c0 + g) * XCH);
+#pragma unroll
+          for (int k = 0; k < WPT; ++k) {
+            const int u = k * 256 + tid;
+            if (u < MT * 64) *reinterpret_cast<uint4*>(s_w + (size_t)(c0 + g) * WCHB + u * 16) = wr[g][k];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) mfma_chunk(s_x + (size_t)ch * XCH, s_w + (size_t)ch * WCHB);
+  } else {
+    for (int ch = 0; ch < nch; ++ch) {
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NW; ++it) {
+        const uint4* gp = frag_ptr(ch, it);
+        stage(gp ? *gp : make_uint4(0u, 0u, 0u, 0u), it, s_x);
+      }
+#pragma unroll
+      for (int k = 0; k < WPT; ++k) {
+        const int u = k * 256 + tid;
+        if (u < MT * 64) *reinterpret_cast<uint4*>(s_w + u * 16) = wg[((size_t)ch * mt_total + m0) * 64 + u];
+      }
+      __syncthreads();
+      mfma_chunk(s_x, s_w);
+    }
+  }
+
+  if (a.rms_in) {
+    // the 4 kq lanes of a staged pixel sit 16 lanes apart in the same wave
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      float r = rs[it];
+      r += __shfl_xor(r, 16);
+      r += __shfl_xor(r, 32);
+      if (kq == 0) s_rinv[(it * 4 + wv) * 16 + px] = rms_rinv<DT<T>::precise>(r);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channels (m0+m)*16 + 4kq + r of pixel p0 + (wv*NW+j)*16 + px
+  T* out = reinterpret_cast<T*>(a.out);
+  const bool q_part = (m0 * 16) < a.hidden;
+  const bool k_part = a.kmax != nullptr && (m0 * 16) >= a.hidden && (m0 * 16) < 2 * a.hidden;
+  float cmax[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cmax[m][r] = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int qq = (wv * NW + j) * 16 + px;
+    const int p = p0 + qq;
+    const bool valid = p < HW;
+    const float rinv = a.rms_in ? s_rinv[qq] : 1.0f;
+    float v[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int co = (m0 + m) * 16 + kq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[m][r] = acc[m][j][r] * rinv + (a.bias ? a.bias[co + r] : 0.f);
+    }
+    if (EPI == LD_EPI_QKV_LINEAR && q_part) {
+      // softmax over the 32 channels of each head = 2 channel tiles x 4 regs x 4 kq lanes
+#pragma unroll
+      for (int m = 0; m < MT; m += 2) {   // MT is even; (m, m+1) = one head
+        float mx = v[m][0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mx = fmaxf(mx, v[m][r]); mx = fmaxf(mx, v[m + 1][r]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[m][r] = DT<T>::precise ? expf(v[m][r] - mx) : __expf(v[m][r] - mx);
+          v[m + 1][r] = DT<T>::precise ? expf(v[m + 1][r] - mx) : __expf(v[m + 1][r] - mx);
+          sum += v[m][r] + v[m + 1][r];
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float sc = DT<T>::precise ? a.q_scale / sum : a.q_scale * __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[m][r] *= sc; v[m + 1][r] *= sc; }
+      }
+    } else if (EPI == LD_EPI_QKV_FULL && q_part) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[m][r] *= a.q_scale;
+    } else if (EPI == LD_EPI_RMS_RES) {
+      float ss = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss = fmaf(v[m][r], v[m][r], ss);
+      ss += __shfl_xor(ss, 16);
+      ss += __shfl_xor(ss, 32);
+      const float inv = rms_rinv<DT<T>::precise>(ss);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int co = (m0 + m) * 16 + kq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[m][r] = v[m][r] * inv * a.g2[co + r];
+      }
+    }
+    if (k_part && valid) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cmax[m][r] = fmaxf(cmax[m][r], v[m][r]);
+    }
+    if (valid) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int co = (m0 + m) * 16 + kq * 4;
+        const size_t o = ((size_t)b * HW + p) * a.Cout + co;
+        if constexpr (EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[m][r] += op2[m][j][r];
+        } else if constexpr (EPI == LD_EPI_GN_TAIL) {
+          float rv[4] = {op2[m][j][0], op2[m][j][1], op2[m][j][2], op2[m][j][3]};
+          affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
+          if (a.res) {                                   // step-invariant half of res_conv (conv_fusion)
+            float r2[4];
+            load4<T>(reinterpret_cast<const T*>(a.res) + o, r2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[m][r] += r2[r];
+          }
+        }
+        store4<T>(out + o, v[m]);
+      }
+    }
+  }
+  if (k_part) {
+    // softmax_n(k) needs max_n k per (batch, channel) (ddpm.py:243): row-reduce over the 16 pixel
+    // lanes (DPP), combine the 4 waves through LDS, then ONE 64-lane integer
+    // atomicMax per workgroup into its stripe of the [B, stripes, hidden] buffer.
+    float* s_cm = reinterpret_cast<float*>(s_x);          // the staging tile is dead after the K loop
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float cm = wave16_max(cmax[m][r]);
+        if (px == 0) s_cm[wv * 16 * MT + m * 16 + kq * 4 + r] = cm;
+      }
+    __syncthreads();
+    if (tid < 16 * MT) {
+      const float cm = fmaxf(fmaxf(s_cm[tid], s_cm[16 * MT + tid]), fmaxf(s_cm[32 * MT + tid], s_cm[48 * MT + tid]));
+      const int stripe = blockIdx.x % LD_STAT_STRIPES;    // spread same-address atomics (see LD_STAT_STRIPES)
+      if (cm > -INFINITY)
+        atomicMax(a.kmax + ((size_t)b * LD_STAT_STRIPES + stripe) * a.hidden + m0 * 16 + tid - a.hidden, enc_max(cm));
+    }
+  }
+}
+
+constexpr size_t FULLK_MAX_LDS = 150 * 1024;
+
+template <typename T, int MT, int NW, int EPI>
+int launch_epi(const Conv1Dev& a, hipStream_t st) {
+  constexpr int NPT = 64 * NW;
+  const size_t tail = NPT * sizeof(float) + (EPI == LD_EPI_GN_TAIL ? 2 * a.Cout * sizeof(float) + 64 * sizeof(double) : 0);
+  const size_t chunk = 4 * NPT * 16 + MT * 1024;
+  const int HW = a.H * a.W;
+  dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
+  if (a.fullk) {
+    const int ck = DT<T>::CK;
+    const int nc0 = a.s[0].C / ck;
+    const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / ck : 0);
+    const size_t lds = nch * chunk + tail;
+    if (lds <= FULLK_MAX_LDS) {
+      static size_t allowed = 0;
+      if (lds > allowed) {
+        LD_HIP(ld_allow_lds((conv1x1_kernel<T, MT, NW, EPI, true>), lds));
+        allowed = lds;
+      }
+      LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI, true>), grid, dim3(256), lds, st, a);
+      LD_LAUNCH_CHECK("conv1x1(full K)");
+      return LD_OK;
+    }
+  }
+  LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI>), grid, dim3(256), chunk + tail, st, a);
+  LD_LAUNCH_CHECK("conv1x1");
+  return LD_OK;
+}
+
+template <typename T, int MT, int NW>
+int launch(const Conv1Dev& a, hipStream_t st) {
+  switch (a.epi) {
+    case LD_EPI_PLAIN: return launch_epi<T, MT, NW, LD_EPI_PLAIN>(a, st);
+    case LD_EPI_QKV_LINEAR: return launch_epi<T, MT, NW, LD_EPI_QKV_LINEAR>(a, st);
+    case LD_EPI_QKV_FULL: return launch_epi<T, MT, NW, LD_EPI_QKV_FULL>(a, st);
+    case LD_EPI_RMS_RES: return launch_epi<T, MT, NW, LD_EPI_RMS_RES>(a, st);
+    case LD_EPI_RES: return launch_epi<T, MT, NW, LD_EPI_RES>(a, st);
+    default: return launch_epi<T, MT, NW, LD_EPI_GN_TAIL>(a, st);
+  }
+}
+
+template <typename T>
+int dispatch(const Conv1Dev& a0, hipStream_t st) {
+  Conv1Dev a = a0;
+  const int HW = a.H * a.W;
+  {
+    // full-K staging pays where the launch is a chain of dependent round trips over a small map: at most
+    // LD_C1_FULLK_MAX_PX pixels in the whole batch (default 64^2 x 8) and at least 4 K-chunks
+    static const long fullk_max_px = getenv("LD_C1_FULLK_MAX_PX") ? atol(getenv("LD_C1_FULLK_MAX_PX")) : 32768;
+    const int ck = DT<T>::CK;
+    const int nc0 = a.s[0].C / ck;
+    const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / ck : 0);
+    a.fullk = (long)HW * a.B <= fullk_max_px && nch >= 4 && nch <= 2 * FG;
+    if (a.fullk && a.epi != LD_EPI_RMS_RES) {
+      // 128-pixel tiles (8 KiB + MT KiB of LDS per chunk) while the whole K extent fits, else 64-pixel tiles
+      bool mt4 = (a.Cout % 64) == 0;
+      static const long small_min = getenv("LD_C1_SMALL_MIN") ? atol(getenv("LD_C1_SMALL_MIN")) : 512;
+      if (mt4 && (long)((HW + 127) / 128) * (a.Cout / 64) * a.B < small_min) mt4 = false;
+      const size_t per_chunk = 8192 + (mt4 ? 4096 : 2048);
+      const bool nw2 = nch * per_chunk + 4096 <= FULLK_MAX_LDS;
+      if (mt4) return nw2 ? launch<T, 4, 2>(a, st) : launch<T, 4, 1>(a, st);
+      return nw2 ? launch<T, 2, 2>(a, st) : launch<T, 2, 1>(a, st);
+    }
+  }
+  if (a.epi == LD_EPI_RMS_RES) {
+    switch (a.Cout) {
+      case 32: return launch<T, 2, 2>(a, st);
+      case 64: return launch<T, 4, 2>(a, st);
+      case 128: return launch<T, 8, 2>(a, st);
+      default: return ld_fail(LD_EINVAL, "ld_conv1x1: RMS_RES epilogue supports Cout 32/64/128 (got %d)", a.Cout);
+    }
+  }
+  bool mt4 = (a.Cout % 64) == 0;
+  // small maps: prefer 32-channel tiles while the 64-channel grid (128-pixel tiles) would leave CUs with at most
+  // one workgroup -- the K loop is a chain of synchronous chunk loads and a second resident workgroup hides it
+  static const long small_min = getenv("LD_C1_SMALL_MIN") ? atol(getenv("LD_C1_SMALL_MIN")) : 512;
+  if (mt4 && (long)((HW + 127) / 128) * (a.Cout / 64) * a.B < small_min) mt4 = false;
+  const long blocks4 = (long)((HW + 255) / 256) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
+  const bool big = blocks4 >= 512;
+  if (mt4) return big ? launch<T, 4, 4>(a, st) : launch<T, 4, 2>(a, st);
+  return big ? launch<T, 2, 4>(a, st) : launch<T, 2, 2>(a, st);
+}
+
+}  // namespace
+
+extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
+  LD_REQUIRE(p != nullptr, "ld_conv1x1: null args");
+  LD_REQUIRE(p->nsrc == 1 || p->nsrc == 2, "ld_conv1x1: nsrc must be 1 or 2");
+  LD_REQUIRE(ld_dtype_ok(p->dtype), "ld_conv1x1: bad dtype %d", p->dtype);
+  LD_REQUIRE(p->Cout > 0 && p->Cout % 32 == 0, "ld_conv1x1: Cout %d must be a multiple of 32", p->Cout);
+  LD_REQUIRE(p->B > 0 && p->H > 0 && p->W > 0 && p->weight && p->out, "ld_conv1x1: bad shape/null");
+  LD_REQUIRE(!(p->unshuffle && p->nsrc != 1), "ld_conv1x1: unshuffle takes one source");
+  LD_REQUIRE(p->epilogue >= LD_EPI_PLAIN && p->epilogue <= LD_EPI_GN_TAIL, "ld_conv1x1: bad epilogue");
+  if (p->epilogue == LD_EPI_QKV_LINEAR || p->epilogue == LD_EPI_QKV_FULL)
+    LD_REQUIRE(p->hidden > 0 && p->hidden % 64 == 0 && p->Cout == 3 * p->hidden,
+               "ld_conv1x1: QKV epilogue needs Cout == 3*hidden, hidden %% 64 == 0");
+  if (p->epilogue == LD_EPI_RMS_RES) LD_REQUIRE(p->g2 && p->residual, "ld_conv1x1: RMS_RES needs g2/residual");
+  if (p->epilogue == LD_EPI_RES) LD_REQUIRE(p->residual, "ld_conv1x1: RES needs residual");
+  Conv1Dev a;
+  for (int s = 0; s < p->nsrc; ++s) {
+    LD_REQUIRE(p->src[s].data && p->src[s].C > 0 && p->src[s].C % 32 == 0,
+               "ld_conv1x1: src[%d] null or C %% 32 != 0", s);
+    LD_REQUIRE(p->src[s].gn_stats == nullptr && !p->src[s].upsample,
+               "ld_conv1x1: GroupNorm/upsample prologues are 3x3-only");
+    a.s[s] = to_dev(p->src[s]);
+  }
+  if (p->nsrc == 1) a.s[1] = a.s[0];
+  a.nsrc = p->nsrc; a.unshuffle = p->unshuffle; a.rms_in = p->rms_in;
+  a.w = p->weight; a.w_bstride = p->weight_bstride; a.bias = p->bias;
+  a.epi = p->epilogue;
+  a.hidden = (p->epilogue == LD_EPI_QKV_LINEAR || p->epilogue == LD_EPI_QKV_FULL) ? p->hidden : 0;
+  a.q_scale = p->q_scale; a.g2 = p->g2; a.res = p->residual; a.out = p->out;
+  a.kmax = (p->epilogue == LD_EPI_QKV_LINEAR) ? p->kmax_out : nullptr;
+  if (p->epilogue == LD_EPI_GN_TAIL) {
+    const ld_src& t = p->gn_tail;
+    LD_REQUIRE(t.data && t.gn_stats && t.gn_gamma && t.gn_beta && t.gn_groups > 0 && t.C == p->Cout &&
+               t.C % t.gn_groups == 0 && (t.pix_stride == 0 || t.pix_stride == t.C) && !t.film,
+               "ld_conv1x1: GN_TAIL operand incomplete");
+    a.tail = to_dev(t);
+  } else {
+    a.tail = a.s[0];
+  }
+  a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout;
+  a.fullk = 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  return LD_DISPATCH(p->dtype, dispatch<T>(a, st));
+}
