@@ -1,7 +1,11 @@
 """Summarise rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE collected in SEPARATE runs) into per-kernel
 HBM traffic per launch, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section):
-FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> doubled; WRITE_SIZE is exact;
-both are reported in KiB by rocprofv3.  Usage: pmc_summarize.py <fetch_dir> <write_dir> <out.json>"""
+FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream (16 B per lane) -> doubled; WRITE_SIZE is exact;
+both are reported in KiB by rocprofv3.  Every global load of these kernels is a 16-byte-per-lane load of 64-byte
+(pixel) or 1-KiB (weight block) contiguous runs; the doubling is CALIBRATED inside the same passes by the kernels
+whose traffic is known exactly (gn_apply: reads each operand once and writes the result once; linattn_kvctx: reads x
+once) -- the summary prints their counter / algorithmic ratio, which must come out at 1.0 for the correction to hold.
+Usage: pmc_summarize.py <fetch_dir> <write_dir> <out.json> [bench.json with roofline.families]"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -20,12 +24,13 @@ def load(d, counter):
 
 def family(name):
     import re
-    bf = "DF16b" in name or "bf16" in name or "_Accum" in name     # rocprofv3's demangler prints __bf16 as "bool _Accum"
-    if "conv3x3_c32_kernel" in name:                           # persistent variant of the <.,2,4> family
-        return f"conv3x3<{'bf16' if bf else 'f32'},2,4>"
-    m = re.search(r"conv3x3_kernelI(?:f|DF16b)Li(\d)ELi(\d)E", name) or re.search(r"conv3x3_kernel<[^,]+, (\d), (\d)", name)
+    # storage type from the (mangled or demangled) name; rocprofv3's demangler prints __bf16 as "bool _Accum"
+    dt = "bf16" if ("DF16b" in name or "bf16" in name or "_Accum" in name) else ("f16" if ("DF16_" in name or "_Float16" in name) else "f32")
+    if "conv3x3_c32_kernel" in name:                           # persistent LDS-DMA variant (bench.py names it the same)
+        return f"conv3x3_c32<{dt}>"
+    m = re.search(r"conv3x3_kernelI(?:f|DF16b|DF16_)Li(\d)ELi(\d)E", name) or re.search(r"conv3x3_kernel<[^,]+, (\d), (\d)", name)
     if m:
-        return f"conv3x3<{'bf16' if bf else 'f32'},{m.group(1)},{m.group(2)}>"
+        return f"conv3x3<{dt},{m.group(1)},{m.group(2)}>"
     for key, fam in [("conv1x1", "conv1x1"), ("gn_apply", "gn_apply"), ("kvctx", "linattn_kvctx"), ("linout", "linattn_out"),
                      ("attention", "attention"), ("conv_image", "conv_image7x7"), ("conv_stem", "conv_image7x7"),
                      ("ctxfold", "linattn_ctxfold")]:
@@ -52,6 +57,17 @@ for f, d in fams.items():
     wr = d["write_kib"] * 1024 / n
     out[f] = {"hbm_bytes_per_launch": rd + wr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "launches": n,
               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 correction)"}
+algo = {}
+if len(sys.argv) > 4:
+    try:
+        algo = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])["roofline"]["families"]
+    except Exception as e:                                       # the summary is still useful without the comparison
+        print(f"(no algorithmic bytes: {e})")
+for f, d in out.items():
+    if f in algo:
+        d["algorithmic_bytes_per_launch"] = algo[f]["bytes_per_launch"]
+        d["traffic_over_algorithmic"] = round(d["hbm_bytes_per_launch"] / max(1, algo[f]["bytes_per_launch"]), 3)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for f, d in sorted(out.items()):
-    print(f"{f:24s} launches {d['launches']:6d}  read {d['read_bytes_per_launch']/1e6:9.2f} MB  write {d['write_bytes_per_launch']/1e6:9.2f} MB")
+    extra = f"  algorithmic {d['algorithmic_bytes_per_launch']/1e6:9.2f} MB  ratio {d['traffic_over_algorithmic']:.2f}" if "traffic_over_algorithmic" in d else ""
+    print(f"{f:24s} launches {d['launches']:6d}  read {d['read_bytes_per_launch']/1e6:9.2f} MB  write {d['write_bytes_per_launch']/1e6:9.2f} MB{extra}")
