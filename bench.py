@@ -65,7 +65,8 @@ def launch_ranks(a):
     import socket
     import subprocess
     n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
-    if n_dev < a.gpus:
+    shared = os.environ.get("LD_BENCH_SHARE_GPU") == "1"     # functional test of the N > 1 path on a 1-GPU box (gloo)
+    if n_dev < a.gpus and not shared:
         print(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
         return 2
     s = socket.socket()
@@ -74,7 +75,7 @@ def launch_ranks(a):
     s.close()
     procs = []
     for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(1, n_dev) if shared else r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -270,12 +271,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("LD_BENCH_SHARE_GPU") == "1":
+        local %= max(1, torch.cuda.device_count())
     if world != a.gpus:
         print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # RCCL ("nccl" IS RCCL on ROCm).  LD_BENCH_SHARE_GPU=1 (test only: several ranks on one GPU, which RCCL refuses)
+        # switches to gloo so that the N > 1 control flow can be exercised on a 1-GPU box; the JSON says so.
+        if os.environ.get("LD_BENCH_SHARE_GPU") == "1":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -354,7 +362,9 @@ def main():
         "config": {"workload": f"cfg3: {P} local patches (vertical band masks) of one 3x{H}x{H} image per GPU, "
                                f"4-stage dim-32 conditional UNet (12.1M params), DDPM T={T_STEPS}, pred_x0, sigmoid schedule",
                    "patches_per_gpu": P, "image": [3, H, H], "timesteps": T_STEPS,
-                   "parallelism": f"patch-sharded x{world}, one all-gather per sample",
+                   "parallelism": f"patch-sharded x{world}, one all-gather per sample"
+                                  + (" [LD_BENCH_SHARE_GPU: ranks share one GPU over gloo -- functional test, not a measurement]"
+                                     if os.environ.get("LD_BENCH_SHARE_GPU") == "1" else ""),
                    "hip_graph": bool(gd.use_graph),
                    "concurrent_sub_batches": (gd.sub_batches if gd.timed_plan(jp) is not jp else 1)},
     }
