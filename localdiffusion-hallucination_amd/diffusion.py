@@ -773,6 +773,10 @@ class GaussianDiffusion(nn.Module):
         lo, hi = float(min_max_val[0]), float(min_max_val[1])
         T, S, eta = self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
         branch, fuse, mask_x = self._flags(mask)
+        if branch and mask is not None and mask.shape[1] > 1:
+            raise NotImplementedError("K-mask branching (mask [B,K,H,W], K > 1) is implemented for the DDPM loop; the "
+                                      "reference's DDIM fusion (ddpm.py:1025-1041) selects by exact zeros of the OOD "
+                                      "prediction, which has no mask-based K > 2 form")
         obj = cabi.OBJ[self.objective]
         times, pairs = schedule.ddim_time_pairs(T, S)
         t_fuse = times[-int(self.config["start_timestep"]) - 2]                 # ddpm.py:987

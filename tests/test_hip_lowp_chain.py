@@ -71,3 +71,27 @@ def test_g7_ddim_chain_16bit_vs_reference_golden(golden, dtype):
     mx, mean = err(run(make(dict(mode="mri"), kw, 64, 50, 10, dtype=dtype), cond, mask, 1), g["nofuse_final"])
     print(f"G7 DDIM S=10 of 50, branches kept apart, {dtype}: max-abs {mx:.3e} mean-abs {mean:.3e}")
     assert mean <= BOUND_G7_MEAN[dtype], (dtype, mx, mean)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_cfg1_and_branch_fusion_16bit_vs_reference_golden(golden, dtype):
+    """BASELINE.json configs[0] (MNIST 28x28, T=100, 4 patches, branch + fusion at t <= 2; G4) and the T=50 branch +
+    fusion runs of G6 (mri: OOD prediction kept; mnist: replaced by the conditioning) in 16-bit storage against the
+    reference goldens.  Printed per case; asserted on the mean (measured: see DESIGN.md section 2)."""
+    from test_hip_sampler import MNIST
+    bound = {"bf16": 6e-2, "fp16": 1.5e-2}[dtype]
+    g = golden("g4_cfg1_mnist")
+    gd = make(MNIST, dict(data="mnist", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True, ood_AD=True),
+              28, 100, dtype=dtype)
+    mx, mean = err(run(gd, torch.from_numpy(g["cond"]), torch.from_numpy(g["mask"]), 4), g["final"])
+    print(f"G4 cfg1 (MNIST, T=100, 4 patches, branch + fusion) {dtype}: max-abs {mx:.3e} mean-abs {mean:.3e}")
+    assert mean <= bound, (dtype, mx, mean)
+    g6 = golden("g6_branch_fusion")
+    for tag, kw, H, data in [("mri32", dict(mode="mri"), 32, "mri"), ("mnist28", MNIST, 28, "mnist")]:
+        cond = torch.from_numpy(rng.uniform((2, 1, H, H), 6, 1, 0.0, 2.0))
+        mask = torch.zeros(2, 1, H, H)
+        mask[:, :, :, :H // 4] = 1.0
+        gd = make(kw, dict(data=data, branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True), H, 50, dtype=dtype)
+        mx, mean = err(run(gd, cond, mask, 2), g6[tag + "_final"])
+        print(f"G6 {tag} (T=50, branch + fusion) {dtype}: max-abs {mx:.3e} mean-abs {mean:.3e}")
+        assert mean <= bound, (dtype, tag, mx, mean)

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--n", type=int, default=4)
     ap.add_argument("--timesteps", type=int, default=100)
     ap.add_argument("--ddim", type=int, default=0, help="sampling_timesteps (0 = ancestral DDPM)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"])
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     imgs, labs = evalio.select_digits(evalio.read_idx(a.images), evalio.read_idx(a.labels), a.digit, a.n)
