@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--patches", type=int, default=8, help="local patches per GPU (K masks of one image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-dtype", action="store_true", help="skip the short extra run in the other 16-bit storage type")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the reverse step from a captured HIP graph (default: eager launches)")
     return ap.parse_args()
 
@@ -307,12 +308,6 @@ def main():
     cond_img = torch.from_numpy(rng.uniform((1, 3, H, H), 100 + rank, 1, 0.0, 2.0))
     conds = patch_conditions(cond_img, masks).to(dev)
     lib, st = cabi.lib(), torch.cuda.current_stream().cuda_stream
-    jp = net.plan(P, H, H, table_T=T_STEPS)
-    jp.cond_in.copy_(conds)
-    x_T = torch.empty(P, 3, H, H, device=dev)
-    gd._noise(x_T, 0)
-    jp.x_in.copy_(x_T)
-    z = torch.empty_like(x_T)
     lo, hi = 0.0, 2.0
 
     def sync_all():
@@ -321,37 +316,48 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warm-up (untimed): encoder + W steps
-    jp.run_cond(st)
-    draw = gd.run_joint_steps(jp, T_STEPS - 1, a.warmup, lo, hi, z, 1)
-    sync_all()
-    t0 = time.perf_counter()
-    jp.run_cond(st)                                             # once per sample, inside the timed region
-    t_start = T_STEPS - 1 - a.warmup
-    done = 0
-    while done < a.steps:                                       # wrap to a new sample after T steps
-        chunk = min(a.steps - done, t_start + 1)
-        draw = gd.run_joint_steps(jp, t_start, chunk, lo, hi, z, draw)
-        done += chunk
-        t_start -= chunk
-        if t_start < 0:
-            t_start = T_STEPS - 1
-    # per-sample exchange: all-gather the local patches and recompose by the masks
-    xl = jp.x_in
-    if world > 1:
-        gathered = torch.empty(world * P, 3, H, H, device=dev)
-        dist.all_gather_into_tensor(gathered, xl.contiguous())
-        xl = gathered[rank * P:(rank + 1) * P]
-    img = torch.empty(1, 3, H, H, device=dev)
-    mk = masks.reshape(P, H * H).to(dev)
-    cabi.check(lib.ld_recompose(xl.contiguous().data_ptr(), mk.data_ptr(), img.data_ptr(), 1, P, 3, H * H, st), "recompose")
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(img).all(), "non-finite output"
+    def measure(steps, warmup):
+        """W untimed + K timed reverse steps in the model's current storage dtype -> (seconds, plan, z)."""
+        jp = net.plan(P, H, H, table_T=T_STEPS)
+        jp.cond_in.copy_(conds)
+        x_T = torch.empty(P, 3, H, H, device=dev)
+        gd._noise(x_T, 0)
+        jp.x_in.copy_(x_T)
+        z = torch.empty_like(x_T)
+        # warm-up (untimed): encoder + W steps
+        jp.run_cond(st)
+        draw = gd.run_joint_steps(jp, T_STEPS - 1, warmup, lo, hi, z, 1)
+        sync_all()
+        t0 = time.perf_counter()
+        jp.run_cond(st)                                             # once per sample, inside the timed region
+        t_start = T_STEPS - 1 - warmup
+        done = 0
+        while done < steps:                                         # wrap to a new sample after T steps
+            chunk = min(steps - done, t_start + 1)
+            draw = gd.run_joint_steps(jp, t_start, chunk, lo, hi, z, draw)
+            done += chunk
+            t_start -= chunk
+            if t_start < 0:
+                t_start = T_STEPS - 1
+        # per-sample exchange: all-gather the local patches and recompose by the masks
+        xl = jp.x_in
+        if world > 1:
+            gathered = torch.empty(world * P, 3, H, H, device=dev)
+            dist.all_gather_into_tensor(gathered, xl.contiguous())
+            xl = gathered[rank * P:(rank + 1) * P]
+        img = torch.empty(1, 3, H, H, device=dev)
+        mk = masks.reshape(P, H * H).to(dev)
+        cabi.check(lib.ld_recompose(xl.contiguous().data_ptr(), mk.data_ptr(), img.data_ptr(), 1, P, 3, H * H, st), "recompose")
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        assert torch.isfinite(img).all(), "non-finite output"
+        return elapsed, jp, z
+
+    elapsed, jp, z = measure(a.steps, a.warmup)
 
     value = world * P * a.steps / (T_STEPS * elapsed)
     out = {
@@ -371,6 +377,16 @@ def main():
 
     if rank == 0 and not a.no_roofline:
         out["roofline"] = roofline_leg(gd, jp, tp_value=value / world, dtype=a.dtype, H=H, lo=lo, hi=hi, z=z)
+    if world == 1 and a.dtype in ("bf16", "fp16") and not a.no_other_dtype:
+        # the same workload in the other 16-bit storage type (BASELINE configs[2] says bf16, the north star fp16): a
+        # shorter timed run after the contract's measurement, reported beside it
+        other = "fp16" if a.dtype == "bf16" else "bf16"
+        net.set_compute_dtype(other)
+        k2 = min(a.steps, 200)
+        e2, _, _ = measure(k2, min(a.warmup, 10))
+        out["other_dtype"] = {"dtype": other, "value": P * k2 / (T_STEPS * e2), "unit": "patches/s", "steps": k2,
+                              "ms_per_step": 1e3 * e2 / k2}
+        net.set_compute_dtype(a.dtype)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:        # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(net.cfg, sd, H)
     if rank == 0:

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_m
-LD_SUB_BATCHES=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d /tmp/prof_m -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pm.log 2>&1 < /dev/null
+LD_SUB_BATCHES=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d /tmp/prof_m -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_pm.log 2>&1 < /dev/null
 python3 - <<PY > $OUT/${TAG}_pmc_mfma.txt
 import csv, glob, collections, re, os
 def short(k):
