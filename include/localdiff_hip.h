@@ -303,6 +303,10 @@ int ld_randn_at(float* out, int64_t n, int64_t first, uint64_t seed, int64_t str
                 const int32_t* t_ptr, void* stream);
 /* *t_ptr += delta  (graph-replayable step counter) */
 int ld_step_add(int32_t* t_ptr, int delta, void* stream);
+/* head of one denoiser evaluation in ONE launch: zero up to two arenas (GroupNorm statistics, k-max codes; 16-byte
+ * aligned and sized; either may be NULL / 0) and, if t_ptr is given, *t_ptr += delta BEFORE any kernel of the
+ * evaluation reads it.  Replaces two hipMemsetAsync nodes + ld_step_add at the head / tail of every replayed step. */
+int ld_step_begin(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta, void* stream);
 
 /* p_sample, single branch (ddpm.py:631-666, 739-761, 817-838, 857-858):
  *   x0 = clamp(to_x0(model_out)), x_prev = c1*x0 + c2*x_t + (t>0 ? sigma*z : 0).

@@ -39,6 +39,14 @@ __global__ void randn_kernel(float* out, long n, long first, unsigned long long 
   }
 }
 __global__ void step_add_kernel(int* t, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *t += delta; }
+// start of a denoiser evaluation in ONE launch: zero the statistics arena(s) and advance the device step counter
+// (as two hipMemsetAsync + ld_step_add these were three dependent ~5-8 us nodes at the head of every replayed step)
+__global__ void step_begin_kernel(uint4* a, long na, uint4* b, long nb, int* t, int delta) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  GRID_STRIDE(i, na) a[i] = z;
+  GRID_STRIDE(i, nb) b[i] = z;
+  if (t && delta != 0 && threadIdx.x == 0 && blockIdx.x == 0) *t += delta;
+}
 
 // ---------------------------------------------------------------- DDPM / DDIM steps
 __global__ void ddpm_step_kernel(const float* x, const float* mo, const float* z, float* xp, float* x0o,
@@ -275,6 +283,17 @@ extern "C" int ld_step_add(int32_t* t_ptr, int delta, void* stream) {
   LD_REQUIRE(t_ptr, "ld_step_add: null");
   LD_LAUNCH(step_add_kernel, dim3(1), dim3(64), 0, ST(stream), t_ptr, delta);
   LD_LAUNCH_CHECK("step_add");
+  return LD_OK;
+}
+extern "C" int ld_step_begin(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
+                             void* stream) {
+  LD_REQUIRE((zero_a || bytes_a == 0) && (zero_b || bytes_b == 0), "ld_step_begin: null arena");
+  LD_REQUIRE(bytes_a % 16 == 0 && bytes_b % 16 == 0 && ((size_t)zero_a % 16) == 0 && ((size_t)zero_b % 16) == 0,
+             "ld_step_begin: arenas must be 16-byte aligned and sized");
+  const long na = (long)(bytes_a / 16), nb = (long)(bytes_b / 16);
+  LD_LAUNCH(step_begin_kernel, dim3(nblocks(na + nb + 1)), dim3(BS), 0, ST(stream), (uint4*)zero_a, na, (uint4*)zero_b, nb,
+            t_ptr, delta);
+  LD_LAUNCH_CHECK("step_begin");
   return LD_OK;
 }
 extern "C" int ld_ddpm_step(const float* x_t, const float* model_out, const float* noise, float* x_prev,

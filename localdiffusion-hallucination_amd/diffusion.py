@@ -67,14 +67,15 @@ class _SubBatches:
         lib = cabi.lib()
         xa, wf, bf = sp.final
         B_, C_, H_, W_ = sp.model_out.shape
-        sp.run_main(st, skip_final=True)
+        # the step counter moves at the HEAD of the step (inside ld_step_begin): callers park it one above the step
+        # they want to run next
+        sp.run_main(st, skip_final=True, step_delta=-1)
         cabi.check(lib.ld_final_step_at(xa.data_ptr(), wf.data_ptr(), bf.data_ptr(), sp.model_out.data_ptr(),
                                         sp.x_in.data_ptr(), None, gd._sched_table().data_ptr(), sp.t_dev.data_ptr(),
                                         lo, hi, cabi.OBJ[gd.objective], gd.noise_seed, base, -1,
                                         gd.noise_offset + (0 if self.shared_noise else i * sp.x_in.numel()),
                                         cabi.ptr(self.masks.get(i)),
                                         B_, H_, W_, wf.shape[1], C_, sp.dt, st), "final_step")
-        cabi.check(lib.ld_step_add(sp.t_dev.data_ptr(), -1, st), "step_add")
 
     def _ensure_graph(self, i, gs, lo, hi, base):
         """Capture sub-batch i's step for this noise base if not done yet (call with ``gs`` current).  Returns the
@@ -126,7 +127,7 @@ class _SubBatches:
                 if recond:                          # the parent's conditioning changed: encode this slice of it
                     sp.cond_in.copy_(jp.cond_in[i * b:(i + 1) * b])
                     sp.run_cond(st)
-                sp.set_step(t_start)
+                sp.set_step(t_start + 1)
                 todo[i] -= self._ensure_graph(i, gs, lo, hi, base)
                 ex[i] = self.graphs[(i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)]
         # interleave the launches so that neither hardware queue runs ahead of the other
@@ -153,7 +154,7 @@ class _SubBatches:
             gs.wait_stream(cur)
             with torch.cuda.stream(gs):
                 sp.x_in.copy_(jp.x_in[i * b:(i + 1) * b])
-                sp.set_step(t_start)
+                sp.set_step(t_start + (1 if i > 0 else 0))       # replayed steps move the counter at their head
         for i in range(1, self.S):
             with torch.cuda.stream(self.streams[i]):
                 self._ensure_graph(i, self.streams[i], lo, hi, base)

@@ -315,6 +315,10 @@ class _Plan:
             self.fusion_const = (p1, p2, torch.zeros(c, dtype=torch.float32, device=self.dev))
         self._slot_cursor = self.cond_slots
         self._build_main()
+        self._slots_used = self._slot_cursor       # statistics slots [cond_slots, _slots_used) are zeroed per evaluation
+        s_, km_ = self.stats[self.cond_slots:self._slots_used], self.kmax_arena[:self._kmax_cursor]
+        self._begin_args = (s_.data_ptr(), s_.numel() * 8, km_.data_ptr() if km_.numel() else None, km_.numel() * 4)
+        self._t_dev_ptr = self.t_dev.data_ptr()
         if table_T:
             st = torch.cuda.current_stream().cuda_stream
             for op in self.ops_time:
@@ -711,11 +715,13 @@ class _Plan:
         for op in self.ops_cond:
             op(st)
 
-    def run_main(self, st, skip_final=False):
-        """One denoiser evaluation.  ``skip_final``: stop before final_conv (the caller runs ld_final_step)."""
-        s = self.stats[self.cond_slots:]
-        cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
-        cabi.check(self.lib.ld_memset_zero(self.kmax_arena.data_ptr(), self.kmax_arena.numel() * 4, st), "memset")
+    def run_main(self, st, skip_final=False, step_delta=0):
+        """One denoiser evaluation.  ``skip_final``: stop before final_conv (the caller runs ld_final_step).
+        ``step_delta``: added to the device step counter by the evaluation's first launch (ld_step_begin zeroes the
+        statistics slots this plan uses, the k-max arena if the unfused linear attention is on the plan, and moves
+        the counter -- one launch where two memsets and ld_step_add were three)."""
+        cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr if step_delta else None, int(step_delta), st),
+                   "step_begin")
         ops = self.ops_main[:-1] if skip_final else self.ops_main
         for op in ops:
             op(st)
@@ -725,9 +731,7 @@ class _Plan:
         its own start/stop events, so the times are kernel execution times as rocprofv3 reports them); adds each
         op's kernel time to ``acc[index] = [ms_total, launches]`` (bench.py's per-kernel roofline leg)."""
         lib = self.lib
-        s = self.stats[self.cond_slots:]
-        cabi.check(lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
-        cabi.check(lib.ld_memset_zero(self.kmax_arena.data_ptr(), self.kmax_arena.numel() * 4, st), "memset")
+        cabi.check(lib.ld_step_begin(*self._begin_args, None, 0, st), "step_begin")
         cabi.check(lib.ld_timing_begin(8 * len(self.ops_main)), "timing_begin")
         marks = [0]
         try:
