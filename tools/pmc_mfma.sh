@@ -15,7 +15,7 @@ def short(k):
     k = re.sub(r"\(anonymous namespace\)::", "", k); return re.sub(r"_ZN12_GLOBAL__N_1\d+", "", k)[:72]
 # un-profiled durations of the same kernels: the kernel-trace summary of the same command (profile_round.sh)
 real = {}
-st = "$R/profiles/${TAG}_s1_kernel_stats.csv"
+st = "$OUT/${TAG}_s1_kernel_stats.csv" if os.path.exists("$OUT/${TAG}_s1_kernel_stats.csv") else "$R/profiles/${TAG}_s1_kernel_stats.csv"
 if os.path.exists(st):
     for r in csv.DictReader(open(st)): real[short(r["Name"])] = float(r["AverageNs"])
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
