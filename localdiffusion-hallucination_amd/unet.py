@@ -516,7 +516,10 @@ class _Plan:
         n, hid, B, heads, dt, es = h * w, cfg.hidden, self.B, cfg.attn_heads, self.dt, self.esize
         # one workgroup per (batch, chunk) with a wave per head: 512-pixel chunks give >= 1024 workgroups at 256^2
         # pixels per kvctx workgroup (measured, cfg3: 512 best up to 128^2; 1024 halves the partials at 256^2)
-        chunk_px = int(os.environ.get("LD_LINATTN_CHUNK_PX", "1024" if n >= 65536 else "512"))
+        # (round 2, per launch in the two-sub-batch regime: 64^2 maps with 512-pixel chunks were 32 workgroups walking
+        # 16 dependent 32-pixel groups each -- 128-pixel chunks there, 256 at 128^2: kvctx 21.7 -> ~15 us per launch,
+        # the reduce + fold launch pays 2 us of it back for the extra partials; tools/exp_kvctx.sh)
+        chunk_px = int(os.environ.get("LD_LINATTN_CHUNK_PX", "1024" if n >= 65536 else ("256" if n >= 16384 else "128")))
         nchunks = max(1, min(128, n // chunk_px)) if heads == 4 else max(1, min(32, n // 256))
         ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, heads, 32, nchunks)), dtype=torch.float32, device=self.dev)
         wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)
