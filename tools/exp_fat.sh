@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: needs tools/experiments/conv3x3_fat_waves.hip copied over csrc/conv3x3.hip (the variant is shelved, DESIGN finding 32)
 # GPU box: fat-wave conv3x3 variants (LD_CONV_FAT = 0 off / 1 the 32-channel-tile launches / 2 also the 64-channel-tile ones)
 cd $GRAFT_REPO_ROOT
 run() {

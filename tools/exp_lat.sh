@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the variant this sweeps (LD_CONV_LAT_MAX_WGS) was removed after the measurement (DESIGN finding 33); kept as the record of the run
 # GPU box: latency variant of the generic conv3x3 (all fragment reads of a chunk fenced ahead of its MFMAs) vs the default
 cd $GRAFT_REPO_ROOT
 run() {
