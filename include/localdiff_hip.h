@@ -304,9 +304,12 @@ int ld_randn_at(float* out, int64_t n, int64_t first, uint64_t seed, int64_t str
 /* *t_ptr += delta  (graph-replayable step counter) */
 int ld_step_add(int32_t* t_ptr, int delta, void* stream);
 /* head of one denoiser evaluation in ONE launch: zero up to two arenas (GroupNorm statistics, k-max codes; 16-byte
- * aligned and sized; either may be NULL / 0) and, if t_ptr is given, *t_ptr += delta BEFORE any kernel of the
- * evaluation reads it.  Replaces two hipMemsetAsync nodes + ld_step_add at the head / tail of every replayed step. */
-int ld_step_begin(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta, void* stream);
+ * aligned and sized; either may be NULL / 0) and move the device step counter BEFORE any kernel of the evaluation
+ * reads it: *t_ptr += delta (ancestral loop), or -- when idx_ptr and t_table are given (strided DDIM loop,
+ * ddpm.py:984-986) -- *idx_ptr += 1; *t_ptr = t_table[*idx_ptr].  Replaces two hipMemsetAsync nodes + ld_step_add
+ * at the head / tail of every replayed step. */
+int ld_step_begin(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
+                  int32_t* idx_ptr, const int32_t* t_table, void* stream);
 
 /* p_sample, single branch (ddpm.py:631-666, 739-761, 817-838, 857-858):
  *   x0 = clamp(to_x0(model_out)), x_prev = c1*x0 + c2*x_t + (t>0 ? sigma*z : 0).
@@ -321,6 +324,11 @@ int ld_ddim_step(const float* x_t, const float* model_out, const float* noise, f
                  float sqrt_recip, float sqrt_recipm1, float sqrt_ab, float sqrt_1mab,
                  float sqrt_abar_next, float c, float sigma, float lo, float hi, int objective,
                  int last, int64_t n, void* stream);
+/* ld_ddim_step with the pair's scalars in a device table [pairs, 8] = {sqrt_recip, sqrt_recipm1, sqrt_ab, sqrt_1mab,
+ * sqrt_abar_next, c, sigma, last} and the row selected by *idx_ptr: the form a replayed HIP graph needs. */
+int ld_ddim_step_at(const float* x_t, const float* model_out, const float* noise, float* x_next,
+                    const float* pair_table, const int32_t* idx_ptr, float lo, float hi, int objective, int64_t n,
+                    void* stream);
 /* branch conditioning (ddpm.py:672-690): binary=(mask>=1); cond_out=cond*binary;
  * cond_in=cond*clip(1-binary, lo_clip, 1).  mask [B,1,H,W], cond [B,C,H,W]. */
 int ld_branch_conditions(const float* cond, const float* mask, float* cond_out, float* cond_in,

@@ -41,11 +41,19 @@ __global__ void randn_kernel(float* out, long n, long first, unsigned long long 
 __global__ void step_add_kernel(int* t, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *t += delta; }
 // start of a denoiser evaluation in ONE launch: zero the statistics arena(s) and advance the device step counter
 // (as two hipMemsetAsync + ld_step_add these were three dependent ~5-8 us nodes at the head of every replayed step)
-__global__ void step_begin_kernel(uint4* a, long na, uint4* b, long nb, int* t, int delta) {
+__global__ void step_begin_kernel(uint4* a, long na, uint4* b, long nb, int* t, int delta, int* idx, const int* t_table) {
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
   GRID_STRIDE(i, na) a[i] = z;
   GRID_STRIDE(i, nb) b[i] = z;
-  if (t && delta != 0 && threadIdx.x == 0 && blockIdx.x == 0) *t += delta;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (idx && t_table) {                 // strided (DDIM) sampling: advance the pair counter, look the timestep up
+      const int k = *idx + 1;
+      *idx = k;
+      if (t) *t = t_table[k];
+    } else if (t && delta != 0) {
+      *t += delta;
+    }
+  }
 }
 
 // ---------------------------------------------------------------- DDPM / DDIM steps
@@ -84,6 +92,26 @@ __global__ void ddim_step_kernel(const float* x, const float* mo, const float* z
     if (k.last) { xn[i] = x0; continue; }
     const float eps = (k.sr * xi - x0) / k.srm1;
     xn[i] = x0 * k.san + k.c * eps + k.sigma * (z ? z[i] : 0.f);
+  }
+}
+
+// the same update with the pair's scalars read from a device table row {sr, srm1, sab, s1mab, san, c, sigma, last}
+// selected by a device pair counter: one captured launch serves every DDIM step of a replayed graph
+__global__ void ddim_step_at_kernel(const float* x, const float* mo, const float* z, float* xn, const float* table,
+                                    const int* idx, float lo, float hi, int obj, long n) {
+  const float* r = table + 8 * (size_t)(*idx);
+  const float sr = r[0], srm1 = r[1], sab = r[2], s1mab = r[3], san = r[4], c = r[5], sigma = r[6];
+  const bool last = r[7] != 0.0f;
+  GRID_STRIDE(i, n) {
+    const float xi = x[i], m = mo[i];
+    float x0;
+    if (obj == LD_OBJ_X0) x0 = m;
+    else if (obj == LD_OBJ_NOISE) x0 = sr * xi - srm1 * m;
+    else x0 = sab * xi - s1mab * m;
+    x0 = clampf(x0, lo, hi);
+    if (last) { xn[i] = x0; continue; }
+    const float eps = (sr * xi - x0) / srm1;
+    xn[i] = x0 * san + c * eps + sigma * (z ? z[i] : 0.f);
   }
 }
 
@@ -286,13 +314,14 @@ extern "C" int ld_step_add(int32_t* t_ptr, int delta, void* stream) {
   return LD_OK;
 }
 extern "C" int ld_step_begin(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
-                             void* stream) {
+                             int32_t* idx_ptr, const int32_t* t_table, void* stream) {
+  LD_REQUIRE((idx_ptr == nullptr) == (t_table == nullptr), "ld_step_begin: idx_ptr and t_table go together");
   LD_REQUIRE((zero_a || bytes_a == 0) && (zero_b || bytes_b == 0), "ld_step_begin: null arena");
   LD_REQUIRE(bytes_a % 16 == 0 && bytes_b % 16 == 0 && ((size_t)zero_a % 16) == 0 && ((size_t)zero_b % 16) == 0,
              "ld_step_begin: arenas must be 16-byte aligned and sized");
   const long na = (long)(bytes_a / 16), nb = (long)(bytes_b / 16);
   LD_LAUNCH(step_begin_kernel, dim3(nblocks(na + nb + 1)), dim3(BS), 0, ST(stream), (uint4*)zero_a, na, (uint4*)zero_b, nb,
-            t_ptr, delta);
+            t_ptr, delta, idx_ptr, t_table);
   LD_LAUNCH_CHECK("step_begin");
   return LD_OK;
 }
@@ -322,6 +351,16 @@ extern "C" int ld_ddim_step(const float* x_t, const float* model_out, const floa
   DdimK k{sqrt_recip, sqrt_recipm1, sqrt_ab, sqrt_1mab, sqrt_abar_next, c, sigma, lo, hi, objective, last};
   LD_LAUNCH(ddim_step_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, model_out, noise, x_next, k, (long)n);
   LD_LAUNCH_CHECK("ddim_step");
+  return LD_OK;
+}
+extern "C" int ld_ddim_step_at(const float* x_t, const float* model_out, const float* noise, float* x_next,
+                               const float* pair_table, const int32_t* idx_ptr, float lo, float hi, int objective,
+                               int64_t n, void* stream) {
+  LD_REQUIRE(x_t && model_out && x_next && pair_table && idx_ptr && n > 0, "ld_ddim_step_at: null pointer");
+  LD_REQUIRE(objective >= 0 && objective <= 2, "ld_ddim_step_at: objective %d", objective);
+  LD_LAUNCH(ddim_step_at_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_t, model_out, noise, x_next, pair_table, idx_ptr,
+            lo, hi, objective, (long)n);
+  LD_LAUNCH_CHECK("ddim_step_at");
   return LD_OK;
 }
 extern "C" int ld_branch_conditions(const float* cond, const float* mask, float* cond_out, float* cond_in,

@@ -180,6 +180,82 @@ class _SubBatches:
         return draw + min(n_steps, t_start)
 
 
+class _DdimBranches:
+    """The DDIM steps before the fusion time with the OOD and the IND branch as two concurrent sub-batches, each a
+    replayed HIP graph of one step on its own stream (the DDIM counterpart of ``_SubBatches(shared_noise=True)``).
+    A step reads its timestep and its pair of schedule scalars through a device pair counter (``ld_step_begin`` with
+    a timestep table, ``ld_ddim_step_at``), so one captured graph serves every pair (ddpm.py:984-986, 1013-1068)."""
+
+    def __init__(self, gd, B, H, W, mask_x, times, pair_rows):
+        self.gd, self.B, self.mask_x = gd, B, mask_x
+        dev = gd.device
+        self.plans = [gd.model.plan(B, H, W, table_T=gd.num_timesteps_ori, instance=200 + i) for i in range(2)]
+        self.streams = gd._sub_streams(2)
+        self.idx = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.times = torch.tensor(times, dtype=torch.int32, device=dev)
+        self.table = torch.tensor(pair_rows, dtype=torch.float32, device=dev).contiguous()
+        self.mask = torch.ones(B, H * W, dtype=torch.float32, device=dev)
+        self.z = [torch.zeros(B, gd.channels, H, W, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.with_noise = any(r[6] != 0.0 for r in pair_rows)          # eta > 0: sigma * z is not identically zero
+        self.graphs = {}
+
+    def _step(self, i, st, lo, hi):
+        gd, sp, lib = self.gd, self.plans[i], cabi.lib()
+        B, C, H, W = sp.model_out.shape
+        n = sp.x_in.numel()
+        sp.run_main(st, idx_ptr=self.idx[i].data_ptr(), t_table=self.times.data_ptr())
+        if i == 0 and self.mask_x:
+            cabi.check(lib.ld_mask_out(sp.model_out.data_ptr(), self.mask.data_ptr(), lo, B, C, H * W, st), "mask_out")
+        zp = None
+        if self.with_noise:      # both branches use the SAME draw (ddpm.py:1020): draw index of pair k is 1 + k
+            cabi.check(lib.ld_randn_at(self.z[i].data_ptr(), n, gd.noise_offset, gd.noise_seed, 1, 1, self.idx[i].data_ptr(), st), "randn")
+            zp = self.z[i].data_ptr()
+        cabi.check(lib.ld_ddim_step_at(sp.x_in.data_ptr(), sp.model_out.data_ptr(), zp, sp.x_in.data_ptr(), self.table.data_ptr(),
+                                       self.idx[i].data_ptr(), lo, hi, cabi.OBJ[gd.objective], n, st), "ddim_step_at")
+
+    def run(self, x_out, x_in, cond_out, cond_in, mask, first_pair, n_steps, lo, hi):
+        """Pairs first_pair .. first_pair + n_steps - 1 for both branches; x_out / x_in are updated in place."""
+        import ctypes as C
+        lib = cabi.lib()
+        cur = torch.cuda.current_stream()
+        self.mask.copy_(mask.reshape(self.mask.shape))
+        todo, ex = [n_steps, n_steps], [None, None]
+        for i, (sp, gs, xv, cv) in enumerate(zip(self.plans, self.streams, (x_out, x_in), (cond_out, cond_in))):
+            gs.wait_stream(cur)
+            st = gs.cuda_stream
+            with torch.cuda.stream(gs):
+                sp.x_in.copy_(xv)
+                sp.cond_in.copy_(cv)
+                sp.run_cond(st)
+                self.idx[i].fill_(first_pair - 1)            # the step's first launch advances the pair counter
+                key = (i, float(lo), float(hi), gd_key(self.gd))
+                if key not in self.graphs:
+                    self._step(i, st, lo, hi)                # eager first (lazy attribute calls must not be captured)
+                    todo[i] -= 1
+                    gs.synchronize()
+                    cabi.check(lib.ld_graph_begin(st), "graph_begin")
+                    try:
+                        self._step(i, st, lo, hi)
+                    finally:
+                        g = C.c_void_p()
+                        rc = lib.ld_graph_end(st, C.byref(g))
+                    cabi.check(rc, "graph_end")
+                    self.graphs[key] = g
+                ex[i] = self.graphs[key]
+        for k in range(max(todo)):
+            for i, gs in enumerate(self.streams):
+                if k < todo[i]:
+                    cabi.check(lib.ld_graph_launch(ex[i], gs.cuda_stream), "graph_launch")
+        for sp, gs, xv in zip(self.plans, self.streams, (x_out, x_in)):
+            with torch.cuda.stream(gs):
+                xv.copy_(sp.x_in)
+            cur.wait_stream(gs)
+
+
+def gd_key(gd):
+    return (gd.noise_seed, gd.noise_offset, gd.objective)
+
+
 class GaussianDiffusion(nn.Module):
     def __init__(self, config, model, *, image_size, timesteps=1000, sampling_timesteps=None,
                  objective="pred_v", beta_schedule="sigmoid", schedule_fn_kwargs=dict(),
@@ -768,6 +844,7 @@ class GaussianDiffusion(nn.Module):
     # ------------------------------------------------------------------ DDIM loop
     @torch.inference_mode()
     def ddim_sample(self, cond_img, mask, min_max_val, shape, return_all_timesteps=False):
+        self._sync_model()
         lib, st, dev = cabi.lib(), self._st(), self.device
         B, C, H, W = shape
         HW, n = H * W, B * C * H * W
@@ -839,6 +916,24 @@ class GaussianDiffusion(nn.Module):
             mo_in = plan.model_out if replaced else plan.model_out[B:]
             mo_out = cond_out if replaced else plan.model_out[:B]
             fused = False
+            # the pairs before the fusion time: OOD and IND branch as two concurrent sub-batches (replayed graphs)
+            n_plain = 0
+            for (t_, tn_) in pairs:
+                if tn_ < 0 or (fuse and t_ <= t_fuse):
+                    break
+                n_plain += 1
+            if (not replaced and self.sub_batches > 1 and self.noise_source == "device" and not return_all_timesteps
+                    and n_plain >= 4 and not self.use_graph and (B >= self.min_sub_batch or B * H * W >= 512 * 512)):
+                key = ("ddim", B, H, W, bool(mask_x), T, S, float(eta))
+                if key not in self._subs:
+                    rows = []
+                    for (t_, tn_) in pairs:
+                        san_, c_, sg_ = (0.0, 0.0, 0.0) if tn_ < 0 else scalars(t_, tn_)
+                        rows.append([float(sr_all[t_]), float(srm1_all[t_]), float(sab_all[t_]), float(s1m_all[t_]), san_, c_, sg_,
+                                     1.0 if tn_ < 0 else 0.0])
+                    self._subs[key] = _DdimBranches(self, B, H, W, mask_x, [p_[0] for p_ in pairs], rows)
+                self._subs[key].run(x_out_view, x_in_view, cond_out, cond_in, mask, 0, n_plain, lo, hi)
+                idx, draw = n_plain, 1 + n_plain
             while idx < len(pairs):
                 t, t_next = pairs[idx]
                 fwd(plan, t)

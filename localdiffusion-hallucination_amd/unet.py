@@ -718,13 +718,16 @@ class _Plan:
         for op in self.ops_cond:
             op(st)
 
-    def run_main(self, st, skip_final=False, step_delta=0):
+    def run_main(self, st, skip_final=False, step_delta=0, idx_ptr=None, t_table=None):
         """One denoiser evaluation.  ``skip_final``: stop before final_conv (the caller runs ld_final_step).
         ``step_delta``: added to the device step counter by the evaluation's first launch (ld_step_begin zeroes the
         statistics slots this plan uses, the k-max arena if the unfused linear attention is on the plan, and moves
         the counter -- one launch where two memsets and ld_step_add were three)."""
-        cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr if step_delta else None, int(step_delta), st),
-                   "step_begin")
+        if idx_ptr is not None:                    # strided sampling: t_dev = t_table[++idx] (ld_step_begin)
+            cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr, 0, idx_ptr, t_table, st), "step_begin")
+        else:
+            cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr if step_delta else None, int(step_delta),
+                                              None, None, st), "step_begin")
         ops = self.ops_main[:-1] if skip_final else self.ops_main
         for op in ops:
             op(st)
@@ -734,7 +737,7 @@ class _Plan:
         its own start/stop events, so the times are kernel execution times as rocprofv3 reports them); adds each
         op's kernel time to ``acc[index] = [ms_total, launches]`` (bench.py's per-kernel roofline leg)."""
         lib = self.lib
-        cabi.check(lib.ld_step_begin(*self._begin_args, None, 0, st), "step_begin")
+        cabi.check(lib.ld_step_begin(*self._begin_args, None, 0, None, None, st), "step_begin")
         cabi.check(lib.ld_timing_begin(8 * len(self.ops_main)), "timing_begin")
         marks = [0]
         try:

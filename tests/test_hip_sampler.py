@@ -290,6 +290,30 @@ def test_branch_phase_as_concurrent_sub_batches(dtype, tol, fuse):
     check(f"branch sub-batches {dtype} fuse={fuse} (replayed)", run(gd, cond, mask, B), single, tol)
 
 
+@pytest.mark.parametrize("fuse,S,T", [(True, 50, 1000), (False, 10, 50)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("fp16", 1e-2)])
+def test_ddim_branch_phase_as_concurrent_sub_batches(dtype, tol, fuse, S, T):
+    """The DDIM pairs before the fusion time with the OOD and the IND branch as two replayed HIP graphs on two streams
+    (timestep and schedule scalars looked up through a device pair counter: ld_step_begin + ld_ddim_step_at) == the
+    eager batched DDIM loop; with eta > 0 both branches use the same draw per pair."""
+    B, H = 2, 64
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 7, 1, 0.0, 2.0))
+    mask = torch.zeros(B, 1, H, H)
+    mask[:, :, H // 4: H // 2, H // 4: H // 2] = 1.0
+    for eta in (0.0, 0.5):
+        gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=2, mask_x=True),
+                  H, T, S, dtype=dtype)
+        gd.ddim_sampling_eta = eta
+        gd.noise_source = "device"
+        gd.sub_batches = 1
+        single = run(gd, cond, mask, B)
+        gd.sub_batches = 2
+        split = run(gd, cond, mask, B)
+        assert any(k[0] == "ddim" for k in gd._subs if isinstance(k, tuple)), "the DDIM branch phase did not take the sub-batch path"
+        check(f"DDIM branch sub-batches {dtype} fuse={fuse} eta={eta}", split, single, tol)
+        check(f"DDIM branch sub-batches {dtype} fuse={fuse} eta={eta} (replayed)", run(gd, cond, mask, B), single, tol)
+
+
 def test_cfg3_shape_sub_batches_and_batch_independence():
     """BASELINE.json configs[2] at full size (8 patches of 3x256x256, bf16, the bench's workload) through the
     size-independent properties: the two-sub-batch run equals the single-batch run, patches do not influence each
