@@ -420,6 +420,11 @@ class GaussianDiffusion(nn.Module):
             sub.graphs = {}
         self._subs = {}
 
+    def _sub_ok(self, b, H, W):
+        """Is a sub-batch of ``b`` samples of H x W worth its own stream?  The threshold was measured at 256^2
+        (2 patches per sub-batch lose, 4 win); larger maps count by their pixels (one 512^2 image = 4 such patches)."""
+        return b * H * W >= self.min_sub_batch * 256 * 256 or b >= 2 * self.min_sub_batch
+
     def _sub_streams(self, S):
         """The S side streams of the sub-batch runners (shared by all of them: HIP maps streams onto a few
         hardware queues per process, so more streams than needed only make two of them share a queue)."""
@@ -448,7 +453,8 @@ class GaussianDiffusion(nn.Module):
         n = jp.x_in.numel()
         B_ = jp.x_in.shape[0]
         S = self.sub_batches
-        if (S > 1 and B_ % S == 0 and B_ // S >= self.min_sub_batch and self.noise_source == "device"
+        if (S > 1 and B_ % S == 0 and (B_ // S >= self.min_sub_batch or self._sub_ok(B_ // S, *jp.x_in.shape[2:]))
+                and self.noise_source == "device"
                 and x0_buf is None and after is None and timers is None and n_steps >= 4 and not self.use_graph
                 and jp.x_in.shape[1] == jp.model_out.shape[1]):
             key = (id(jp), S)
@@ -626,7 +632,8 @@ class GaussianDiffusion(nn.Module):
             # the steps before the fusion time: the OOD and the IND branch as two concurrent sub-batches (same
             # draw for both, ld_mask_out folded into the OOD branch's final step)
             n_plain = (t - int(self.config["start_timestep"])) if fuse else t + 1
-            if (not replaced and self.sub_batches > 1 and B >= self.min_sub_batch and self.noise_source == "device"
+            if (not replaced and self.sub_batches > 1 and (B >= self.min_sub_batch or self._sub_ok(B, H, W))
+                    and self.noise_source == "device"
                     and not return_all_timesteps and not return_all_outputs and n_plain >= 4
                     and C == plan.model_out.shape[1] and not self.use_graph):
                 key = (id(plan), "branch", bool(mask_x))
@@ -923,7 +930,7 @@ class GaussianDiffusion(nn.Module):
                     break
                 n_plain += 1
             if (not replaced and self.sub_batches > 1 and self.noise_source == "device" and not return_all_timesteps
-                    and n_plain >= 4 and not self.use_graph and (B >= self.min_sub_batch or B * H * W >= 512 * 512)):
+                    and n_plain >= 4 and not self.use_graph and (B >= self.min_sub_batch or self._sub_ok(B, H, W))):
                 key = ("ddim", B, H, W, bool(mask_x), T, S, float(eta))
                 if key not in self._subs:
                     rows = []
