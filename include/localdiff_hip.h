@@ -371,6 +371,17 @@ int ld_q_sample(const float* x0, const float* noise, float* out, float sqrt_ab, 
 int ld_recompose(const float* patches /*[B,K,C,HW]*/, const float* masks /*[K,HW]*/, float* out,
                  int B, int K, int C, int HW, void* stream);
 
+/* ---- the one collective of the path: all-gather of every rank's finished samples, RCCL over xGMI ---- */
+/* RCCL is dlopen'ed on first use (the copy the process already mapped, e.g. torch's, is preferred; LD_RCCL_PATH
+ * overrides), so the library loads without it.  ld_comm_unique_id on one rank -> hand the 128 bytes to every rank ->
+ * ld_comm_init on each (uses the calling thread's current HIP device) -> ld_allgather enqueued on `stream`:
+ * recv[r*bytes_per_rank ...] = rank r's send buffer -> ld_comm_destroy.  The product's default keeps this collective
+ * in torch.distributed (same RCCL); dist.gather_patches uses these entry points when asked to. */
+int ld_comm_unique_id(void* id_out_128 /* host, 128 bytes */);
+int ld_comm_init(void** comm_out, const void* id_128 /* host */, int world, int rank);
+int ld_allgather(const void* send, void* recv, size_t bytes_per_rank, void* comm, void* stream);
+int ld_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

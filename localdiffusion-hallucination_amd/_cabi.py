@@ -105,6 +105,10 @@ _SIGS = {
                                C.c_int, C.c_int, vp]),
     "ld_q_sample": (C.c_int, [vp, vp, vp, f32, f32, i64, vp]),
     "ld_recompose": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_comm_unique_id": (C.c_int, [vp]),
+    "ld_comm_init": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
+    "ld_allgather": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
+    "ld_comm_destroy": (C.c_int, [vp]),
 }
 
 EXPORTS = tuple(_SIGS)

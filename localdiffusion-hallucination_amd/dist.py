@@ -38,12 +38,83 @@ def shard_patches(x, world=None, rank=None):
     return x[lo:hi]
 
 
-def gather_patches(local, n_items, group=None):
+class LdComm:
+    """The C ABI's own RCCL communicator (``ld_comm_* / ld_allgather``, include/localdiff_hip.h): what a caller without
+    a torch process group uses, and an opt-in for ``gather_patches(..., comm=...)``.  The 128-byte unique id made on rank
+    0 has to reach every rank through SOME channel; ``bootstrap`` uses the torch process group when there is one (a
+    byte-tensor broadcast) or a file path otherwise."""
+
+    def __init__(self, world, rank, unique_id):
+        import ctypes as C
+        from . import _cabi as cabi
+        self.world, self.rank = world, rank
+        self._comm = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        cabi.check(cabi.lib().ld_comm_init(C.byref(self._comm), buf, world, rank), "comm_init")
+
+    @staticmethod
+    def make_unique_id():
+        import ctypes as C
+        from . import _cabi as cabi
+        buf = (C.c_char * 128)()
+        cabi.check(cabi.lib().ld_comm_unique_id(buf), "comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def bootstrap(cls, world=None, rank=None, id_file=None):
+        """Collective: every rank calls it.  With a torch process group the id travels by broadcast; otherwise rank 0
+        writes ``id_file`` and the others poll for it."""
+        import os
+        import time
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(), dist.get_rank()
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            t = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                t.copy_(torch.frombuffer(bytearray(cls.make_unique_id()), dtype=torch.uint8))
+            dist.broadcast(t, 0)
+            return cls(world, rank, bytes(t.cpu().numpy().tobytes()))
+        assert world is not None and rank is not None and (id_file is not None or world == 1)
+        if world == 1:
+            return cls(1, 0, cls.make_unique_id())
+        if rank == 0:
+            with open(id_file + ".tmp", "wb") as f:
+                f.write(cls.make_unique_id())
+            os.replace(id_file + ".tmp", id_file)
+        while not os.path.exists(id_file):
+            time.sleep(0.01)
+        return cls(world, rank, open(id_file, "rb").read())
+
+    def all_gather(self, send, recv):
+        """recv[r*len(send) ...] = rank r's ``send`` (contiguous device tensors), enqueued on the current stream."""
+        from . import _cabi as cabi
+        assert send.is_contiguous() and recv.is_contiguous() and recv.numel() * recv.element_size() == self.world * send.numel() * send.element_size()
+        cabi.check(cabi.lib().ld_allgather(send.data_ptr(), recv.data_ptr(), send.numel() * send.element_size(), self._comm,
+                                           torch.cuda.current_stream().cuda_stream), "allgather")
+
+    def close(self):
+        from . import _cabi as cabi
+        if self._comm:
+            cabi.check(cabi.lib().ld_comm_destroy(self._comm), "comm_destroy")
+            self._comm = None
+
+
+def gather_patches(local, n_items, group=None, comm=None):
     """All-gather ragged shards back into [n_items, ...] on every rank (one collective).
 
     Shards are padded to the largest shard so a single ``all_gather_into_tensor`` suffices
-    (payload: <= 201 MB at 512 patches of 3x256x256 bf16 -- latency-, not bandwidth-bound on xGMI).
+    (payload: 402 MB of fp32 boundary tensors at 512 patches of 3x256x256 -- latency-, not bandwidth-bound on xGMI).
+    ``comm``: an ``LdComm`` -- the same collective through the C ABI's ``ld_allgather`` instead of torch.distributed.
     """
+    if comm is not None:
+        world = comm.world
+        sizes = [shard_bounds(n_items, world, r) for r in range(world)]
+        mx = max(hi - lo for lo, hi in sizes)
+        pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        comm.all_gather(pad.contiguous(), out)
+        return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
     world = dist.get_world_size(group)
     sizes = [shard_bounds(n_items, world, r) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)

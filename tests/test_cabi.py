@@ -87,3 +87,16 @@ def test_state_dict_round_trip_and_reference_names():
     sd = {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 1).items()}
     net.load_state_dict(sd)
     assert torch.equal(net.state_dict()["final_conv.bias"], sd["final_conv.bias"])
+
+
+def test_rccl_entry_points_load_lazily():
+    """ld_comm_* / ld_allgather dlopen RCCL on first use: the library itself loads without it (checked by every other
+    test here), a unique id can be made on a box without a GPU, and bad arguments are refused before RCCL is touched."""
+    import ctypes as C
+    lib = cabi.lib()
+    buf = (C.c_char * 128)()
+    rc = lib.ld_comm_unique_id(buf)
+    assert rc == 0 or b"RCCL unavailable" in lib.ld_last_error()
+    comm = C.c_void_p()
+    assert lib.ld_comm_init(C.byref(comm), buf, 2, 5) == -1 and b"bad arguments" in lib.ld_last_error()
+    assert lib.ld_allgather(None, None, 0, None, None) == -1

@@ -78,3 +78,16 @@ def test_sharded_drivers_world1(world1):
     x = gd3.sample(conds, None, batch_size=B * K, min_max_val=(0.0, 2.0)).reshape(B, K, 1, H, H)
     ref = (x * masks.cuda()[None]).sum(1)
     assert tuple(img.shape) == (B, 1, H, H) and float((img - ref).abs().max()) <= 1e-6
+
+
+def test_ld_allgather_world1_through_the_c_abi():
+    """The C ABI's own RCCL communicator (dlopen'ed librccl: ld_comm_unique_id / ld_comm_init / ld_allgather) at world
+    size 1 on the GPU, alone and as the collective of gather_patches; N > 1 is the same call with the id shared."""
+    comm = ldist.LdComm.bootstrap(world=1, rank=0)
+    x = torch.from_numpy(rng.uniform((5, 3, 16, 16), 77, 1, 0.0, 2.0)).cuda()
+    y = torch.empty_like(x)
+    comm.all_gather(x, y)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    assert torch.equal(ldist.gather_patches(x, 5, comm=comm), x)
+    comm.close()
