@@ -191,6 +191,7 @@ def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5):
       in_situ -- the regime of the timed region: the batch as concurrent sub-batches on two streams; sub-batch 0 is
                  timed while the other one's kernels share the chip (launches are slower, the step is faster)."""
     torch.cuda.synchronize()
+    jp.run_cond(torch.cuda.current_stream().cuda_stream)      # the solo leg evaluates the parent plan itself
     peak_tf = MFMA_PEAK_TF[dtype]
     legs = {}
     split = gd.timed_plan(jp) is not jp
@@ -388,11 +389,11 @@ def main():
         jp.x_in.copy_(x_T)
         z = torch.empty_like(x_T)
         # warm-up (untimed): encoder + W steps
-        jp.run_cond(st)
+        gd.encode_cond(jp, warmup)
         draw = gd.run_joint_steps(jp, T_STEPS - 1, warmup, lo, hi, z, 1)
         sync_all()
         t0 = time.perf_counter()
-        jp.run_cond(st)                                             # once per sample, inside the timed region
+        gd.encode_cond(jp, steps)                                   # conditioning encoder: once per sample, inside the timed region
         t_start = T_STEPS - 1 - warmup
         done = 0
         while done < steps:                                         # wrap to a new sample after T steps

@@ -441,6 +441,22 @@ class GaussianDiffusion(nn.Module):
         return sub.plans[0] if sub is not None else jp
 
     # ------------------------------------------------------------------ joint reverse steps
+    def _will_sub_batch(self, jp, n_steps, x0_buf=None, after=None, timers=None):
+        """The condition under which run_joint_steps hands the steps to the concurrent sub-batch runner."""
+        S, B_ = self.sub_batches, jp.x_in.shape[0]
+        return (S > 1 and B_ % S == 0 and (B_ // S >= self.min_sub_batch or self._sub_ok(B_ // S, *jp.x_in.shape[2:]))
+                and self.noise_source == "device" and x0_buf is None and after is None and timers is None and n_steps >= 4
+                and not self.use_graph and jp.x_in.shape[1] == jp.model_out.shape[1])
+
+    def encode_cond(self, jp, n_steps, x0_buf=None, after=None):
+        """Evaluate the conditioning encoder for the joint steps that follow (``jp.cond_in`` holds the images).  When those
+        steps will run as sub-batches, each sub-batch plan encodes its own slice (``_SubBatches.run`` sees the new
+        ``cond_version``) and the parent plan's evaluation would be thrown away: it is skipped."""
+        if self._will_sub_batch(jp, n_steps, x0_buf, after):
+            jp.cond_version = getattr(jp, "cond_version", 0) + 1
+        else:
+            jp.run_cond(self._st())
+
     def run_joint_steps(self, jp, t_start, n_steps, lo, hi, z, draw, x0_buf=None, after=None, timers=None):
         """``n_steps`` ancestral steps t_start, t_start-1, ... on plan ``jp`` (x_t lives in
         ``jp.x_in`` and is updated in place; the conditioning features must already be encoded).
@@ -453,10 +469,7 @@ class GaussianDiffusion(nn.Module):
         n = jp.x_in.numel()
         B_ = jp.x_in.shape[0]
         S = self.sub_batches
-        if (S > 1 and B_ % S == 0 and (B_ // S >= self.min_sub_batch or self._sub_ok(B_ // S, *jp.x_in.shape[2:]))
-                and self.noise_source == "device"
-                and x0_buf is None and after is None and timers is None and n_steps >= 4 and not self.use_graph
-                and jp.x_in.shape[1] == jp.model_out.shape[1]):
+        if self._will_sub_batch(jp, n_steps, x0_buf, after, timers):
             key = (id(jp), S)
             if key not in self._subs:
                 self._subs[key] = _SubBatches(self, jp, S)
@@ -688,20 +701,21 @@ class GaussianDiffusion(nn.Module):
             if t == start_t:                               # no branch phase ran: start from x_T
                 jp.x_in.copy_(x_T)
             jp.cond_in.copy_(cond)
-            jp.run_cond(st)
             def after(_t):
                 if return_all_outputs:
                     hist_x0.append(x0_buf.cpu())
                 if return_all_timesteps:
                     hist_x.append(jp.x_in.clone())
+            cb = after if (return_all_outputs or return_all_timesteps) else None
             if gate and x_branchout is not None:
+                jp.run_cond(st)
                 if x0_buf is None:
                     x0_buf = torch.empty(shape, dtype=torch.float32, device=dev)
                 self._gated_joint_steps(jp, t, lo, hi, z, draw, x0_buf, x_branchout, cond, cond_out, cond_in,
                                         mask, mask_x, after if (return_all_outputs or return_all_timesteps) else None)
             else:
-                self.run_joint_steps(jp, t, t + 1, lo, hi, z, draw, x0_buf=x0_buf,
-                                     after=after if (return_all_outputs or return_all_timesteps) else None)
+                self.encode_cond(jp, t + 1, x0_buf, cb)
+                self.run_joint_steps(jp, t, t + 1, lo, hi, z, draw, x0_buf=x0_buf, after=cb)
             ret = jp.x_in.clone()
         else:
             ret = xs
