@@ -135,3 +135,38 @@ def test_per_sample_timesteps_and_state_dict_names():
     with torch.no_grad():
         y_ref = unet_ref.unet_forward(sd, net.cfg, x, cond, tv)
     assert float((y - y_ref).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("dtype,limit", [("fp16", 8.0), ("bf16", 40.0)])
+def test_large_k_projections_fall_back_to_the_exact_softmax_shift(dtype, limit):
+    """The single-sweep linear attention shifts softmax_n(k) by the Cauchy-Schwarz bound of k instead of its maximum; the
+    stored weights exp(k - bound) must stay inside the storage type's range, so blocks whose bound exceeds 8 (fp16) /
+    40 (bf16) must take the exact two-sweep maximum.  Scale the k rows of every to_qkv so that some blocks cross the
+    fp16 limit and check (a) the host's choice per block, (b) the forward against the oracle."""
+    kw, B, H = CASES["mri64"]
+    net = ldh.Unet(dim=32, init_dim=32, compute_dtype=dtype, **kw)
+    sd = {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()}
+    hid = net.cfg.hidden
+    for k in list(sd):
+        if k.endswith(".to_qkv.weight") and (k[:-len(".to_qkv.weight")] + ".to_out.1.g") in sd:
+            sd[k] = sd[k].clone()
+            sd[k][hid:2 * hid] *= 6.0                       # k rows: bounds of ~3 become ~18
+    net.load_state_dict(sd)
+    net = net.to("cuda")
+    P = net.packed()
+    bounds = {}
+    for base, ks in P["kshift"].items():
+        w = sd[base + ".to_qkv.weight"]
+        g = sd[base + ".norm.g"].flatten()
+        bounds[base] = float((w[hid:2 * hid, :, 0, 0] * (g * g.numel() ** 0.5)[None, :]).norm(dim=1).max()) * 1.01
+        assert (ks is None) == (bounds[base] > limit), (base, bounds[base], ks is None)
+    assert any(b > 8.0 for b in bounds.values()), bounds
+    x = torch.from_numpy(rng.randn((B, 1, H, H), 1, 100))
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 1, 101, 0.0, 2.0))
+    tv = torch.full((B,), 5, dtype=torch.long)
+    y = net(x.cuda(), cond.cuda(), tv.cuda()).cpu()
+    with torch.no_grad():
+        y_ref = unet_ref.unet_forward(sd, net.cfg, x, cond, tv)
+    rel = float((y - y_ref).abs().max()) / float(y_ref.abs().max())
+    print(f"k rows x6, {dtype}: bounds {sorted(round(b, 1) for b in bounds.values())}, out rel err {rel:.3e}")
+    assert torch.isfinite(y).all() and rel < (8e-3 if dtype == "fp16" else 5e-2)
