@@ -290,17 +290,6 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
   const int h = blockIdx.x, b = blockIdx.y, quarter = blockIdx.z, tid = threadIdx.x;
   const float* src = ctx_part + ((size_t)b * heads + h) * nchunks * CTX_STRIDE;
   const int dl = tid >> 5, sub = tid & 31, d = quarter * 8 + dl;
-  // The launch is ~90 % fixed latency (three phases of dependent global round trips around two barriers).  The W_out
-  // row of this thread's first fold element does not depend on anything computed here: request it now (8 x 16 B), so
-  // that the fold phase starts with its operand in registers instead of 32 scalar loads behind the second barrier.
-  const int hidden0 = heads * 32;
-  float4 wpre[8];
-  {
-    const float* wrow0 = w_out + (size_t)(tid >> 3) * hidden0 + h * 32;      // idx = tid: co = tid >> 3 (< C when tid < 8*C)
-    const bool okw = tid < C * 8;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) wpre[q] = okw ? *reinterpret_cast<const float4*>(wrow0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   {   // per k-channel d (32 threads each): global max of the chunk maxima, rescale weights, Z
     float mc[MAXCH / 32], zc[MAXCH / 32];
     float M = -INFINITY;
@@ -330,12 +319,12 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
   {
     const int i = quarter * 256 + tid;                   // element d*32+e of the head's context
     float s = 0.f;
-    for (int c0 = 0; c0 < nchunks; c0 += 32) {            // 32 partials in flight per round trip
-      float v[32];
+    for (int c0 = 0; c0 < nchunks; c0 += 16) {
+      float v[16];
 #pragma unroll
-      for (int k = 0; k < 32; ++k) v[k] = (c0 + k < nchunks) ? src[(size_t)(c0 + k) * CTX_STRIDE + i] : 0.f;
+      for (int k = 0; k < 16; ++k) v[k] = (c0 + k < nchunks) ? src[(size_t)(c0 + k) * CTX_STRIDE + i] : 0.f;
 #pragma unroll
-      for (int k = 0; k < 32; ++k) s = fmaf(s_w[dl][c0 + k < nchunks ? c0 + k : 0], v[k], s);
+      for (int k = 0; k < 16; ++k) s = fmaf(s_w[dl][c0 + k < nchunks ? c0 + k : 0], v[k], s);
     }
     s_ctx[dl * 33 + sub] = s / s_z[dl];
   }
@@ -347,16 +336,8 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
     const float* wrow = w_out + (size_t)co * hidden + h * 32;
     const float* crow = s_ctx + d8 * 33;
     float m = 0.f;
-    if (idx == tid) {                                     // first element: operand prefetched at kernel start
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {                       // same order of the 32 fmas as the loop below
-        m = fmaf(wpre[q].x, crow[4 * q + 0], m); m = fmaf(wpre[q].y, crow[4 * q + 1], m);
-        m = fmaf(wpre[q].z, crow[4 * q + 2], m); m = fmaf(wpre[q].w, crow[4 * q + 3], m);
-      }
-    } else {
 #pragma unroll 8
-      for (int e = 0; e < 32; ++e) m = fmaf(wrow[e], crow[e], m);
-    }
+    for (int e = 0; e < 32; ++e) m = fmaf(wrow[e], crow[e], m);
     const int mt = co >> 4, ii = co & 15;
     int ch = ci / CK, kq = (ci % CK) / E, e = ci % E;
     if (perm) { ch = ci >> 5; kq = (ci >> 2) & 3; e = ((ci >> 4) & 1) * 4 + (ci & 3); }
