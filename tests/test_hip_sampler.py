@@ -314,6 +314,24 @@ def test_ddim_branch_phase_as_concurrent_sub_batches(dtype, tol, fuse, S, T):
         check(f"DDIM branch sub-batches {dtype} fuse={fuse} eta={eta} (replayed)", run(gd, cond, mask, B), single, tol)
 
 
+def test_single_large_image_branches_run_as_sub_batches():
+    """One 512x512 image (cfg5's shape) through the DDPM branch -> fusion -> joint loop: a sub-batch of ONE image of that
+    size counts as four 256^2 patches (GaussianDiffusion._sub_ok), so its OOD and IND branch take the concurrent
+    sub-batch runner; the result must equal the eager batched loop."""
+    H, T = 512, 12
+    yy, xx = np.mgrid[0:H, 0:H]
+    mask = torch.from_numpy((((yy - H / 2) ** 2 + (xx - H / 2) ** 2) <= 64 ** 2).astype(np.float32))[None, None]
+    cond = torch.from_numpy(rng.uniform((1, 1, H, H), 12, 1, 0.0, 2.0))
+    gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True), H, T)
+    gd.noise_source = "device"
+    gd.sub_batches = 1
+    single = run(gd, cond, mask, 1)
+    gd.sub_batches = 2
+    split = run(gd, cond, mask, 1)
+    assert any(isinstance(k, tuple) and len(k) > 1 and k[1] == "branch" for k in gd._subs), "the branch phase did not take the sub-batch path"
+    check("512^2 single image, branch sub-batches vs eager", split, single, 1e-4)
+
+
 def test_cfg3_shape_sub_batches_and_batch_independence():
     """BASELINE.json configs[2] at full size (8 patches of 3x256x256, bf16, the bench's workload) through the
     size-independent properties: the two-sub-batch run equals the single-batch run, patches do not influence each
