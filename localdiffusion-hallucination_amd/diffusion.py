@@ -186,8 +186,11 @@ class _DdimBranches:
     A step reads its timestep and its pair of schedule scalars through a device pair counter (``ld_step_begin`` with
     a timestep table, ``ld_ddim_step_at``), so one captured graph serves every pair (ddpm.py:984-986, 1013-1068)."""
 
-    def __init__(self, gd, B, H, W, mask_x, times, pair_rows):
-        self.gd, self.B, self.mask_x = gd, B, mask_x
+    def __init__(self, gd, B, H, W, mask_x, times, pair_rows, shared=True):
+        """``shared=True``: the two sub-batches are the OOD and the IND branch of the same B images (same draw per
+        pair, mask_x on sub-batch 0).  ``shared=False``: they are the two halves of one single-branch batch of 2B
+        samples, each drawing its own slice of the pair's draw."""
+        self.gd, self.B, self.mask_x, self.shared = gd, B, mask_x and shared, shared
         dev = gd.device
         self.plans = [gd.model.plan(B, H, W, table_T=gd.num_timesteps_ori, instance=200 + i) for i in range(2)]
         self.streams = gd._sub_streams(2)
@@ -207,8 +210,9 @@ class _DdimBranches:
         if i == 0 and self.mask_x:
             cabi.check(lib.ld_mask_out(sp.model_out.data_ptr(), self.mask.data_ptr(), lo, B, C, H * W, st), "mask_out")
         zp = None
-        if self.with_noise:      # both branches use the SAME draw (ddpm.py:1020): draw index of pair k is 1 + k
-            cabi.check(lib.ld_randn_at(self.z[i].data_ptr(), n, gd.noise_offset, gd.noise_seed, 1, 1, self.idx[i].data_ptr(), st), "randn")
+        if self.with_noise:      # branches use the SAME draw (ddpm.py:1020), halves of a batch their slice; draw of pair k is 1 + k
+            first = gd.noise_offset + (0 if self.shared else i * n)
+            cabi.check(lib.ld_randn_at(self.z[i].data_ptr(), n, first, gd.noise_seed, 1, 1, self.idx[i].data_ptr(), st), "randn")
             zp = self.z[i].data_ptr()
         cabi.check(lib.ld_ddim_step_at(sp.x_in.data_ptr(), sp.model_out.data_ptr(), zp, sp.x_in.data_ptr(), self.table.data_ptr(),
                                        self.idx[i].data_ptr(), lo, hi, cabi.OBJ[gd.objective], n, st), "ddim_step_at")
@@ -218,7 +222,8 @@ class _DdimBranches:
         import ctypes as C
         lib = cabi.lib()
         cur = torch.cuda.current_stream()
-        self.mask.copy_(mask.reshape(self.mask.shape))
+        if mask is not None:
+            self.mask.copy_(mask.reshape(self.mask.shape))
         todo, ex = [n_steps, n_steps], [None, None]
         for i, (sp, gs, xv, cv) in enumerate(zip(self.plans, self.streams, (x_out, x_in), (cond_out, cond_in))):
             gs.wait_stream(cur)
@@ -228,7 +233,7 @@ class _DdimBranches:
                 sp.cond_in.copy_(cv)
                 sp.run_cond(st)
                 self.idx[i].fill_(first_pair - 1)            # the step's first launch advances the pair counter
-                key = (i, float(lo), float(hi), gd_key(self.gd))
+                key = (i, float(lo), float(hi), gd_key(self.gd), self.shared)
                 if key not in self.graphs:
                     self._step(i, st, lo, hi)                # eager first (lazy attribute calls must not be captured)
                     todo[i] -= 1
@@ -987,6 +992,21 @@ class GaussianDiffusion(nn.Module):
             if idx == 0:
                 jp.x_in.copy_(x_T)
             jp.cond_in.copy_(cond)
+            n_left = len(pairs) - idx
+            if (self.sub_batches == 2 and B % 2 == 0 and (B // 2 >= self.min_sub_batch or self._sub_ok(B // 2, H, W))
+                    and self.noise_source == "device" and not return_all_timesteps and n_left >= 4 and not self.use_graph):
+                # single-branch pairs as two concurrent halves of the batch (replayed graphs, sliced draws)
+                key = ("ddim-joint", B, H, W, T, S, float(eta))
+                if key not in self._subs:
+                    rows = []
+                    for (t_, tn_) in pairs:
+                        san_, c_, sg_ = (0.0, 0.0, 0.0) if tn_ < 0 else scalars(t_, tn_)
+                        rows.append([float(sr_all[t_]), float(srm1_all[t_]), float(sab_all[t_]), float(s1m_all[t_]), san_, c_, sg_,
+                                     1.0 if tn_ < 0 else 0.0])
+                    self._subs[key] = _DdimBranches(self, B // 2, H, W, False, [p_[0] for p_ in pairs], rows, shared=False)
+                h = B // 2
+                self._subs[key].run(jp.x_in[:h], jp.x_in[h:], cond[:h], cond[h:], None, idx, n_left, lo, hi)
+                return jp.x_in.clone()
             jp.run_cond(st)
             while idx < len(pairs):
                 t, t_next = pairs[idx]

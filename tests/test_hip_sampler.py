@@ -314,6 +314,25 @@ def test_ddim_branch_phase_as_concurrent_sub_batches(dtype, tol, fuse, S, T):
         check(f"DDIM branch sub-batches {dtype} fuse={fuse} eta={eta} (replayed)", run(gd, cond, mask, B), single, tol)
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+def test_ddim_single_branch_as_concurrent_halves(dtype, tol):
+    """Single-branch DDIM (mask=None) of 4 samples as two concurrent halves (replayed graphs, each half drawing its slice
+    of the pair's draw) == the eager batch of 4; eta 0 and 0.5."""
+    B, H = 4, 64
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 7, 1, 0.0, 2.0))
+    for eta in (0.0, 0.5):
+        gd = make(dict(mode="mri"), dict(data="mri"), H, 50, 10, dtype=dtype)
+        gd.ddim_sampling_eta = eta
+        gd.noise_source = "device"
+        gd.sub_batches = 1
+        single = run(gd, cond, None, B)
+        gd.sub_batches = 2
+        split = run(gd, cond, None, B)
+        assert any(isinstance(k, tuple) and k[0] == "ddim-joint" for k in gd._subs), "the DDIM pairs did not take the sub-batch path"
+        check(f"DDIM halves {dtype} eta={eta}", split, single, tol)
+        check(f"DDIM halves {dtype} eta={eta} (replayed)", run(gd, cond, None, B), single, tol)
+
+
 def test_single_large_image_branches_run_as_sub_batches():
     """One 512x512 image (cfg5's shape) through the DDPM branch -> fusion -> joint loop: a sub-batch of ONE image of that
     size counts as four 256^2 patches (GaussianDiffusion._sub_ok), so its OOD and IND branch take the concurrent
