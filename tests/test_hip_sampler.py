@@ -74,6 +74,14 @@ def test_cfg2_mri128_full(golden):
         check(f"G5 cfg2 x after t={t}", hist[:, 1000 - t], g[f"x_after_t{t}"])
     check("G5 cfg2 final", hist[:, -1], g["final"])
     check("G5 cfg2 (plain call)", run(gd, cond, None, 1), g["final"])
+    # the yardstick for the margin: the reference against ITSELF on one thread instead of eight (fixture G13, made by
+    # tools/make_goldens.py from the real reference): any fp32 evaluation in another summation order sits there
+    self_d = golden("g13_cfg2_reference_self_distance")
+    for t in (100, 10, 0):
+        mine = float(np.abs(hist[:, 1000 - t] - g[f"x_after_t{t}"]).max())
+        ref_self = float(self_d[f"maxabs_t{t}"])
+        print(f"G5 cfg2 t={t}: HIP vs reference {mine:.3e}; reference (1 thread) vs reference (8 threads) {ref_self:.3e}; ratio {mine / ref_self:.2f}")
+        assert mine <= 4.0 * ref_self, (t, mine, ref_self)
 
 
 def test_branch_fusion(golden):

@@ -700,6 +700,38 @@ def g12(ddpm):
     print(f"  wrote tests/golden/g12_trainer_save_manifest.json ({len(man['model'])} model keys, {len(man['ema'])} ema keys)")
 
 
+def g13(ddpm):
+    """How far the REFERENCE is from ITSELF on cfg2 when only its summation order changes: the same code, weights and
+    noise with torch.set_num_threads(1) instead of all cores (MKL-DNN / ATen split reductions differently).  This is the
+    reproducibility floor of the 1e-3 gate: any fp32 implementation that sums in another order sits at this distance."""
+    print("G13 cfg2 on ONE thread vs the golden made on all cores  (tens of minutes)")
+    cfg, H, B, T = CFG_MRI, 128, 1, 1000
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 5, 1, 0.0, 2.0))
+    g5_ = np.load(os.path.join(GOLD, "g5_cfg2_mri128.npz"))
+    sd = sd_torch(cfg)
+    ref_model = build_reference_unet(ddpm, cfg, sd)
+    gd = _ref_diffusion(ddpm, base_config(data="mri"), ref_model, H, T, "sigmoid", "pred_x0", None).eval()
+    n0 = torch.get_num_threads()
+    torch.set_num_threads(1)
+    t0 = time.time()
+    try:
+        with reference_run(PortableNoise(10)):
+            with torch.inference_mode():
+                hist = gd.sample(cond.clone(), None, batch_size=B, mask=None, min_max_val=(0.0, 2.0), return_all_timesteps=True).numpy()
+    finally:
+        torch.set_num_threads(n0)
+    print(f"  reference sample() on 1 thread: wall {time.time()-t0:.1f}s")
+    out = {}
+    for t in (999, 750, 500, 250, 100, 10, 0):
+        d = np.abs(hist[:, T - t] - g5_[f"x_after_t{t}"])
+        print(f"    1 thread vs {n0} threads: x after t={t}: max-abs {d.max():.3e} mean-abs {d.mean():.3e}")
+        out[f"maxabs_t{t}"] = np.float64(d.max())
+        out[f"meanabs_t{t}"] = np.float64(d.mean())
+    out["final_1thread"] = hist[:, -1]
+    out["threads"] = np.array([1, n0])
+    save("g13_cfg2_reference_self_distance", **out)
+
+
 def g0_inventory(ddpm):
     print("G0 parameter inventory")
     lines = []
@@ -722,12 +754,12 @@ def main():
     ddpm = import_reference()
     os.makedirs(GOLD, exist_ok=True)
     todo = [("G0", g0_inventory), ("G1", g1), ("G2", g2), ("G3", g3), ("G4", g4), ("G6", g6),
-            ("G7", g7), ("G8", g8), ("G9", g9), ("G10", g10), ("G12", g12), ("G5", g5), ("G11", g11)]
+            ("G7", g7), ("G8", g8), ("G9", g9), ("G10", g10), ("G12", g12), ("G5", g5), ("G11", g11), ("G13", g13)]
     only = set(filter(None, a.only.split(",")))
     for name, fn in todo:
         if only and name not in only:
             continue
-        if a.skip_long and name in ("G5", "G11"):
+        if a.skip_long and name in ("G5", "G11", "G13"):
             continue
         t0 = time.time()
         fn(ddpm)
