@@ -31,6 +31,29 @@ from . import rng, schedule
 _REPLACE_OUT = ("mnist", "mvtec", "oct", "imagenet")
 
 
+def _masked_stream(i):
+    """Experiment (DESIGN finding 40): a side stream restricted to a subset of the CUs, LD_SUB_CU_MASK =
+    ``lo`` (mask bits [128 i, 128 i + 128)), ``xcd`` (bits with (bit mod 8) div 4 == i: the KFD stripes mask bits over
+    the XCDs, so this is four whole XCDs per stream) or ``even`` (bit mod 2 == i).  Unset: an ordinary stream."""
+    import os
+    kind = os.environ.get("LD_SUB_CU_MASK", "")
+    if not kind:
+        return None
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    n, i = 256, i % 2
+    pick = {"lo": lambda b: b // 128 == i, "xcd": lambda b: (b % 8) // 4 == i, "even": lambda b: b % 2 == i}[kind]
+    words = (C.c_uint32 * (n // 32))()
+    for b in range(n):
+        if pick(b):
+            words[b // 32] |= 1 << (b % 32)
+    st = C.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(n // 32), words)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+    return torch.cuda.ExternalStream(st.value)
+
+
 class _SubBatches:
     """The joint reverse steps of one batch run as S independent sub-batches, each on its own HIP stream as a
     replayed HIP graph of one step.
@@ -131,10 +154,15 @@ class _SubBatches:
                 todo[i] -= self._ensure_graph(i, gs, lo, hi, base)
                 ex[i] = self.graphs[(i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)]
         # interleave the launches so that neither hardware queue runs ahead of the other
+        import time
+        h0 = time.perf_counter()
         for k in range(max(todo)):
             for i, gs in enumerate(self.streams):
                 if k < todo[i]:
                     cabi.check(lib.ld_graph_launch(ex[i], gs.cuda_stream), "graph_launch")
+        # host seconds spent enqueueing replays (includes back-pressure once the hardware queue is full)
+        self.host_launch_s = getattr(self, "host_launch_s", 0.0) + time.perf_counter() - h0
+        self.host_launch_n = getattr(self, "host_launch_n", 0) + sum(todo)
         for i, (sp, gs) in enumerate(zip(self.plans, self.streams)):
             with torch.cuda.stream(gs):
                 jp.x_in[i * b:(i + 1) * b].copy_(sp.x_in)
@@ -436,7 +464,7 @@ class GaussianDiffusion(nn.Module):
         if not hasattr(self, "_side_streams"):
             self._side_streams = []
         while len(self._side_streams) < S:
-            self._side_streams.append(torch.cuda.Stream())
+            self._side_streams.append(_masked_stream(len(self._side_streams)) or torch.cuda.Stream())
         return self._side_streams[:S]
 
     def timed_plan(self, jp):
