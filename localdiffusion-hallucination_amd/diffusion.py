@@ -19,6 +19,7 @@ Noise: ``noise_source='device'`` draws z_t with the counter-based generator on t
 fixtures); a callable ``f(shape, k) -> tensor`` may be supplied instead.
 """
 import os
+import time
 from functools import partial
 
 import numpy as np
@@ -35,7 +36,6 @@ def _masked_stream(i):
     """Experiment (DESIGN finding 40): a side stream restricted to a subset of the CUs, LD_SUB_CU_MASK =
     ``lo`` (mask bits [128 i, 128 i + 128)), ``xcd`` (bits with (bit mod 8) div 4 == i: the KFD stripes mask bits over
     the XCDs, so this is four whole XCDs per stream) or ``even`` (bit mod 2 == i).  Unset: an ordinary stream."""
-    import os
     kind = os.environ.get("LD_SUB_CU_MASK", "")
     if not kind:
         return None
@@ -154,7 +154,6 @@ class _SubBatches:
                 todo[i] -= self._ensure_graph(i, gs, lo, hi, base)
                 ex[i] = self.graphs[(i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)]
         # interleave the launches so that neither hardware queue runs ahead of the other
-        import time
         h0 = time.perf_counter()
         for k in range(max(todo)):
             for i, gs in enumerate(self.streams):
