@@ -286,13 +286,18 @@ __global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     for (int ch = 0; ch < nch; ++ch) {
       __syncthreads();               // previous chunk fully consumed (first time: coefficients visible)
       if (ch == 0) TR_STAMP(4);
+      if (ch == 2) TR_STAMP(11);     // 11..15: one steady-state chunk (tools/trace_conv.py)
       write_lds(ch, hxA, wxA);
       if (ch == 0) TR_STAMP(5);
+      if (ch == 2) TR_STAMP(12);
       __syncthreads();
       if (ch == 0) TR_STAMP(6);
+      if (ch == 2) TR_STAMP(13);
       if (ch + 1 < nch) issue_loads(ch + 1, hxA, wxA);
+      if (ch == 2) TR_STAMP(14);
       compute();
       if (ch == 0) TR_STAMP(7);
+      if (ch == 2) TR_STAMP(15);
     }
     TR_STAMP(8);
   } else {

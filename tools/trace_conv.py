@@ -36,6 +36,14 @@ def run(B, cin, cout, H, W, dtype="bf16", prologue=False, stats=True):
         if t[k]:
             print(f"   {n:32s} +{t[k] - prev:6d}   (at {t[k] - t[0]})")
             prev = t[k]
+    if t[11] and t[15]:      # steady state: chunk 2 of the loop
+        for k, n in ((12, "chunk 2: LDS written (vmcnt wait + transform + writes)"), (13, "chunk 2: barrier"),
+                     (14, "chunk 2: next chunk's loads issued"), (15, "chunk 2: fragment reads + MFMAs")):
+            print(f"   {n:56s} +{t[k] - t[k - 1]:6d}")
+        print(f"   chunk 2 total {t[15] - t[11]}; the barrier that opened it was reached at {t[11] - t[0]}")
+        print("   (caveat: in the traced build hipcc puts an s_waitcnt vmcnt(0) behind the last, partial weight load of a "
+              "chunk -- the stamp that follows copies a register -- so 'loads issued' contains the loads' LATENCY; the "
+              "production kernel has no such wait and pays it at the next chunk's LDS write instead)")
 
 
 if __name__ == "__main__":
