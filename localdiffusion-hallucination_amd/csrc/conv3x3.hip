@@ -50,7 +50,11 @@ __device__ unsigned long long g_conv_trace[16];
 // while one half waits for its loads, transforms and writes them to LDS, the other reads fragments and issues MFMAs,
 // so every SIMD holds two waves whose staging and matrix phases overlap (a 256-thread workgroup alone on a CU is one
 // dependent chain per SIMD with the matrix pipe 25 % busy, DESIGN finding 24).  The halves' partial sums meet in LDS.
-template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false>
+// RAW: no source carries a GroupNorm prologue (32 of the 45 launches of a cfg3 step: block1 convolutions, resampling
+// convolutions and the 32^2 block2 convolutions whose input a separate gn_apply pass materialised).  The staging code of
+// the general kernel tests `stats != nullptr` and the activation kind per fragment at run time; with one wave per SIMD
+// those scalar tests, branches and register copies sit on the chunk loop's critical path (DESIGN finding 42).
+template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
 __global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(SK ? 2 : (MT == 2 ? 3 : 1), SK ? 2 : (MT == 2 ? 3 : 2)))) void conv3x3_kernel(Conv3Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int TR = 4 * NW, TC = 16, HR = TR + 2, HC = TC + 2;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
     const SrcDev S = si ? a.s[1] : a.s[0];
     const int c0 = (ch - si * nch0) * CK;
     const int coef_off = si ? 2 * a.s[0].C : 0;
-    const bool has_coef = S.stats != nullptr;
+    const bool has_coef = !RAW && S.stats != nullptr;
     // this thread always stages the same E channels of the chunk: keep their (a, s) in registers
     float ca[E], cs[E];
     if (has_coef) {
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
 
   // ---- prologue coefficients (overlaps the loads above)
   {
-    const bool any = a.s[0].stats != nullptr || (a.nsrc > 1 && a.s[1].stats != nullptr);
+    const bool any = !RAW && (a.s[0].stats != nullptr || (a.nsrc > 1 && a.s[1].stats != nullptr));
     if (any) {
       const int trow = a.t_ptr ? *a.t_ptr : 0;
       int off = 0;
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(
   }
 }
 
-template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false>
+template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
 int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   constexpr int TR = 4 * NW, HR = TR + 2, HC = 18;
   constexpr int NPIXP = (HR * HC + 15) / 16 * 16;
@@ -422,14 +426,14 @@ int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   const size_t lds = (SK ? 2 : 1) * (4 * NPIXP * 16 + 9 * MT * 1024) + 2 * ctot * sizeof(float) + 4 * 2 * 16 * MT * sizeof(double);
   static size_t allowed = 0;
   if (lds > allowed) {
-    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG, SK>, lds));
+    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>, lds));
     allowed = lds;
   }
   Conv3Dev d = a;
   d.tiles_x = (a.W + 15) / 16;
   const int tiles_y = (a.H + TR - 1) / TR;
   dim3 grid(d.tiles_x * tiles_y, a.Cout / (16 * MT), a.B);
-  LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG, SK>), grid, dim3(SK ? 512 : 256), lds, st, d);
+  LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>), grid, dim3(SK ? 512 : 256), lds, st, d);
   LD_LAUNCH_CHECK("conv3x3");
   return LD_OK;
 }
@@ -455,6 +459,11 @@ int launch(const Conv3Dev& a, hipStream_t st) {
     }
   }
 #endif
+  if constexpr (!DEEP) {
+    static const bool no_raw = getenv("LD_CONV_NO_RAW") != nullptr;      // tuning override: always the general kernel
+    const bool raw = !a.s[0].stats && !(a.nsrc > 1 && a.s[1].stats);
+    if (raw && !no_raw) return launch_dbg<T, MT, NW, DEEP, 0, false, true>(a, st);
+  }
   return launch_dbg<T, MT, NW, DEEP, 0>(a, st);
 }
 
