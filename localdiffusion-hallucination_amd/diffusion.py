@@ -20,9 +20,7 @@ fixtures); a callable ``f(shape, k) -> tensor`` may be supplied instead.
 """
 import os
 import time
-from functools import partial
 
-import numpy as np
 import torch
 from torch import nn
 

@@ -9,7 +9,7 @@ parameter name and a seed (see ``procedural_state_dict``), regenerated identical
 container (golden generation) and on the GPU box.
 """
 from collections import OrderedDict
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Tuple
 
 import numpy as np

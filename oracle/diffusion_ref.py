@@ -16,7 +16,7 @@ Pinned against the real reference by ``tools/make_goldens.py`` (see oracle/unet_
 """
 import math
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Optional
 
 import numpy as np
 import torch
