@@ -519,7 +519,12 @@ class _Plan:
         # (round 2, per launch in the two-sub-batch regime: 64^2 maps with 512-pixel chunks were 32 workgroups walking
         # 16 dependent 32-pixel groups each -- 128-pixel chunks there, 256 at 128^2: kvctx 21.7 -> ~15 us per launch,
         # the reduce + fold launch pays 2 us of it back for the extra partials; tools/exp_kvctx.sh)
-        chunk_px = int(os.environ.get("LD_LINATTN_CHUNK_PX", "1024" if n >= 65536 else ("256" if n >= 16384 else "128")))
+        # (end of round 2: 512 instead of 1024 at 256^2 -- 128 partials per image, two workgroups per CU at 4 patches:
+        # step -1.0 % on the same box, three alternating rounds)
+        # ... at up to 8 patches per launch; 64 patches per GPU measured 0.8 % slower with it and keep 1024)
+        rule = os.environ.get("LD_LINATTN_CHUNK_PX", "512,256,128" if B <= 8 else "1024,256,128").split(",")   # n >= 65536, n >= 16384, smaller
+        rule = [int(v) for v in (rule * 3)[:3]]
+        chunk_px = rule[0] if n >= 65536 else (rule[1] if n >= 16384 else rule[2])
         nchunks = max(1, min(128, n // chunk_px)) if heads == 4 else max(1, min(32, n // 256))
         ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, heads, 32, nchunks)), dtype=torch.float32, device=self.dev)
         wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)
