@@ -32,19 +32,32 @@ struct Conv1Dev {
   unsigned* kmax;
   SrcDev tail;          // LD_EPI_GN_TAIL operand
   int B, H, W, Cout;
+  int group;            // host decision: stage KG K-chunks per barrier pair (small maps), see conv1x1_kernel
 };
 
 // EPI (the epilogue kind) is a template parameter: as a runtime switch inside the store loop it kept every
 // epilogue's registers and branches alive in every launch.
-template <typename T, int MT, int NW, int EPI>
+// G (small maps): the K loop of the plain variant (G = 1) is one dependent global round trip per 64-byte channel
+// chunk (load -> LDS -> barrier -> MT*NW MFMAs: 12-16 round trips for the 384- and 512-channel inputs of the 32^2 /
+// 64^2 stages, 15-20 us for a megabyte of data).  With G = KG the loads of KG chunks are in flight together and
+// share one barrier pair: nch / KG round trips, KG staging buffers of LDS (48 KB at 128-pixel x 64-channel tiles, so
+// three workgroups still fit a CU; staging the whole K extent at once -- the shelved tools/experiments/ variant of
+// finding 28 -- left one workgroup per CU and lost on the launches with several workgroups per CU).
+constexpr int KG = 4;
+template <typename T, int MT, int NW, int EPI, int G = 1>
 __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int NPT = 64 * NW, PLANE = NPT * 16;
+  constexpr int XCH = 4 * PLANE, WCHB = MT * 1024;                    // bytes of one staged chunk: tile, weights
+
+  // K-chunk bookkeeping: plain = chunks of src0 then src1; unshuffle = 4 sub-pixels x chunks of src0
+  const int nc0 = a.s[0].C / CK;
+  const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* s_x = smem;
-  char* s_w = smem + 4 * PLANE;
-  float* s_rinv = reinterpret_cast<float*>(s_w + MT * 1024);
+  char* s_x = smem;                                                  // [G][4][PLANE]
+  char* s_w = smem + G * XCH;                                        // [G][MT][1 KiB]
+  float* s_rinv = reinterpret_cast<float*>(s_w + G * WCHB);
   float* s_tcoef = s_rinv + NPT;                                   // [2*Cout] GN_TAIL coefficients, then 64 doubles scratch
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
@@ -81,13 +94,10 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
     }
   }
 
-  // K-chunk bookkeeping: plain = chunks of src0 then src1; unshuffle = 4 sub-pixels x chunks of src0
-  const int nc0 = a.s[0].C / CK;
-  const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
   const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)b * a.w_bstride);
 
-  for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();
+  // global address of this thread's fragment of chunk `ch` for tile pixel slot `it` (nullptr: past the image)
+  auto frag_ptr = [&](int ch, int it) -> const uint4* {
     int si = 0, c0, p1 = 0, p2 = 0;
     if (a.unshuffle) {
       const int pp = ch / nc0;
@@ -99,46 +109,89 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
     }
     const T* sdata = reinterpret_cast<const T*>(si ? a.s[1].data : a.s[0].data);
     const int Cs = si ? a.s[1].ld : a.s[0].ld;   // pixel stride in elements
-#pragma unroll
-    for (int it = 0; it < NW; ++it) {
-      const int qq = (it * 4 + wv) * 16 + px;
-      const int p = p0 + qq;
-      uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-      if (p < HW) {
-        size_t pix;
-        if (a.unshuffle) {
-          const int y = p / a.W, x = p - y * a.W;
-          pix = ((size_t)b * (2 * a.H) + 2 * y + p1) * (2 * a.W) + 2 * x + p2;
-        } else {
-          pix = (size_t)b * HW + p;
-        }
-        raw = *reinterpret_cast<const uint4*>(sdata + pix * Cs + c0 + kq * E);
-        if (a.rms_in) {
-          float v[E];
-          unpack16<T>(raw, v);
-#pragma unroll
-          for (int e = 0; e < E; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
-        }
-      }
-      *reinterpret_cast<uint4*>(s_x + kq * PLANE + qq * 16) = raw;
+    const int p = p0 + (it * 4 + wv) * 16 + px;
+    if (p >= HW) return nullptr;
+    size_t pix;
+    if (a.unshuffle) {
+      const int y = p / a.W, x = p - y * a.W;
+      pix = ((size_t)b * (2 * a.H) + 2 * y + p1) * (2 * a.W) + 2 * x + p2;
+    } else {
+      pix = (size_t)b * HW + p;
     }
-    if (tid < MT * 64) {
-      *reinterpret_cast<uint4*>(s_w + tid * 16) = wg[((size_t)ch * mt_total + m0) * 64 + tid];
-    }
-    if (MT * 64 > 256) {
+    return reinterpret_cast<const uint4*>(sdata + pix * Cs + c0 + kq * E);
+  };
+  auto stage = [&](const uint4& raw, int it, char* xdst) {             // tile fragment -> LDS (+ RMSNorm sum of squares)
+    if (a.rms_in) {
+      float v[E];
+      unpack16<T>(raw, v);
 #pragma unroll
-      for (int u = 256 + tid; u < MT * 64; u += 256)
-        *reinterpret_cast<uint4*>(s_w + u * 16) = wg[((size_t)ch * mt_total + m0) * 64 + u];
+      for (int e = 0; e < E; ++e) rs[it] = fmaf(v[e], v[e], rs[it]);
     }
-    __syncthreads();
+    *reinterpret_cast<uint4*>(xdst + kq * PLANE + ((it * 4 + wv) * 16 + px) * 16) = raw;
+  };
+  auto mfma_chunk = [&](const char* xsrc, const char* wsrc) {
     uint4 A[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) A[m] = *reinterpret_cast<const uint4*>(s_w + m * 1024 + lane * 16);
+    for (int m = 0; m < MT; ++m) A[m] = *reinterpret_cast<const uint4*>(wsrc + m * 1024 + lane * 16);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + kq * PLANE + ((wv * NW + j) * 16 + px) * 16);
+      const uint4 Bf = *reinterpret_cast<const uint4*>(xsrc + kq * PLANE + ((wv * NW + j) * 16 + px) * 16);
 #pragma unroll
       for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[m], Bf);
+    }
+  };
+  constexpr int WPT = (MT * 64 + 255) / 256;                           // weight fragments per thread and chunk
+  if constexpr (G > 1) {
+    for (int c0 = 0; c0 < nch; c0 += G) {
+      uint4 raw[G][NW], wr[G][WPT];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (c0 + g < nch) {                                            // uniform
+#pragma unroll
+          for (int it = 0; it < NW; ++it) {
+            const uint4* gp = frag_ptr(c0 + g, it);
+            raw[g][it] = gp ? *gp : make_uint4(0u, 0u, 0u, 0u);
+          }
+#pragma unroll
+          for (int k = 0; k < WPT; ++k) {
+            const int u = k * 256 + tid;
+            wr[g][k] = u < MT * 64 ? wg[((size_t)(c0 + g) * mt_total + m0) * 64 + u] : make_uint4(0u, 0u, 0u, 0u);
+          }
+        }
+      }
+      __syncthreads();                                                 // the previous group's fragments are consumed
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (c0 + g < nch) {
+#pragma unroll
+          for (int it = 0; it < NW; ++it) stage(raw[g][it], it, s_x + (size_t)g * XCH);
+#pragma unroll
+          for (int k = 0; k < WPT; ++k) {
+            const int u = k * 256 + tid;
+            if (u < MT * 64) *reinterpret_cast<uint4*>(s_w + (size_t)g * WCHB + u * 16) = wr[g][k];
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        if (c0 + g < nch) mfma_chunk(s_x + (size_t)g * XCH, s_w + (size_t)g * WCHB);
+    }
+  } else {
+    for (int ch = 0; ch < nch; ++ch) {
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < NW; ++it) {
+        const uint4* gp = frag_ptr(ch, it);
+        stage(gp ? *gp : make_uint4(0u, 0u, 0u, 0u), it, s_x);
+      }
+#pragma unroll
+      for (int k = 0; k < WPT; ++k) {
+        const int u = k * 256 + tid;
+        if (u < MT * 64) *reinterpret_cast<uint4*>(s_w + u * 16) = wg[((size_t)ch * mt_total + m0) * 64 + u];
+      }
+      __syncthreads();
+      mfma_chunk(s_x, s_w);
     }
   }
 
@@ -275,10 +328,22 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 template <typename T, int MT, int NW, int EPI>
 int launch_epi(const Conv1Dev& a, hipStream_t st) {
   constexpr int NPT = 64 * NW;
-  const size_t lds = 4 * NPT * 16 + MT * 1024 + NPT * sizeof(float) + (EPI == LD_EPI_GN_TAIL ? 2 * a.Cout * sizeof(float) + 64 * sizeof(double) : 0);
+  const size_t tail = NPT * sizeof(float) + (EPI == LD_EPI_GN_TAIL ? 2 * a.Cout * sizeof(float) + 64 * sizeof(double) : 0);
+  const size_t chunk = 4 * NPT * 16 + MT * 1024;
   const int HW = a.H * a.W;
   dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
-  LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI>), grid, dim3(256), lds, st, a);
+  if (a.group) {
+    const size_t lds = KG * chunk + tail;
+    static size_t allowed = 0;
+    if (lds > allowed) {
+      LD_HIP(ld_allow_lds((conv1x1_kernel<T, MT, NW, EPI, KG>), lds));
+      allowed = lds;
+    }
+    LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI, KG>), grid, dim3(256), lds, st, a);
+    LD_LAUNCH_CHECK("conv1x1(grouped K)");
+    return LD_OK;
+  }
+  LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI>), grid, dim3(256), chunk + tail, st, a);
   LD_LAUNCH_CHECK("conv1x1");
   return LD_OK;
 }
@@ -296,8 +361,19 @@ int launch(const Conv1Dev& a, hipStream_t st) {
 }
 
 template <typename T>
-int dispatch(const Conv1Dev& a, hipStream_t st) {
+int dispatch(const Conv1Dev& a0, hipStream_t st) {
+  Conv1Dev a = a0;
   const int HW = a.H * a.W;
+  {
+    // grouped staging where the launch is a chain of dependent round trips over a small map: at most
+    // LD_C1_GROUP_MAX_PX pixels in the whole launch (default 64^2 x 8) and at least 4 K-chunks; LD_C1_GROUP=0: off
+    static const long group_max_px = getenv("LD_C1_GROUP_MAX_PX") ? atol(getenv("LD_C1_GROUP_MAX_PX")) : 32768;
+    static const int group_on = getenv("LD_C1_GROUP") ? atoi(getenv("LD_C1_GROUP")) : 1;
+    const int ck = DT<T>::CK;
+    const int nc0 = a.s[0].C / ck;
+    const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / ck : 0);
+    a.group = group_on && (long)HW * a.B <= group_max_px && nch >= 4;
+  }
   if (a.epi == LD_EPI_RMS_RES) {
     switch (a.Cout) {
       case 32: return launch<T, 2, 2>(a, st);
@@ -357,6 +433,7 @@ extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
     a.tail = a.s[0];
   }
   a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout;
+  a.group = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return LD_DISPATCH(p->dtype, dispatch<T>(a, st));
 }
