@@ -372,7 +372,8 @@ int dispatch(const Conv1Dev& a0, hipStream_t st) {
     const int ck = DT<T>::CK;
     const int nc0 = a.s[0].C / ck;
     const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / ck : 0);
-    a.group = group_on && (long)HW * a.B <= group_max_px && nch >= 4;
+    static const int group_min_ch = getenv("LD_C1_GROUP_MIN_CH") ? atoi(getenv("LD_C1_GROUP_MIN_CH")) : 4;
+    a.group = group_on && (long)HW * a.B <= group_max_px && nch >= group_min_ch;
   }
   if (a.epi == LD_EPI_RMS_RES) {
     switch (a.Cout) {
