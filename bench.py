@@ -331,6 +331,7 @@ def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a))
+    import localdiffusion_hallucination_amd as ldh      # before the first GPU call: the package sets a HIP runtime default
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -350,7 +351,6 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    import localdiffusion_hallucination_amd as ldh
     from localdiffusion_hallucination_amd import _cabi as cabi, rng, weights
 
     if a.workload == "cfg5":
