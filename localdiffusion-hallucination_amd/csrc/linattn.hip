@@ -281,16 +281,21 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctx
 // h*32+d of M_b = W_out . blockdiag(ctx^T) (fold_kernel's arithmetic and output order): a column of M_b only
 // needs row d of the context, so the quarters are independent.  Two dependent launches of ~10-25 us of latency
 // each become one; the chunk loop keeps 16 loads per thread in flight.
-template <typename T>
+// DR = k-channels d per workgroup (grid.z = 32 / DR).  DR = 8: every thread owns one element of the 8x32 slice and
+// walks ALL chunk partials (nchunks / 16 dependent load batches: 8 at the 128 partials of a 256^2 block).  DR = 2:
+// the 256 threads are 4 chunk groups x (2 x 32 elements); a thread sums every fourth partial (2 batches at 128
+// partials), the groups meet in LDS -- four times the workgroups, a quarter of the dependent round trips.
+template <typename T, int DR>
 __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ ctx_part, int nchunks,
                                                       const float* __restrict__ w_out, T* __restrict__ w_packed,
                                                       int C, int heads, int perm) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
-  __shared__ float s_w[8][MAXCH + 1], s_z[8], s_ctx[8 * 33];
-  const int h = blockIdx.x, b = blockIdx.y, quarter = blockIdx.z, tid = threadIdx.x;
+  constexpr int CG = 8 / DR, EL = DR * 32;                 // chunk groups, elements of the slice
+  __shared__ float s_w[DR][MAXCH + 1], s_z[DR], s_ctx[DR * 33], s_part[CG][EL];
+  const int h = blockIdx.x, b = blockIdx.y, part = blockIdx.z, tid = threadIdx.x;
   const float* src = ctx_part + ((size_t)b * heads + h) * nchunks * CTX_STRIDE;
-  const int dl = tid >> 5, sub = tid & 31, d = quarter * 8 + dl;
-  {   // per k-channel d (32 threads each): global max of the chunk maxima, rescale weights, Z
+  if (tid < EL) {   // per k-channel d (32 threads each): global max of the chunk maxima, rescale weights, Z
+    const int dl = tid >> 5, sub = tid & 31, d = part * DR + dl;
     float mc[MAXCH / 32], zc[MAXCH / 32];
     float M = -INFINITY;
 #pragma unroll
@@ -317,22 +322,34 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
   }
   __syncthreads();
   {
-    const int i = quarter * 256 + tid;                   // element d*32+e of the head's context
+    const int cg = tid / EL, rem = tid - cg * EL, dl = rem >> 5;
+    const int i = part * EL + rem;                         // element d*32+e of the head's context
     float s = 0.f;
-    for (int c0 = 0; c0 < nchunks; c0 += 16) {
+    for (int c0 = cg; c0 < nchunks; c0 += 16 * CG) {       // chunks cg, cg + CG, ...: 16 loads in flight
       float v[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = (c0 + k < nchunks) ? src[(size_t)(c0 + k) * CTX_STRIDE + i] : 0.f;
+      for (int k = 0; k < 16; ++k) v[k] = (c0 + k * CG < nchunks) ? src[(size_t)(c0 + k * CG) * CTX_STRIDE + i] : 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s = fmaf(s_w[dl][c0 + k < nchunks ? c0 + k : 0], v[k], s);
+      for (int k = 0; k < 16; ++k) s = fmaf(s_w[dl][c0 + k * CG < nchunks ? c0 + k * CG : 0], v[k], s);
     }
-    s_ctx[dl * 33 + sub] = s / s_z[dl];
+    if constexpr (CG == 1) {
+      s_ctx[dl * 33 + (rem & 31)] = s / s_z[dl];
+    } else {
+      s_part[cg][rem] = s;
+      __syncthreads();
+      if (tid < EL) {
+        float t = s_part[0][tid];
+#pragma unroll
+        for (int g = 1; g < CG; ++g) t += s_part[g][tid];
+        s_ctx[(tid >> 5) * 33 + (tid & 31)] = t / s_z[tid >> 5];
+      }
+    }
   }
   __syncthreads();
   const int hidden = heads * 32, mt_total = C / 16;
   T* dst = w_packed + (size_t)b * C * hidden;
-  for (int idx = tid; idx < C * 8; idx += 256) {
-    const int co = idx >> 3, d8 = idx & 7, ci = h * 32 + quarter * 8 + d8;
+  for (int idx = tid; idx < C * DR; idx += 256) {
+    const int co = idx / DR, d8 = idx - co * DR, ci = h * 32 + part * DR + d8;
     const float* wrow = w_out + (size_t)co * hidden + h * 32;
     const float* crow = s_ctx + d8 * 33;
     float m = 0.f;
@@ -356,7 +373,12 @@ extern "C" int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const floa
   LD_REQUIRE(!(perm && !ld_dtype_16(dtype)), "ld_linattn_ctxfold: perm=1 is the 16-bit chained-operand order");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   LD_DISPATCH(dtype, [&] {
-    LD_LAUNCH(ctxfold_kernel<T>, dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (T*)w_packed, C, heads, perm);
+    // many partials: four chunk groups per workgroup (LD_FOLD_SPLIT_MIN, default 32 partials; 0 = never)
+    static const int split_min = getenv("LD_FOLD_SPLIT_MIN") ? atoi(getenv("LD_FOLD_SPLIT_MIN")) : 32;
+    if (split_min > 0 && nchunks >= split_min)
+      LD_LAUNCH((ctxfold_kernel<T, 2>), dim3(heads, B, 16), dim3(256), 0, st, ctx_part, nchunks, w_out, (T*)w_packed, C, heads, perm);
+    else
+      LD_LAUNCH((ctxfold_kernel<T, 8>), dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (T*)w_packed, C, heads, perm);
     return 0;
   }());
   LD_LAUNCH_CHECK("linattn_ctxfold");
