@@ -29,6 +29,7 @@ from . import rng, schedule
 
 _REPLACE_OUT = ("mnist", "mvtec", "oct", "imagenet")
 _RESYNC = int(os.environ.get("LD_SUB_RESYNC", "32"))     # steps between phase alignments of the sub-batch streams
+_RESYNC_EARLY = int(os.environ.get("LD_SUB_RESYNC_EARLY", "1"))     # ... and before each of the first steps
 
 
 def _align_streams(streams):
@@ -170,7 +171,9 @@ class _SubBatches:
         # again every LD_SUB_RESYNC steps (default 32; 0: never).
         h0 = time.perf_counter()
         for k in range(max(todo)):
-            if self.S > 1 and _RESYNC > 0 and k % _RESYNC == 0 and k < min(todo):
+            # (and in front of step 1: the host enqueues the streams' first replays one after the other, 0.3 ms apart, so
+            # the alignment in front of step 0 finds empty queues and aligns nothing)
+            if self.S > 1 and _RESYNC > 0 and (k % _RESYNC == 0 or k <= _RESYNC_EARLY) and k < min(todo):
                 _align_streams(self.streams)
             for i, gs in enumerate(self.streams):
                 if k < todo[i]:
