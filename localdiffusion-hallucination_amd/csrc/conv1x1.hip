@@ -32,7 +32,7 @@ struct Conv1Dev {
   unsigned* kmax;
   SrcDev tail;          // LD_EPI_GN_TAIL operand
   int B, H, W, Cout;
-  int group;            // host decision: stage KG K-chunks per barrier pair (small maps), see conv1x1_kernel
+  int group;            // host decision: K-chunks staged per barrier pair (0 = 1; KG on small maps, 2 on mid-size ones)
 };
 
 // EPI (the epilogue kind) is a template parameter: as a runtime switch inside the store loop it kept every
@@ -332,7 +332,7 @@ int launch_epi(const Conv1Dev& a, hipStream_t st) {
   const size_t chunk = 4 * NPT * 16 + MT * 1024;
   const int HW = a.H * a.W;
   dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
-  if (a.group) {
+  if (a.group == KG) {
     const size_t lds = KG * chunk + tail;
     static size_t allowed = 0;
     if (lds > allowed) {
@@ -341,6 +341,17 @@ int launch_epi(const Conv1Dev& a, hipStream_t st) {
     }
     LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI, KG>), grid, dim3(256), lds, st, a);
     LD_LAUNCH_CHECK("conv1x1(grouped K)");
+    return LD_OK;
+  }
+  if (a.group == 2) {
+    const size_t lds = 2 * chunk + tail;
+    static size_t allowed2 = 0;
+    if (lds > allowed2) {
+      LD_HIP(ld_allow_lds((conv1x1_kernel<T, MT, NW, EPI, 2>), lds));
+      allowed2 = lds;
+    }
+    LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI, 2>), grid, dim3(256), lds, st, a);
+    LD_LAUNCH_CHECK("conv1x1(grouped K, pairs)");
     return LD_OK;
   }
   LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI>), grid, dim3(256), chunk + tail, st, a);
@@ -373,7 +384,10 @@ int dispatch(const Conv1Dev& a0, hipStream_t st) {
     const int nc0 = a.s[0].C / ck;
     const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / ck : 0);
     static const int group_min_ch = getenv("LD_C1_GROUP_MIN_CH") ? atoi(getenv("LD_C1_GROUP_MIN_CH")) : 4;
-    a.group = group_on && (long)HW * a.B <= group_max_px && nch >= group_min_ch;
+    a.group = (group_on && (long)HW * a.B <= group_max_px && nch >= group_min_ch) ? KG : 0;
+    // mid-size maps (the 128^2 stage at 4 patches per launch): two or three chunks per tile -- pairs
+    static const long pair_max_px = getenv("LD_C1_PAIR_MAX_PX") ? atol(getenv("LD_C1_PAIR_MAX_PX")) : 65536;
+    if (group_on && !a.group && (long)HW * a.B <= pair_max_px && nch >= 2) a.group = 2;
   }
   if (a.epi == LD_EPI_RMS_RES) {
     switch (a.Cout) {
