@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"],
+                    help="storage dtype; default: bf16 for cfg3 (BASELINE configs[2]), fp16 for cfg5 (configs[4])")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--patches", type=int, default=8, help="local patches per GPU (K masks of one image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -60,35 +61,93 @@ def parse():
                     help="cfg3 (default, the headline metric) | cfg5: BASELINE configs[4] as stated -- one 1x512x512 image per GPU, "
                          "DDIM 50 of 1000 steps, OOD/IND branches with a circular mask, fusion at times[-4]; reports images/s")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the reverse step from a captured HIP graph (default: eager launches)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.dtype is None:
+        a.dtype = "fp16" if a.workload == "cfg5" else "bf16"
+    return a
+
+
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT touching HIP: a process that has initialised the GPU must never be
+    re-executed on this pool, and the launcher's children are the ones that should initialise it.  KFD topology nodes
+    with SIMDs are GPUs (CPU nodes have simd_count 0); HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES narrow the set the way the
+    runtime would."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split(None, 1) for line in open(f).read().splitlines() if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def _tail(path, lines=25):
+    try:
+        return "".join(open(path, errors="replace").readlines()[-lines:])
+    except OSError:
+        return ""
 
 
 def launch_ranks(a):
-    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process has made no GPU
-    call and makes none), wait for all of them, relay rank 0's stdout.  Non-zero exit if any rank failed."""
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process makes no GPU call,
+    not even a device count through HIP), relay rank 0's stdout.  Every rank's stderr goes to
+    <logdir>/bench_rank<r>.err (LD_BENCH_LOG_DIR, default a fresh temp dir); when a rank fails the tail of the FIRST
+    failing rank is printed, the others get LD_BENCH_GRACE seconds (default 30) to finish and are then killed by PID;
+    LD_BENCH_RANK_TIMEOUT seconds (default 3600) bound the whole run.  Non-zero exit on any failure or timeout."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU on this image
+    import tempfile
+    n_dev = visible_gpus()
     shared = os.environ.get("LD_BENCH_SHARE_GPU") == "1"     # functional test of the N > 1 path on a 1-GPU box (gloo)
     if n_dev < a.gpus and not shared:
-        print(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
+        print(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) visible (KFD topology / *_VISIBLE_DEVICES)", file=sys.stderr)
         return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    logdir = os.environ.get("LD_BENCH_LOG_DIR") or tempfile.mkdtemp(prefix="ld_bench_")
+    os.makedirs(logdir, exist_ok=True)
+    timeout = float(os.environ.get("LD_BENCH_RANK_TIMEOUT", "3600"))
+    grace = float(os.environ.get("LD_BENCH_GRACE", "30"))
+    procs, errs = [], []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(1, n_dev) if shared else r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        errs.append(os.path.join(logdir, f"bench_rank{r}.err"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+                                      stdout=open(os.path.join(logdir, f"bench_rank{r}.out"), "wb"), stderr=open(errs[-1], "wb")))
+    t0 = time.monotonic()
+    first_bad, deadline, why = None, t0 + timeout, None
+    while any(p.poll() is None for p in procs):
+        now = time.monotonic()
+        if first_bad is None:
+            bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad:
+                first_bad = bad[0]
+                deadline = min(deadline, now + grace)      # the others are most likely stuck in a collective now
+        if now > deadline:
+            why = (f"rank {first_bad} failed and the others did not finish within {grace:.0f} s" if first_bad is not None
+                   else f"timeout: {timeout:.0f} s (LD_BENCH_RANK_TIMEOUT)")
+            for p in procs:                                  # exact PIDs of the children this function started
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(open(os.path.join(logdir, "bench_rank0.out"), errors="replace").read())
     sys.stdout.flush()
-    if any(codes):
-        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+    if any(codes) or why:
+        bad = first_bad if first_bad is not None else next((r for r, c in enumerate(codes) if c), 0)
+        print(f"bench.py: rank exit codes {codes}" + (f" ({why})" if why else "") + f"; per-rank stderr in {logdir}", file=sys.stderr)
+        print(f"---- tail of {errs[bad]} ----\n{_tail(errs[bad])}", file=sys.stderr)
         return 1
     return 0
 
@@ -258,9 +317,17 @@ def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5):
                  # once per sample instead of once per step
                  "path_frac": tp_value * ALGO_TB_PER_PATCH * 1e3 / HBM_PEAK_GBS,
                  "resblock_conv_path": conv_path(per_op), "families": table})
+    roof["timed_regime_kernel"], roof["timed_regime_frac"], roof["timed_regime_bound"] = name, roof["frac"], roof["bound"]
     if "in_situ" in legs:
         t2, ops2, plan2 = legs["in_situ"]
         r2, g2, f2 = price(t2[name]) if name in t2 else ({"frac": None}, 0, 0)
+        # the family that dominates the regime the timed region actually runs in, priced per launch while the other
+        # sub-batch's kernels share the chip (each launch carries launch_batch patches)
+        dom2 = next(iter(t2))
+        rd, _, _ = price(t2[dom2])
+        roof["timed_regime_kernel"] = dom2
+        roof["timed_regime_frac"] = rd["frac"]
+        roof["timed_regime_bound"] = rd["bound"]
         roof["in_situ"] = {"regime": "%d concurrent sub-batches of %d, sub-batch 0 timed" % (gd.sub_batches, int(plan2.x_in.shape[0])),
                            "launch_batch": int(plan2.x_in.shape[0]), "frac": r2["frac"],
                            "avg_launch_us": t2.get(name, {}).get("avg_us"), "resblock_conv_path": conv_path(ops2),
@@ -277,12 +344,12 @@ def bench_cfg5(a, rank, world, dev, dist):
     import localdiffusion_hallucination_amd as ldh
     from localdiffusion_hallucination_amd import rng, weights
     H, T, S = 512, T_STEPS, 50
-    dtype = a.dtype if a.dtype != "bf16" or "--dtype" in sys.argv else "fp16"
+    dtype = a.dtype
     net = ldh.Unet(dim=32, init_dim=32, mode="mri", compute_dtype=dtype)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()})
     net = net.to(dev)
     config = dict(branch_out=True, start_intermediate=True, start_timestep=2, data="mri", mask_x=True, mask_cond=False,
-                  ood_AD=False, ood_confidence=False, classifier=False, use_gt=False, use_gt_timestep=100)
+                  ood_AD=True, ood_confidence=False, classifier=False, use_gt=False, use_gt_timestep=100)
     gd = ldh.GaussianDiffusion(config, net, image_size=H, timesteps=T, objective="pred_x0", beta_schedule="sigmoid",
                                sampling_timesteps=S).to(dev)
     gd.noise_source = "device"
@@ -331,8 +398,15 @@ def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a))
-    import localdiffusion_hallucination_amd as ldh      # before the first GPU call: the package sets a HIP runtime default
     rank = int(os.environ.get("RANK", "0"))
+    # fault injection for the launcher's tests (tests/test_bench_cli.py): before anything touches the GPU
+    if os.environ.get("LD_BENCH_FAIL_RANK") in (str(rank), "all"):
+        print(f"bench.py: injected failure on rank {rank} (LD_BENCH_FAIL_RANK)", file=sys.stderr)
+        sys.exit(3)
+    if os.environ.get("LD_BENCH_HANG_RANK") in (str(rank), "all"):
+        time.sleep(1e6)
+    import localdiffusion_hallucination_amd as ldh
+    ldh.configure_runtime()                              # before the first GPU call: graph packet capture off (finding 47)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("LD_BENCH_SHARE_GPU") == "1":
@@ -393,15 +467,24 @@ def main():
         draw = gd.run_joint_steps(jp, T_STEPS - 1, warmup, lo, hi, z, 1)
         sync_all()
         t0 = time.perf_counter()
-        gd.encode_cond(jp, steps)                                   # conditioning encoder: once per sample, inside the timed region
         t_start = T_STEPS - 1 - warmup
-        done = 0
+        done, new_sample, parent_encoded = 0, True, False
         while done < steps:                                         # wrap to a new sample after T steps
             chunk = min(steps - done, t_start + 1)
+            # the conditioning encoder runs once per SAMPLE, inside the timed region.  Whether a chunk's steps run as
+            # sub-batches is decided per chunk (run_joint_steps: >= 4 steps): a short chunk at a wrap runs on the
+            # parent plan, whose features must then have been encoded as well.
+            if new_sample:
+                gd.encode_cond(jp, chunk)
+                parent_encoded = not gd._will_sub_batch(jp, chunk)
+            elif not gd._will_sub_batch(jp, chunk) and not parent_encoded:
+                jp.run_cond(st)
+                parent_encoded = True
             draw = gd.run_joint_steps(jp, t_start, chunk, lo, hi, z, draw)
             done += chunk
             t_start -= chunk
-            if t_start < 0:
+            new_sample = t_start < 0
+            if new_sample:
                 t_start = T_STEPS - 1
         # per-sample exchange: all-gather the local patches and recompose by the masks
         xl = jp.x_in
@@ -435,7 +518,10 @@ def main():
                    "parallelism": f"patch-sharded x{world}, one all-gather per sample"
                                   + (" [LD_BENCH_SHARE_GPU: ranks share one GPU over gloo -- functional test, not a measurement]"
                                      if os.environ.get("LD_BENCH_SHARE_GPU") == "1" else ""),
-                   "hip_graph": bool(gd.use_graph),
+                   # how the timed steps were issued: as replayed HIP graphs of one step per sub-batch (the default
+                   # regime, _SubBatches), as ONE replayed graph of the whole batch (--graph 1), or eagerly
+                   "step_graph_replay": bool(gd.timed_plan(jp) is not jp or gd.use_graph),
+                   "whole_batch_graph_flag": bool(gd.use_graph),
                    "concurrent_sub_batches": (gd.sub_batches if gd.timed_plan(jp) is not jp else 1)},
     }
 

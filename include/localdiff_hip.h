@@ -77,6 +77,18 @@ int ld_event_destroy(void* ev);
 /* make `stream` wait for `ev` (fork/join of independent branches on two streams, e.g. a ResnetBlock's
  * res_conv beside its 3x3 convs; also captured as graph edges) */
 int ld_stream_wait_event(void* stream, void* ev);
+/* Profiler-visible phase markers: nested roctx ranges (host side) around the phases of a sample -- "encoder",
+ * "step", "exchange" -- so that a rocprofv3 --marker-trace of sample() is readable.  The reference's only hook is the
+ * wall-clock timer around sample() (test.py:392-415).  No-ops when no roctx library can be loaded (LD_NO_ROCTX=1:
+ * never try). */
+/* Host-side counters of how the dispatchers routed launch calls since the library was loaded (a call made during
+ * graph capture counts once, its replays do not): lets a test assert WHICH kernel a shape ran on. */
+#define LD_COUNTER_CONV3X3_C32 0      /* ld_conv3x3 calls taken by the persistent LDS-DMA kernel (conv3x3_c32.hip) */
+#define LD_COUNTER_CONV3X3_GENERIC 1  /* ... by the register-staged generic kernel (conv3x3.hip) */
+#define LD_COUNTER_MAX 8
+long long ld_counter(int which);
+int ld_range_push(const char* name /* host string */);
+int ld_range_pop(void);
 
 /* ---- one input of a convolution, with an optional normalise-on-load prologue --------------- */
 /* Replaces the separate GroupNorm / FiLM / SiLU / ReLU / concat / nearest-upsample passes of
@@ -363,6 +375,16 @@ int ld_fuse_ddim(const float* x_out, const float* x_in, const float* x0_out, con
                  const float* mask, const float* noise, float* x_next, float sqrt_recip,
                  float sqrt_recipm1, float sqrt_abar_next, float c, float sigma, float lo,
                  float hi, int B, int C, int HW, void* stream);
+/* K-branch form of ld_fuse_ddim (the reference has K = 2): masks [B,K,HW], branch 0 OOD-style with its
+ * own pointers, branches 1..K-1 in x_rest / x0_rest ([K-1,B,C,HW]).  Per element, with a_k = clamp(x0_k) and
+ * e_k = (sqrt_recip x_k - a_k) / sqrt_recipm1:
+ *   x0  = clamp(a_0 if a_0 != 0 else a_j),  j = the first k >= 1 with m_k >= 1, K-1 if there is none
+ *   eps = first non-zero of e_k*(m_k>=1), k = 0..K-1 (the last one if all are zero)
+ * With K = 2 and m_1 = 1-(m_0>=1) the result is bitwise that of ld_fuse_ddim (ddpm.py:1025-1041). */
+int ld_fuse_ddim_k(const float* x_first, const float* x_rest, const float* x0_first, const float* x0_rest,
+                   const float* masks, const float* noise, float* x_next, float sqrt_recip, float sqrt_recipm1,
+                   float sqrt_abar_next, float c, float sigma, float lo, float hi, int B, int C, int K, int HW,
+                   void* stream);
 /* q_sample (ddpm.py:1148-1154) for the use_gt start (:937-944) */
 int ld_q_sample(const float* x0, const float* noise, float* out, float sqrt_ab, float sqrt_1mab,
                 int64_t n, void* stream);

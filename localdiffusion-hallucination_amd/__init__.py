@@ -10,18 +10,26 @@ Importing the package does not load the HIP library: pure-host helpers (``rng``,
 """
 import os as _os
 
-# Runtime setting for HIP-graph replay (the default sampling regime replays one graph per reverse step and sub-batch):
-# with ROCm 7.2's "graph packet capture" the replayed kernel nodes carry ~0.4 us more each on the GPU side -- cfg3's step
-# 1.585 -> 1.570 ms with it off, a 64^2 x 4-patch step 0.818 -> 0.773 ms, no workload slower (DESIGN finding 47); the
-# host then needs 300 us instead of 36 us per replay, still below the step.  Read by the HIP runtime when it
-# initialises, i.e. it only takes effect if this package is imported before the first GPU call of the process; an
-# explicit value in the environment wins.
-_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+def configure_runtime(graph_packet_capture=False):
+    """Opt-in process-level HIP runtime settings for the graph-replay sampling regime.  Call it BEFORE the first GPU
+    call of the process (the HIP runtime reads its environment when it initialises); nothing here happens at import.
+
+    ``graph_packet_capture=False`` sets ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` unless the variable is already set: with
+    ROCm 7.2's captured AQL packets a replayed kernel node carries ~0.4 us more on the GPU side -- cfg3's step 1.585 ->
+    1.570 ms with it off, a 64^2 x 4-patch step 0.818 -> 0.773 ms, no workload slower (DESIGN finding 47); the host
+    then needs ~300 us instead of 36 us per replay, still below the step.  Returns the settings it applied."""
+    applied = {}
+    if not graph_packet_capture and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in _os.environ:
+        _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+        applied["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    return applied
+
 
 from . import rng, schedule, weights  # noqa: F401,E402
 from .weights import UnetConfig  # noqa: F401,E402
 
-__all__ = ["rng", "schedule", "weights", "UnetConfig", "Unet", "GaussianDiffusion"]
+__all__ = ["rng", "schedule", "weights", "UnetConfig", "Unet", "GaussianDiffusion", "configure_runtime"]
 
 
 def __getattr__(name):

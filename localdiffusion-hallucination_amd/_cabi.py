@@ -16,6 +16,7 @@ EPI_PLAIN, EPI_QKV_LINEAR, EPI_QKV_FULL, EPI_RMS_RES, EPI_RES, EPI_GN_TAIL = 0, 
 OBJ = {"pred_x0": 0, "pred_noise": 1, "pred_v": 2}
 SCHED_COLS = 8
 STAT_STRIPES = 16      # LD_STAT_STRIPES
+COUNTER_CONV3X3_C32, COUNTER_CONV3X3_GENERIC = 0, 1
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
@@ -59,6 +60,9 @@ _SIGS = {
     "ld_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "ld_event_destroy": (C.c_int, [vp]),
     "ld_stream_wait_event": (C.c_int, [vp, vp]),
+    "ld_counter": (C.c_longlong, [C.c_int]),
+    "ld_range_push": (C.c_int, [C.c_char_p]),
+    "ld_range_pop": (C.c_int, []),
     "ld_conv3x3": (C.c_int, [C.POINTER(Conv3x3Args), vp]),
     "ld_conv1x1": (C.c_int, [C.POINTER(Conv1x1Args), vp]),
     "ld_pack_conv_weight": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -103,6 +107,8 @@ _SIGS = {
     "ld_fuse_ddpm_k": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_fuse_ddim": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, C.c_int,
                                C.c_int, C.c_int, vp]),
+    "ld_fuse_ddim_k": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, vp]),
     "ld_q_sample": (C.c_int, [vp, vp, vp, f32, f32, i64, vp]),
     "ld_recompose": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_comm_unique_id": (C.c_int, [vp]),
@@ -142,6 +148,19 @@ def check(rc, what=""):
     if rc != 0:
         msg = lib().ld_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"localdiff_hip {what} failed (rc={rc}): {msg}")
+
+
+class prof_range:
+    """``with prof_range("step"):`` -- a roctx range around a phase of the sampler (ld_range_push / ld_range_pop)."""
+
+    def __init__(self, name):
+        self.name = name.encode()
+
+    def __enter__(self):
+        lib().ld_range_push(self.name)
+
+    def __exit__(self, *exc):
+        lib().ld_range_pop()
 
 
 def ptr(t):

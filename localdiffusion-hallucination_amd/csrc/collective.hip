@@ -9,6 +9,7 @@
 // whatever channel the caller has (file, socket, MPI, torch's TCPStore), ld_comm_init everywhere, ld_allgather on the
 // compute stream, ld_comm_destroy.
 #include "common.hip.h"
+#include <mutex>
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,21 +32,20 @@ struct Rccl {
   char why[256] = "";
 };
 
-Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return &r;
-  tried = true;
+void rccl_load(Rccl& r) {
   const char* names[4] = {getenv("LD_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  const char* last_err = nullptr;
   for (int pass = 0; pass < 2 && !r.handle; ++pass)                     // pass 0: a copy the process already mapped
     for (const char* n : names) {
       if (!n || !*n) continue;
       r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (r.handle) break;
+      const char* e = dlerror();                                        // ONE read: dlerror() clears the message
+      if (e && pass == 1) last_err = e;
     }
   if (!r.handle) {
-    snprintf(r.why, sizeof(r.why), "librccl.so.1 not found (%s); set LD_RCCL_PATH", dlerror() ? dlerror() : "dlopen failed");
-    return &r;
+    snprintf(r.why, sizeof(r.why), "librccl.so.1 not found (%s); set LD_RCCL_PATH", last_err ? last_err : "dlopen failed");
+    return;
   }
   r.get_id = (GetUniqueIdFn)dlsym(r.handle, "ncclGetUniqueId");
   r.init = (CommInitRankFn)dlsym(r.handle, "ncclCommInitRank");
@@ -54,8 +54,15 @@ Rccl* rccl() {
   r.errstr = (ErrStrFn)dlsym(r.handle, "ncclGetErrorString");
   if (!r.get_id || !r.init || !r.allgather || !r.destroy) {
     snprintf(r.why, sizeof(r.why), "the loaded librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy");
+    dlclose(r.handle);
     r.handle = nullptr;
   }
+}
+
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;                                           // callable from any host thread
+  std::call_once(once, [] { rccl_load(r); });
   return &r;
 }
 

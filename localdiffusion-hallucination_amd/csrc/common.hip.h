@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // ---------------------------------------------------------------- host-side error plumbing
 int ld_fail(int code, const char* fmt, ...);   // runtime.hip
+void ld_count(int which);                        // runtime.hip: LD_COUNTER_* launch-routing counters
 #define LD_HIP(call)                                                                   \
   do {                                                                                 \
     hipError_t e_ = (call);                                                            \
@@ -48,10 +49,13 @@ bool ld_timing_next(hipEvent_t* start, hipEvent_t* stop);
   } while (0)
 
 // Opt a kernel into > 64 KiB of dynamic LDS once per process.
+// Raise a kernel's dynamic-LDS limit to at least `bytes` on the CURRENT device.  Cached per (kernel, device) under a
+// mutex in runtime.hip, so call sites call it unconditionally before a launch that needs more than 64 KB: a process
+// that drives several devices, or launches from several host threads, gets the attribute on each of them.
+hipError_t ld_allow_lds_ptr(const void* kernel, size_t bytes);
 template <typename K>
 static inline hipError_t ld_allow_lds(K kernel, size_t bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return ld_allow_lds_ptr(reinterpret_cast<const void*>(kernel), bytes);
 }
 
 // ---------------------------------------------------------------- dtype traits

@@ -334,22 +334,14 @@ int launch_epi(const Conv1Dev& a, hipStream_t st) {
   dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
   if (a.group == KG) {
     const size_t lds = KG * chunk + tail;
-    static size_t allowed = 0;
-    if (lds > allowed) {
-      LD_HIP(ld_allow_lds((conv1x1_kernel<T, MT, NW, EPI, KG>), lds));
-      allowed = lds;
-    }
+    if (lds > 65536) LD_HIP(ld_allow_lds((conv1x1_kernel<T, MT, NW, EPI, KG>), lds));   // cached per device
     LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI, KG>), grid, dim3(256), lds, st, a);
     LD_LAUNCH_CHECK("conv1x1(grouped K)");
     return LD_OK;
   }
   if (a.group == 2) {
     const size_t lds = 2 * chunk + tail;
-    static size_t allowed2 = 0;
-    if (lds > allowed2) {
-      LD_HIP(ld_allow_lds((conv1x1_kernel<T, MT, NW, EPI, 2>), lds));
-      allowed2 = lds;
-    }
+    if (lds > 65536) LD_HIP(ld_allow_lds((conv1x1_kernel<T, MT, NW, EPI, 2>), lds));
     LD_LAUNCH((conv1x1_kernel<T, MT, NW, EPI, 2>), grid, dim3(256), lds, st, a);
     LD_LAUNCH_CHECK("conv1x1(grouped K, pairs)");
     return LD_OK;

@@ -424,11 +424,7 @@ int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   constexpr int NPIXP = (HR * HC + 15) / 16 * 16;
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
   const size_t lds = (SK ? 2 : 1) * (4 * NPIXP * 16 + 9 * MT * 1024) + 2 * ctot * sizeof(float) + 4 * 2 * 16 * MT * sizeof(double);
-  static size_t allowed = 0;
-  if (lds > allowed) {
-    LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>, lds));
-    allowed = lds;
-  }
+  if (lds > 65536) LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>, lds));   // cached per device
   Conv3Dev d = a;
   d.tiles_x = (a.W + 15) / 16;
   const int tiles_y = (a.H + TR - 1) / TR;
@@ -486,7 +482,11 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
   if (force_mt == 4 && (a.Cout % 64) == 0) mt4 = true;
   if (force_nw == 2) big = false;
   if (force_nw == 4) big = true;
+#ifdef LD_DEBUG_VARIANTS          // experiment-only (finding 15): exists in a library built with --debug-variants
   static const int force_deep = getenv("LD_CONV_DEEP") ? atoi(getenv("LD_CONV_DEEP")) : -1;
+#else
+  constexpr int force_deep = -1;
+#endif
   const int ck = sizeof(T) == 4 ? 16 : 32;
   const int nch = (a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0)) / ck;
   const long wg = (long)((a.W + 15) / 16) * ((a.H + 7) / 8) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
@@ -505,8 +505,12 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if (sk) return mt4 ? launch_dbg<T, 4, 2, false, 0, true>(a, st) : launch_dbg<T, 2, 2, false, 0, true>(a, st);
   }
-  if (mt4) return big ? launch<T, 4, 4, false>(a, st) : (deep ? launch<T, 4, 2, true>(a, st) : launch<T, 4, 2, false>(a, st));
-  return big ? launch<T, 2, 4, false>(a, st) : (deep ? launch<T, 2, 2, true>(a, st) : launch<T, 2, 2, false>(a, st));
+#ifdef LD_DEBUG_VARIANTS
+  if (deep && !big) return mt4 ? launch<T, 4, 2, true>(a, st) : launch<T, 2, 2, true>(a, st);
+#endif
+  (void)deep;
+  if (mt4) return big ? launch<T, 4, 4, false>(a, st) : launch<T, 4, 2, false>(a, st);
+  return big ? launch<T, 2, 4, false>(a, st) : launch<T, 2, 2, false>(a, st);
 }
 
 }  // namespace
@@ -554,5 +558,6 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
     const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }
+  ld_count(LD_COUNTER_CONV3X3_GENERIC);
   return LD_DISPATCH(p->dtype, dispatch<T>(a, st));
 }

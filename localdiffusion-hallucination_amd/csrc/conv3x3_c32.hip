@@ -386,11 +386,7 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
 
 template <typename T, int NCH, int R, int DBG>
 int launch_c32_dbg(C32Dev& a, size_t lds, dim3 grid, hipStream_t st) {
-  static size_t allowed = 0;
-  if (lds > allowed) {
-    LD_HIP(ld_allow_lds(conv3x3_c32_kernel<T, NCH, R, DBG>, lds));
-    allowed = lds;
-  }
+  if (lds > 65536) LD_HIP(ld_allow_lds(conv3x3_c32_kernel<T, NCH, R, DBG>, lds));   // cached per device
   LD_LAUNCH((conv3x3_c32_kernel<T, NCH, R, DBG>), grid, dim3(512), lds, st, a);
   LD_LAUNCH_CHECK("conv3x3_c32");
   return LD_OK;
@@ -466,6 +462,7 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   else if (ring == 3) rc = launch_c32<bf16, 1, 3>(a, st);
 #endif
   else rc = launch_c32<bf16, 1, 6>(a, st);
+  if (rc == LD_OK) ld_count(LD_COUNTER_CONV3X3_C32);
   return rc == LD_OK ? 1 : rc;
 }
 

@@ -559,10 +559,13 @@ template <typename T>
 int kvctx_launch(const KvCtxArgs& a, int B, hipStream_t st) {
   const int nch = a.C / 32, heads = a.heads, nchunks = a.nchunks;
   const float* kshift = a.kshift;
+#ifdef LD_DEBUG_VARIANTS          // experiment-only: the first (workgroup-per-head) schedule, for reproducing DESIGN section 5
   static const int no_wph = getenv("LD_KVCTX_V1") ? 1 : 0;
+#else
+  constexpr int no_wph = 0;
+#endif
   if (heads == 4 && (!no_wph || kshift)) {               // wave-per-head schedule
     const size_t lds2 = (size_t)nch * 4 * KTN * 16 + KTN * sizeof(float) + 4 * 2 * SROW * PROW;
-    static bool ok4 = false;
     dim3 grid2(nchunks, B);
     if (nch == 1) {
       if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 1, true>), grid2, dim3(256), lds2, st, a);
@@ -571,11 +574,8 @@ int kvctx_launch(const KvCtxArgs& a, int B, hipStream_t st) {
       if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 2, true>), grid2, dim3(256), lds2, st, a);
       else LD_LAUNCH((kvctx_wph_kernel<T, 2, false>), grid2, dim3(256), lds2, st, a);
     } else {
-      if (!ok4) {
-        LD_HIP(ld_allow_lds((kvctx_wph_kernel<T, 4, true>), lds2));
-        LD_HIP(ld_allow_lds((kvctx_wph_kernel<T, 4, false>), lds2));
-        ok4 = true;
-      }
+      if (kshift) LD_HIP(ld_allow_lds((kvctx_wph_kernel<T, 4, true>), lds2));      // cached per device
+      else LD_HIP(ld_allow_lds((kvctx_wph_kernel<T, 4, false>), lds2));
       if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 4, true>), grid2, dim3(256), lds2, st, a);
       else LD_LAUNCH((kvctx_wph_kernel<T, 4, false>), grid2, dim3(256), lds2, st, a);
     }
@@ -584,14 +584,13 @@ int kvctx_launch(const KvCtxArgs& a, int B, hipStream_t st) {
   }
   dim3 grid(nchunks, heads, B);
   const size_t lds = (size_t)nch * 4 * KTN * 16 + 2 * KTN * PROW + KTN * sizeof(float) + 128 * sizeof(float);
-  static bool allowed[5] = {false, false, false, false, false};
   if (nch == 1) {
     LD_LAUNCH((kvctx_kernel<T, 1>), grid, dim3(256), lds, st, a);
   } else if (nch == 2) {
-    if (!allowed[2]) { LD_HIP(ld_allow_lds((kvctx_kernel<T, 2>), lds)); allowed[2] = true; }
+    LD_HIP(ld_allow_lds((kvctx_kernel<T, 2>), lds));
     LD_LAUNCH((kvctx_kernel<T, 2>), grid, dim3(256), lds, st, a);
   } else {
-    if (!allowed[4]) { LD_HIP(ld_allow_lds((kvctx_kernel<T, 4>), lds)); allowed[4] = true; }
+    LD_HIP(ld_allow_lds((kvctx_kernel<T, 4>), lds));
     LD_LAUNCH((kvctx_kernel<T, 4>), grid, dim3(256), lds, st, a);
   }
   LD_LAUNCH_CHECK("linattn_kvctx");
@@ -603,13 +602,12 @@ int linout_launch(const LinOutArgs& a, int B, hipStream_t st) {
   const int n = a.n, nch = a.C / 32;
   dim3 grid((n + 128 * LINOUT_TPB - 1) / (128 * LINOUT_TPB), B);
   const size_t lds = (size_t)nch * 4 * 128 * 16 + (size_t)nch * 8 * 1024 + (size_t)4 * 2 * nch * 1024 + 128 * sizeof(float);
-  static bool allowed4 = false;
   if (nch == 1) {
     LD_LAUNCH((linout_kernel<T, 1>), grid, dim3(256), lds, st, a);
   } else if (nch == 2) {
     LD_LAUNCH((linout_kernel<T, 2>), grid, dim3(256), lds, st, a);
   } else {
-    if (!allowed4) { LD_HIP(ld_allow_lds((linout_kernel<T, 4>), lds)); allowed4 = true; }
+    LD_HIP(ld_allow_lds((linout_kernel<T, 4>), lds));
     LD_LAUNCH((linout_kernel<T, 4>), grid, dim3(256), lds, st, a);
   }
   LD_LAUNCH_CHECK("linattn_out");

@@ -189,6 +189,29 @@ __global__ void fuse_ddim_kernel(const float* xo, const float* xi, const float* 
     xn[i] = x0 * k.san + k.c * eps + k.sigma * (z ? z[i] : 0.f);
   }
 }
+// K-branch DDIM fusion (ddpm.py:1022-1041 read per branch; K = 2 with m_1 = 1 - (m_0 >= 1) is fuse_ddim_kernel bit for bit)
+__global__ void fuse_ddim_k_kernel(const float* x_first, const float* x_rest, const float* x0_first, const float* x0_rest,
+                                   const float* masks, const float* z, float* xn, FuseDdimK k, int C, int K, int HW, long n) {
+  GRID_STRIDE(i, n) {
+    const long bc = i / HW, p = i - bc * HW, b = bc / C;
+    const float* mrow = masks + (size_t)b * K * HW + p;
+    const float a0 = clampf(x0_first[i], k.lo, k.hi);
+    const float e0 = (k.sr * x_first[i] - a0) / k.srm1;
+    float eps = e0 * (mrow[0] >= 1.0f ? 1.0f : 0.0f);
+    // x0 of the IND branch that owns the pixel: the first k >= 1 with m_k >= 1, the last branch if none does
+    float alt = 0.f;
+    bool have = false;
+    for (int kk = 1; kk < K; ++kk) {
+      const float m = mrow[(size_t)kk * HW] >= 1.0f ? 1.0f : 0.0f;
+      const float ak = clampf(x0_rest[(size_t)(kk - 1) * n + i], k.lo, k.hi);
+      const float ek = (k.sr * x_rest[(size_t)(kk - 1) * n + i] - ak) / k.srm1;
+      if (!have && (m == 1.0f || kk == K - 1)) { alt = ak; have = true; }
+      if (eps == 0.0f) eps = ek * m;
+    }
+    const float x0 = clampf((a0 == 0.0f) ? alt : a0, k.lo, k.hi);
+    xn[i] = x0 * k.san + k.c * eps + k.sigma * (z ? z[i] : 0.f);
+  }
+}
 __global__ void q_sample_kernel(const float* x0, const float* z, float* out, float sab, float s1mab, long n) {
   GRID_STRIDE(i, n) out[i] = sab * x0[i] + s1mab * z[i];
 }
@@ -414,6 +437,18 @@ extern "C" int ld_fuse_ddim(const float* x_out, const float* x_in, const float* 
   FuseDdimK k{sqrt_recip, sqrt_recipm1, sqrt_abar_next, c, sigma, lo, hi};
   LD_LAUNCH(fuse_ddim_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_out, x_in, x0_out, x0_in, mask, noise, x_next, k, C, HW, n);
   LD_LAUNCH_CHECK("fuse_ddim");
+  return LD_OK;
+}
+extern "C" int ld_fuse_ddim_k(const float* x_first, const float* x_rest, const float* x0_first, const float* x0_rest,
+                              const float* masks, const float* noise, float* x_next, float sqrt_recip, float sqrt_recipm1,
+                              float sqrt_abar_next, float c, float sigma, float lo, float hi, int B, int C, int K, int HW,
+                              void* stream) {
+  LD_REQUIRE(x_first && x_rest && x0_first && x0_rest && masks && x_next && K >= 2, "ld_fuse_ddim_k: bad args (K >= 2)");
+  const long n = (long)B * C * HW;
+  FuseDdimK k{sqrt_recip, sqrt_recipm1, sqrt_abar_next, c, sigma, lo, hi};
+  LD_LAUNCH(fuse_ddim_k_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x_first, x_rest, x0_first, x0_rest, masks, noise,
+            x_next, k, C, K, HW, n);
+  LD_LAUNCH_CHECK("fuse_ddim_k");
   return LD_OK;
 }
 extern "C" int ld_q_sample(const float* x0, const float* noise, float* out, float sqrt_ab, float sqrt_1mab,

@@ -7,8 +7,10 @@ their names (:567-615, so ``state_dict`` round-trips), ``sample`` (:1078), ``p_s
 attributes ``is_ddim_sampling / image_size / channels / num_timesteps``.
 
 Changed in form (results identical, see tests/): the reference flips entries of ``self.config``
-while sampling (:780-781, :1023-1024, :1093-1117); here ``config`` is only read, and the phase
-BRANCH -> (FUSE) -> JOINT is explicit.  No tensor leaves the GPU inside the loop (the reference
+while sampling (:780-781, :1023-1024, :1093-1117); here ``config`` is only read, the phase
+BRANCH -> (FUSE) -> JOINT is explicit, and the one flag whose flipped value survives into the next
+``sample()`` call (``mask_x``) is carried on the object (``_mask_x_get/_mask_x_set``, golden G14).
+No tensor leaves the GPU inside the loop (the reference
 ping-pongs ``.cpu()``/``.to(device)`` every step, :700-708, :865-869), the conditioning encoder
 runs once per phase instead of once per step (its input is constant over t, :434), both branches
 are evaluated as ONE batched denoiser call, and the dead OOD-branch evaluation for non-MRI data
@@ -43,11 +45,10 @@ def _align_streams(streams):
                 gs.wait_event(ev)
 
 
-def _masked_stream(i):
-    """Experiment (DESIGN finding 40): a side stream restricted to a subset of the CUs, LD_SUB_CU_MASK =
+def _masked_stream(i, kind):
+    """A side stream restricted to a subset of the CUs (``GaussianDiffusion.sub_cu_mask``; DESIGN finding 40):
     ``lo`` (mask bits [128 i, 128 i + 128)), ``xcd`` (bits with (bit mod 8) div 4 == i: the KFD stripes mask bits over
-    the XCDs, so this is four whole XCDs per stream) or ``even`` (bit mod 2 == i).  Unset: an ordinary stream."""
-    kind = os.environ.get("LD_SUB_CU_MASK", "")
+    the XCDs, so this is four whole XCDs per stream) or ``even`` (bit mod 2 == i).  None: an ordinary stream."""
     if not kind:
         return None
     import ctypes as C
@@ -170,6 +171,7 @@ class _SubBatches:
         # taken, persists: line the streams up when they start (their encoders were enqueued one after the other) and
         # again every LD_SUB_RESYNC steps (default 32; 0: never).
         h0 = time.perf_counter()
+        lib.ld_range_push(b"steps (graph replay, %d sub-batches)" % self.S)
         for k in range(max(todo)):
             # (and in front of step 1: the host enqueues the streams' first replays one after the other, 0.3 ms apart, so
             # the alignment in front of step 0 finds empty queues and aligns nothing)
@@ -178,6 +180,7 @@ class _SubBatches:
             for i, gs in enumerate(self.streams):
                 if k < todo[i]:
                     cabi.check(lib.ld_graph_launch(ex[i], gs.cuda_stream), "graph_launch")
+        lib.ld_range_pop()
         # host seconds spent enqueueing replays (includes back-pressure once the hardware queue is full)
         self.host_launch_s = getattr(self, "host_launch_s", 0.0) + time.perf_counter() - h0
         self.host_launch_n = getattr(self, "host_launch_n", 0) + sum(todo)
@@ -345,6 +348,16 @@ class GaussianDiffusion(nn.Module):
         self.classifier_flag = 0
         self.pred_cls = 0.0
         self.classifier_calls = 0
+        # config['mask_x'] as the reference carries it from one sample() call to the next (it mutates its config dict;
+        # here the dict is only read and the carried value lives on the object): cleared by the fusion step
+        # (ddpm.py:780-781, 1023-1024) and by the all-ones fallback (:1114), set by a classifier rejection (:907-908),
+        # re-armed by sample() only under ood_AD / ood_confidence (:1106-1108).  So with {mask_x: True, ood_AD: False}
+        # the reference's SECOND sample() on one object leaves the OOD prediction unmasked -- reproduced (golden G14).
+        # ``first_call_semantics = True`` opts out: every call then behaves like the first one on a fresh object.
+        self.first_call_semantics = False
+        self._mask_x_carried = None               # None: the sampler has not written the flag yet
+        self._mask_x_cfg_seen = None
+        self._all_ones_forced = None              # dist.py: the all-ones decision of the GLOBAL batch for a shard's call
         # build-specific knobs (additive; defaults reproduce the reference's behaviour)
         self.noise_source = "device"
         self.fuse_final_step = os.environ.get("LD_NO_FUSED_FINAL") is None
@@ -357,6 +370,7 @@ class GaussianDiffusion(nn.Module):
         # concurrent sub-batches of the joint steps (see _SubBatches); 1 = one batch on the caller's stream
         self.sub_batches = int(os.environ.get("LD_SUB_BATCHES", "2"))
         self.min_sub_batch = int(os.environ.get("LD_MIN_SUB_BATCH", "2"))
+        self.sub_cu_mask = None                   # experiments: "xcd" / "lo" / "even" CU-masked sub-batch streams (set before sampling)
         self._sched = None
         self._graphs = {}
         self._subs = {}
@@ -402,17 +416,54 @@ class GaussianDiffusion(nn.Module):
             raise ValueError(f"noise_source {src!r}")
 
     # ------------------------------------------------------------------ flags
+    def _mask_x_get(self):
+        """config['mask_x'] as the reference would hold it now (see __init__).  A caller who edits the dict between
+        calls wins over the carried value, as in the reference."""
+        cfgv = bool(self.config.get("mask_x", False))
+        if self.first_call_semantics or self._mask_x_carried is None or cfgv != self._mask_x_cfg_seen:
+            self._mask_x_carried = None
+            return cfgv
+        return self._mask_x_carried
+
+    def _mask_x_set(self, v):
+        if not self.first_call_semantics:
+            self._mask_x_carried = bool(v)
+            self._mask_x_cfg_seen = bool(self.config.get("mask_x", False))
+
+    def reset_call_state(self):
+        """Forget what earlier sample() calls left behind (mask_x carry-over, classifier_flag): the object behaves like
+        a freshly constructed one again."""
+        self._mask_x_carried, self._mask_x_cfg_seen = None, None
+        self.classifier_flag = 0
+
+    def _all_ones(self, mask):
+        """ddpm.py:1110-1112 (one device sync per call, as there)."""
+        if self._all_ones_forced is not None:
+            return self._all_ones_forced
+        if mask is None or mask.shape[1] != 1:
+            return False
+        u = torch.unique(mask)
+        return len(u) == 1 and float(u[0]) == 1.0
+
     def _flags(self, mask):
-        """Effective (branch, fuse, mask_x) of this call: ddpm.py:1093-1117 without the mutation."""
+        """Effective (branch, fuse, mask_x) of this call: ddpm.py:1093-1117 without mutating the dict."""
         c = self.config
         branch = bool(c["branch_out"]) or self.branch_out
         fuse = bool(c["start_intermediate"]) or self.start_intermediate
-        mask_x = bool(c.get("mask_x", False)) or bool(c.get("ood_AD", False)) or bool(c.get("ood_confidence", False))
-        if branch and mask is not None and mask.shape[1] == 1:
-            u = torch.unique(mask)
-            if len(u) == 1 and float(u[0]) == 1.0:        # "Original reverse process as AD is low"
-                branch, fuse, mask_x = False, False, False
+        mask_x = self._mask_x_get() or bool(c.get("ood_AD", False)) or bool(c.get("ood_confidence", False))
+        if branch and self._all_ones(mask):               # "Original reverse process as AD is low"
+            branch, fuse, mask_x = False, False, False
         return branch, fuse, mask_x
+
+    def result_layout(self, mask):
+        """What sample() returns for this mask: "plain" [B,C,H,W]; "stacked" [2,B,C,H,W] (DDPM, branches never fused,
+        ddpm.py:964-970 -- also when the all-ones fallback ran a single branch); "list" of two [B,C,H,W] (DDIM that
+        never fused, :1069-1075).  dist.py derives the gather layout from it on every rank, idle ones included."""
+        branch, fuse, _ = self._flags(mask)
+        if self.is_ddim_sampling:
+            return "list" if (branch and not fuse) else "plain"
+        start_int = bool(self.config["start_intermediate"]) or self.start_intermediate
+        return "stacked" if ((not start_int) and self.branch_out) else "plain"
 
     def _replaced_out(self, mask_x):
         d = self.config["data"]
@@ -426,11 +477,25 @@ class GaussianDiffusion(nn.Module):
         self.cnt += 1
         self.min_max_val = min_max_val
         self.hr = gt
-        shape = (batch_size, self.channels, self.image_size, self.image_size)
-        if self.is_ddim_sampling:
-            return self.ddim_sample(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps)
-        return self.p_sample_loop(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps,
-                                  return_all_outputs=return_all_outputs)
+        # the per-call flag handling of ddpm.py:1106-1117 that outlives the call
+        c = self.config
+        if bool(c.get("ood_AD", False)) or bool(c.get("ood_confidence", False)):
+            self._mask_x_set(True)
+        branch_cfg = bool(c["branch_out"]) or self.branch_out
+        decided_here = branch_cfg and self._all_ones_forced is None
+        if decided_here:                                   # one torch.unique (device sync) per call, reused by the loop
+            self._all_ones_forced = self._all_ones(mask)
+        try:
+            if branch_cfg and self._all_ones_forced:
+                self._mask_x_set(False)                    # ddpm.py:1114
+            shape = (batch_size, self.channels, self.image_size, self.image_size)
+            if self.is_ddim_sampling:
+                return self.ddim_sample(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps)
+            return self.p_sample_loop(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps,
+                                      return_all_outputs=return_all_outputs)
+        finally:
+            if decided_here:
+                self._all_ones_forced = None
 
     @torch.inference_mode()
     def p_sample(self, x, mask, min_max_val, cond_img, t: int, x_self_cond=None, draw=None):
@@ -482,7 +547,7 @@ class GaussianDiffusion(nn.Module):
         if not hasattr(self, "_side_streams"):
             self._side_streams = []
         while len(self._side_streams) < S:
-            self._side_streams.append(_masked_stream(len(self._side_streams)) or torch.cuda.Stream())
+            self._side_streams.append(_masked_stream(len(self._side_streams), self.sub_cu_mask) or torch.cuda.Stream())
         return self._side_streams[:S]
 
     def timed_plan(self, jp):
@@ -648,10 +713,12 @@ class GaussianDiffusion(nn.Module):
             start_t = t0 - 1
         z = torch.empty(shape, dtype=torch.float32, device=dev)
         if branch and mask is not None and mask.shape[1] > 1:        # K-mask generalisation
-            if return_all_timesteps or return_all_outputs or (bool(self.config.get("classifier", False)) and fuse):
-                raise NotImplementedError("K-mask branching: history returns and the classifier gate exist for the "
-                                          "reference's two-branch form only")
-            return self._p_sample_loop_kmask(cond, mask, lo, hi, shape, x_T, z, start_t, fuse, mask_x)
+            if return_all_timesteps:
+                # as for two branches: ddpm.py:963 stacks `imgs`, which holds per-branch lists for every branch step
+                raise TypeError("return_all_timesteps is only defined for the single-branch reverse process "
+                                "(the reference's torch.stack(imgs) fails on the per-branch lists, ddpm.py:865,963)")
+            return self._p_sample_loop_kmask(cond, mask, lo, hi, shape, x_T, z, start_t, fuse, mask_x,
+                                             return_all_outputs=return_all_outputs)
         x0_buf = torch.empty(shape, dtype=torch.float32, device=dev) if return_all_outputs else None
         if return_all_timesteps and branch:
             # ddpm.py:963 stacks `imgs`, which holds [x_out, x_in] lists for every branch step (:865): torch.stack
@@ -725,6 +792,7 @@ class GaussianDiffusion(nn.Module):
                     cabi.check(lib.ld_fuse_ddpm(x_out_view.data_ptr(), x_in_view.data_ptr(), mo_out.data_ptr(),
                                                 mo_in.data_ptr(), mask.data_ptr(), jp.x_in.data_ptr(),
                                                 x0f.data_ptr(), lo, hi, B, C, HW, st), "fuse_ddpm")
+                    self._mask_x_set(False)                # ddpm.py:781
                     jp.set_step(t)
                     cabi.check(lib.ld_posterior_step(jp.x_in.data_ptr(), x0f.data_ptr(), z.data_ptr(),
                                                      jp.x_in.data_ptr(), sched.data_ptr(), jp.t_dev.data_ptr(), n, st),
@@ -779,21 +847,12 @@ class GaussianDiffusion(nn.Module):
             return ret, hist_x0, []
         return ret
 
-    def _p_sample_loop_kmask(self, cond, masks, lo, hi, shape, x_T, z, start_t, fuse, mask_x):
-        """Branch -> fusion -> joint with K >= 2 masks [B,K,H,W] (SURVEY 8f-3; the reference's loop, ddpm.py:672-708,
-        769-810, 852-858, has K = 2).  Branch 0 is the OOD-style branch (hard-masked conditioning; with mask_x its
-        prediction is replaced by the range minimum outside m_0, or by its conditioning for the datasets of :704-708),
-        branches 1..K-1 are IND-style (conditioning floored at 0.95 / 0.5).  All branches share each step's draw; at
-        t <= start_timestep they are recomposed (x0 = clamp(sum_k x0_k m_k), x_t = first non-zero of x_t,k m_k) and the
-        remaining steps run on the fused image.  Without fusion the K branch states come back as [K,B,C,H,W].
-        oracle/diffusion_ref.py::p_sample_loop_kmask is the restatement; for K = 2 and m_1 = 1 - (m_0 >= 1) both are
-        bitwise the two-branch path."""
+    def _kmask_setup(self, cond, masks, lo, shape, mask_x):
+        """Conditioning, plan and state / prediction views of a K-branch run (shared by the DDPM and the DDIM loop)."""
         lib, st, dev = cabi.lib(), self._st(), self.device
         B, C, H, W = shape
-        K, HW, n = masks.shape[1], H * W, B * C * H * W
+        K, HW = masks.shape[1], H * W
         assert self.objective == "pred_x0", "branch mode exists only for pred_x0 (ddpm.py:739-749)"
-        sched, obj = self._sched_table(), cabi.OBJ[self.objective]
-        masks = masks.to(dev, torch.float32).contiguous()
         m0 = masks[:, 0:1].contiguous()
         if mask_x:
             assert len(torch.unique((m0 >= 1.0).float())) == 2, "mask should be binary"   # ddpm.py:698
@@ -810,10 +869,34 @@ class GaussianDiffusion(nn.Module):
         x_rest = plan.x_in if replaced else plan.x_in[B:]
         mo_first = cond_k[0] if replaced else plan.model_out[:B]
         mo_rest = plan.model_out if replaced else plan.model_out[B:]
+        return plan, m0, cond_k, replaced, x_first, x_rest, mo_first, mo_rest
+
+    def _p_sample_loop_kmask(self, cond, masks, lo, hi, shape, x_T, z, start_t, fuse, mask_x, return_all_outputs=False):
+        """Branch -> fusion -> joint with K >= 2 masks [B,K,H,W] (SURVEY 8f-3; the reference's loop, ddpm.py:672-708,
+        769-810, 852-858, has K = 2).  Branch 0 is the OOD-style branch (hard-masked conditioning; with mask_x its
+        prediction is replaced by the range minimum outside m_0, or by its conditioning for the datasets of :704-708),
+        branches 1..K-1 are IND-style (conditioning floored at 0.95 / 0.5).  All branches share each step's draw; at
+        t <= start_timestep they are recomposed (x0 = clamp(sum_k x0_k m_k), x_t = first non-zero of x_t,k m_k) and the
+        remaining steps run on the fused image.  Without fusion the K branch states come back as [K,B,C,H,W].
+        ``return_all_outputs``: (ret, x_start_lst, []) -- a K-list of x0 per branch step (ddpm.py:869), the fused /
+        single x0 otherwise (:879, 922).  config['classifier']: the joint steps run under the gate of fusion()
+        (:883-916) with a K-branch redo.  oracle/diffusion_ref.py::p_sample_loop_kmask is the restatement; for K = 2 and
+        m_1 = 1 - (m_0 >= 1) both are bitwise the two-branch path."""
+        lib, st, dev = cabi.lib(), self._st(), self.device
+        B, C, H, W = shape
+        K, HW, n = masks.shape[1], H * W, B * C * H * W
+        sched, obj = self._sched_table(), cabi.OBJ[self.objective]
+        masks = masks.to(dev, torch.float32).contiguous()
+        plan, m0, cond_k, replaced, x_first, x_rest, mo_first, mo_rest = self._kmask_setup(cond, masks, lo, shape, mask_x)
         x_first.copy_(x_T)
         x_rest.copy_(x_T.repeat(K - 1, 1, 1, 1))
+        gate = bool(self.config.get("classifier", False)) and fuse
+        if gate:
+            self.call_classifier()
+        hist_x0 = []
+        x0_k = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(K)] if return_all_outputs else None
         t, draw = start_t, 1
-        fused = False
+        fused, kept = False, None
         while t >= 0:
             plan.set_step(t)
             plan.run_main(st)
@@ -825,25 +908,172 @@ class GaussianDiffusion(nn.Module):
             if fuse and t <= int(self.config["start_timestep"]):
                 jp = self.model.plan(B, H, W, table_T=self.num_timesteps_ori)
                 x0f = torch.empty(shape, dtype=torch.float32, device=dev)
+                if gate:                                       # self.x_branchout (ddpm.py:799), one state per branch
+                    bm = (masks >= 1.0).float()
+                    kept = [x_first * bm[:, 0:1]] + [x_rest[(k - 1) * B:k * B] * bm[:, k:k + 1] for k in range(1, K)]
                 cabi.check(lib.ld_fuse_ddpm_k(x_first.data_ptr(), x_rest.data_ptr(), mo_first.data_ptr(), mo_rest.data_ptr(),
                                               masks.data_ptr(), jp.x_in.data_ptr(), x0f.data_ptr(), lo, hi, B, C, K, HW, st),
                            "fuse_ddpm_k")
+                self._mask_x_set(False)                    # ddpm.py:781
                 jp.set_step(t)
                 cabi.check(lib.ld_posterior_step(jp.x_in.data_ptr(), x0f.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(),
                                                  sched.data_ptr(), jp.t_dev.data_ptr(), n, st), "posterior_step")
+                if return_all_outputs:
+                    hist_x0.append(x0f.cpu())
                 t -= 1
                 fused = True
                 break
             views = [(x_first, mo_first)] + [(x_rest[(k - 1) * B:k * B], mo_rest[(k - 1) * B:k * B]) for k in range(1, K)]
-            for xv, mv in views:                               # one shared draw for every branch (ddpm.py:852-858)
-                cabi.check(lib.ld_ddpm_step(xv.data_ptr(), mv.data_ptr(), z.data_ptr(), xv.data_ptr(), None,
+            for k, (xv, mv) in enumerate(views):               # one shared draw for every branch (ddpm.py:852-858)
+                cabi.check(lib.ld_ddpm_step(xv.data_ptr(), mv.data_ptr(), z.data_ptr(), xv.data_ptr(),
+                                            cabi.ptr(x0_k[k]) if x0_k else None,
                                             sched.data_ptr(), plan.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+            if return_all_outputs:                             # branching_out(), ddpm.py:869
+                hist_x0.append([b.cpu() for b in x0_k])
             t -= 1
         if not fused:
-            return torch.cat([x_first.reshape(1, *shape), x_rest.reshape(K - 1, *shape)], 0).clone()
+            ret = torch.cat([x_first.reshape(1, *shape), x_rest.reshape(K - 1, *shape)], 0).clone()
+            return (ret, hist_x0, []) if return_all_outputs else ret
         jp.cond_in.copy_(cond)
         jp.run_cond(st)
-        self.run_joint_steps(jp, t, t + 1, lo, hi, z, draw)
+        x0_buf = torch.empty(shape, dtype=torch.float32, device=dev) if (return_all_outputs or gate) else None
+        after = (lambda _t: hist_x0.append(x0_buf.cpu())) if return_all_outputs else None
+        if gate:
+            self._gated_joint_steps_k(jp, t, lo, hi, z, draw, x0_buf, kept, cond, cond_k, masks, m0, after)
+        else:
+            self.run_joint_steps(jp, t, t + 1, lo, hi, z, draw, x0_buf=x0_buf, after=after)
+        ret = jp.x_in.clone()
+        return (ret, hist_x0, []) if return_all_outputs else ret
+
+    def _gated_joint_steps_k(self, jp, t, lo, hi, z, draw, x0_buf, kept, cond, cond_k, masks, m0, after):
+        """``_gated_joint_steps`` for K branches: a rejected joint step (score <= 0, t > 0) is replaced by a K-branch
+        evaluation + fusion at the same t from the masked branch states ``kept`` (one per branch, ddpm.py:799), with
+        mask_x forced on (:906-908)."""
+        lib, st = cabi.lib(), self._st()
+        sched, obj = self._sched_table(), cabi.OBJ[self.objective]
+        B, C, H, W = jp.x_in.shape
+        K, HW, n = masks.shape[1], H * W, jp.x_in.numel()
+        bp = None
+        while t >= 0:
+            jp.set_step(t)
+            jp.run_main(st)
+            if t > 0:
+                self._noise(z, draw)
+                draw += 1
+            cabi.check(lib.ld_ddpm_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(),
+                                        x0_buf.data_ptr(), sched.data_ptr(), jp.t_dev.data_ptr(), lo, hi, obj, n, st), "ddpm_step")
+            if self.classifier_flag == 0:
+                self.pred_cls = float(self.classifier(x0_buf)[0])
+                self.classifier_calls += 1
+            if self.pred_cls > 0.0 or t == 0:
+                self.classifier_flag = 1
+            else:
+                replaced = self._replaced_out(True)
+                nb = (K - 1) * B if replaced else K * B
+                if bp is None:
+                    bp = self.model.plan(nb, H, W, table_T=self.num_timesteps_ori)
+                bp.cond_in.copy_((cond_k[1:] if replaced else cond_k).reshape(nb, *cond.shape[1:]))
+                bp.run_cond(st)
+                x_first = kept[0] if replaced else bp.x_in[:B]
+                x_rest = bp.x_in if replaced else bp.x_in[B:]
+                if not replaced:
+                    x_first.copy_(kept[0])
+                for k in range(1, K):
+                    x_rest[(k - 1) * B:k * B].copy_(kept[k])
+                mo_first = cond_k[0] if replaced else bp.model_out[:B]
+                mo_rest = bp.model_out if replaced else bp.model_out[B:]
+                bp.set_step(t)
+                bp.run_main(st)
+                if not replaced:
+                    cabi.check(lib.ld_mask_out(mo_first.data_ptr(), m0.data_ptr(), lo, B, C, HW, st), "mask_out")
+                self._noise(z, draw)                        # t > 0 here
+                draw += 1
+                cabi.check(lib.ld_fuse_ddpm_k(x_first.data_ptr(), x_rest.data_ptr(), mo_first.data_ptr(), mo_rest.data_ptr(),
+                                              masks.data_ptr(), jp.x_in.data_ptr(), x0_buf.data_ptr(), lo, hi, B, C, K, HW, st),
+                           "fuse_ddpm_k")
+                self._mask_x_set(False)
+                if bp is jp:                                # plans are cached per batch size: restore the joint one
+                    jp.cond_in.copy_(cond)
+                    jp.run_cond(st)
+                jp.set_step(t)
+                cabi.check(lib.ld_posterior_step(jp.x_in.data_ptr(), x0_buf.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(),
+                                                 sched.data_ptr(), jp.t_dev.data_ptr(), n, st), "posterior_step")
+            if after is not None:
+                after(t)
+            t -= 1
+        return draw
+
+    def _ddim_sample_kmask(self, cond, masks, lo, hi, shape, x_T, fuse, mask_x):
+        """ddim_sample with K >= 2 masks [B,K,H,W]: every pair evaluates the K branches as one batch (clip_x_start,
+        one shared draw, ddpm.py:1005-1020), the fusion pair (t <= times[-start_timestep-2]) recomposes them with
+        ld_fuse_ddim_k, the remaining pairs run on the fused image; never fused -> a list of the K branch states.
+        oracle/diffusion_ref.py::ddim_sample_kmask is the restatement (K = 2 is the reference's path bit for bit)."""
+        lib, st, dev = cabi.lib(), self._st(), self.device
+        B, C, H, W = shape
+        K, HW, n = masks.shape[1], H * W, B * C * H * W
+        T, S, eta = self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        obj = cabi.OBJ[self.objective]
+        masks = masks.to(dev, torch.float32).contiguous()
+        times, pairs = schedule.ddim_time_pairs(T, S)
+        t_fuse = times[-int(self.config["start_timestep"]) - 2]                 # ddpm.py:987
+        abar, sr_all, srm1_all = self.alphas_cumprod, self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod
+        sab_all, s1m_all = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+
+        def scalars(t, t_next):
+            a, an = abar[t], abar[t_next]
+            sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()             # ddpm.py:1017-1018
+            return float(an.sqrt()), float((1 - an - sigma ** 2).sqrt()), float(sigma)
+
+        def step(xv, mv, t, t_next, zz):
+            last = 1 if t_next < 0 else 0
+            san, c, sigma = (0.0, 0.0, 0.0) if last else scalars(t, t_next)
+            cabi.check(lib.ld_ddim_step(xv.data_ptr(), mv.data_ptr(), cabi.ptr(zz), xv.data_ptr(), float(sr_all[t]),
+                                        float(srm1_all[t]), float(sab_all[t]), float(s1m_all[t]), san, c, sigma, lo, hi, obj,
+                                        last, xv.numel(), st), "ddim_step")
+        plan, m0, cond_k, replaced, x_first, x_rest, mo_first, mo_rest = self._kmask_setup(cond, masks, lo, shape, mask_x)
+        x_first.copy_(x_T)
+        x_rest.copy_(x_T.repeat(K - 1, 1, 1, 1))
+        z = torch.zeros(shape, dtype=torch.float32, device=dev)
+        draw, idx, jp = 1, 0, None
+        while idx < len(pairs):
+            t, t_next = pairs[idx]
+            plan.set_step(t)
+            plan.run_main(st)
+            if mask_x and not replaced:
+                cabi.check(lib.ld_mask_out(mo_first.data_ptr(), m0.data_ptr(), lo, B, C, HW, st), "mask_out")
+            views = [(x_first, mo_first)] + [(x_rest[(k - 1) * B:k * B], mo_rest[(k - 1) * B:k * B]) for k in range(1, K)]
+            if t_next < 0:
+                for xv, mv in views:
+                    step(xv, mv, t, t_next, None)
+                idx += 1
+                continue
+            self._noise(z, draw)
+            draw += 1
+            if fuse and t <= t_fuse:
+                jp = self.model.plan(B, H, W, table_T=self.num_timesteps_ori)
+                san, c, sigma = scalars(t, t_next)
+                cabi.check(lib.ld_fuse_ddim_k(x_first.data_ptr(), x_rest.data_ptr(), mo_first.data_ptr(), mo_rest.data_ptr(),
+                                              masks.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(), float(sr_all[t]),
+                                              float(srm1_all[t]), san, c, sigma, lo, hi, B, C, K, HW, st), "fuse_ddim_k")
+                self._mask_x_set(False)                    # ddpm.py:1024
+                idx += 1
+                break
+            for xv, mv in views:
+                step(xv, mv, t, t_next, z)
+            idx += 1
+        if jp is None:
+            return [x_first.clone()] + [x_rest[(k - 1) * B:k * B].clone() for k in range(1, K)]
+        jp.cond_in.copy_(cond)
+        jp.run_cond(st)
+        while idx < len(pairs):
+            t, t_next = pairs[idx]
+            jp.set_step(t)
+            jp.run_main(st)
+            if t_next >= 0:
+                self._noise(z, draw)
+                draw += 1
+            step(jp.x_in, jp.model_out, t, t_next, z if t_next >= 0 else None)
+            idx += 1
         return jp.x_in.clone()
 
     def _gated_joint_steps(self, jp, t, lo, hi, z, draw, x0_buf, x_branchout, cond, cond_out, cond_in, mask,
@@ -901,6 +1131,7 @@ class GaussianDiffusion(nn.Module):
                 cabi.check(lib.ld_fuse_ddpm(x_out_view.data_ptr(), x_in_view.data_ptr(), mo_out.data_ptr(),
                                             mo_in.data_ptr(), mask.data_ptr(), jp.x_in.data_ptr(),
                                             x0_buf.data_ptr(), lo, hi, B, C, HW, st), "fuse_ddpm")
+                self._mask_x_set(False)                     # :908 set it, the redo's fusion step (:781) clears it again
                 if bp is jp:                                # plans are cached per batch size: restore the joint one
                     jp.cond_in.copy_(cond)
                     jp.run_cond(st)
@@ -923,10 +1154,13 @@ class GaussianDiffusion(nn.Module):
         lo, hi = float(min_max_val[0]), float(min_max_val[1])
         T, S, eta = self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
         branch, fuse, mask_x = self._flags(mask)
-        if branch and mask is not None and mask.shape[1] > 1:
-            raise NotImplementedError("K-mask branching (mask [B,K,H,W], K > 1) is implemented for the DDPM loop; the "
-                                      "reference's DDIM fusion (ddpm.py:1025-1041) selects by exact zeros of the OOD "
-                                      "prediction, which has no mask-based K > 2 form")
+        if branch and mask is not None and mask.shape[1] > 1:        # K-mask generalisation
+            if return_all_timesteps:
+                raise TypeError("return_all_timesteps is only defined for the single-branch reverse process "
+                                "(the reference's torch.stack(imgs) fails on the per-branch lists, ddpm.py:1069-1072)")
+            x_T = torch.empty(shape, dtype=torch.float32, device=dev)
+            self._noise(x_T, 0)
+            return self._ddim_sample_kmask(cond_img.to(dev, torch.float32).contiguous(), mask, lo, hi, shape, x_T, fuse, mask_x)
         obj = cabi.OBJ[self.objective]
         times, pairs = schedule.ddim_time_pairs(T, S)
         t_fuse = times[-int(self.config["start_timestep"]) - 2]                 # ddpm.py:987
@@ -1025,6 +1259,7 @@ class GaussianDiffusion(nn.Module):
                                                 mo_in.data_ptr(), mask.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(),
                                                 float(sr_all[t]), float(srm1_all[t]), san, c, sigma, lo, hi,
                                                 B, C, HW, st), "fuse_ddim")
+                    self._mask_x_set(False)                # ddpm.py:1024
                     idx += 1
                     fused = True
                     break

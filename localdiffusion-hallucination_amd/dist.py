@@ -60,10 +60,24 @@ class LdComm:
         cabi.check(cabi.lib().ld_comm_unique_id(buf), "comm_unique_id")
         return bytes(buf)
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     @classmethod
-    def bootstrap(cls, world=None, rank=None, id_file=None):
+    def bootstrap(cls, world=None, rank=None, id_file=None, run_id=None, timeout_s=120.0):
         """Collective: every rank calls it.  With a torch process group the id travels by broadcast; otherwise rank 0
-        writes ``id_file`` and the others poll for it."""
+        writes ``id_file`` and the others poll for it.  ``run_id`` (any string all ranks of THIS run agree on, e.g.
+        MASTER_PORT or a job id) becomes part of the file name, so a file left behind by an earlier run is never read;
+        without one the launcher must hand every run a fresh ``id_file``.  Polling gives up after ``timeout_s``."""
         import os
         import time
         if dist.is_available() and dist.is_initialized():
@@ -77,11 +91,18 @@ class LdComm:
         assert world is not None and rank is not None and (id_file is not None or world == 1)
         if world == 1:
             return cls(1, 0, cls.make_unique_id())
+        if run_id is None:
+            run_id = os.environ.get("MASTER_PORT") or os.environ.get("TORCHELASTIC_RUN_ID")
+        if run_id is not None:
+            id_file = f"{id_file}.{run_id}"
         if rank == 0:
             with open(id_file + ".tmp", "wb") as f:
                 f.write(cls.make_unique_id())
             os.replace(id_file + ".tmp", id_file)
+        t0 = time.monotonic()
         while not os.path.exists(id_file):
+            if time.monotonic() - t0 > timeout_s:
+                raise TimeoutError(f"LdComm.bootstrap: rank {rank} saw no {id_file} within {timeout_s} s")
             time.sleep(0.01)
         return cls(world, rank, open(id_file, "rb").read())
 
@@ -94,36 +115,46 @@ class LdComm:
 
     def close(self):
         from . import _cabi as cabi
-        if self._comm:
+        if getattr(self, "_comm", None):
             cabi.check(cabi.lib().ld_comm_destroy(self._comm), "comm_destroy")
             self._comm = None
 
 
-def gather_patches(local, n_items, group=None, comm=None):
+def gather_patches(local, n_items, group=None, comm=None, dtype=None):
     """All-gather ragged shards back into [n_items, ...] on every rank (one collective).
 
-    Shards are padded to the largest shard so a single ``all_gather_into_tensor`` suffices
-    (payload: 402 MB of fp32 boundary tensors at 512 patches of 3x256x256 -- latency-, not bandwidth-bound on xGMI).
+    Equal shards go straight into the result (no padding, no copy afterwards); ragged ones are padded to the largest
+    shard so that a single ``all_gather_into_tensor`` suffices.  ``dtype``: what travels (the storage
+    dtype -- 201 MB of bf16 / fp16 at cfg4's 512 patches of 3x256x256 instead of 402 MB of the fp32 boundary
+    tensors); the result comes back in that dtype.  Latency-, not bandwidth-bound on xGMI either way.
     ``comm``: an ``LdComm`` -- the same collective through the C ABI's ``ld_allgather`` instead of torch.distributed.
     """
-    if comm is not None:
-        world = comm.world
-        sizes = [shard_bounds(n_items, world, r) for r in range(world)]
-        mx = max(hi - lo for lo, hi in sizes)
-        pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[:local.shape[0]] = local
-        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        comm.all_gather(pad.contiguous(), out)
-        return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
-    world = dist.get_world_size(group)
+    if local.device.type == "cuda":
+        from . import _cabi as cabi
+        with cabi.prof_range("exchange"):
+            return _gather_patches(local, n_items, group, comm, dtype)
+    return _gather_patches(local, n_items, group, comm, dtype)
+
+
+def _gather_patches(local, n_items, group, comm, dtype):
+    if dtype is not None and local.dtype != dtype:
+        local = local.to(dtype)
+    world = comm.world if comm is not None else dist.get_world_size(group)
     sizes = [shard_bounds(n_items, world, r) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)
-    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
+    equal = all(hi - lo == mx for lo, hi in sizes)
+    send = local.contiguous()
+    if not equal:
+        send = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[:local.shape[0]] = local
     out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
-    parts = [out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
-    return torch.cat(parts, 0)
+    if comm is not None:
+        comm.all_gather(send, out)
+    else:
+        dist.all_gather_into_tensor(out, send, group=group)
+    if equal:
+        return out
+    return torch.cat([out[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
 
 
 def recompose(patches, masks):
@@ -155,11 +186,12 @@ def _sample_shard(diffusion, lo, hi, per_sample_elems, call):
         diffusion.noise_offset = keep
 
 
-def sample_patches_sharded(diffusion, conds, min_max_val, n_images, k_masks, masks):
+def sample_patches_sharded(diffusion, conds, min_max_val, n_images, k_masks, masks, gather_dtype=None):
     """Independent local patches: run ``diffusion.sample`` on this rank's contiguous shard
     of the [n_images*k_masks] patch list with no traffic inside the T-loop, ONE all-gather, recomposition by the
     masks.  conds: [n_images*k_masks, Cc, H, W] (already masked per patch), identical on all ranks.
-    Returns the recomposed images [n_images, C, H, W] on every rank."""
+    ``gather_dtype``: the dtype the patches travel in (None: the fp32 boundary tensors; torch.bfloat16 / float16:
+    the denoiser's storage dtype, half the payload).  Returns the recomposed images [n_images, C, H, W] on every rank."""
     P = n_images * k_masks
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_bounds(P, world, rank)
@@ -169,7 +201,7 @@ def sample_patches_sharded(diffusion, conds, min_max_val, n_images, k_masks, mas
             conds[lo:hi], None, batch_size=hi - lo, mask=None, min_max_val=min_max_val))
     else:                                                    # more ranks than patches: replicas idle
         x = conds.new_zeros((0, C, H, H), dtype=torch.float32)
-    allx = gather_patches(x.to(torch.float32), P)
+    allx = gather_patches(x.to(torch.float32), P, dtype=gather_dtype)
     return recompose(allx.reshape(n_images, k_masks, *allx.shape[1:]), masks)
 
 
@@ -186,14 +218,22 @@ def sample_images_sharded(diffusion, cond_img, gt, masks, min_max_val, **sample_
     lo, hi = shard_bounds(n, world, rank)
     C, H = diffusion.channels, diffusion.image_size
     out = None
-    if hi > lo:
-        out = _sample_shard(diffusion, lo, hi, C * H * H, lambda: diffusion.sample(
-            cond_img[lo:hi], None if gt is None else gt[lo:hi], batch_size=hi - lo,
-            mask=None if masks is None else masks[lo:hi], min_max_val=min_max_val, **sample_kw))
-    # the layout of the result is a function of the flags, not of the shard: every rank (also an idle one) derives it
-    branch, fuse, _ = diffusion._flags(masks)
-    as_list = diffusion.is_ddim_sampling and branch and not fuse
-    stacked = (not diffusion.is_ddim_sampling) and (not fuse) and diffusion.branch_out
+    # The reference decides "all-ones mask -> plain reverse process" on the mask of the WHOLE batch (torch.unique over
+    # the batch, ddpm.py:1110-1117).  A shard must not decide it on its own slice: a rank whose images happen to be
+    # all-ones would drop to the single-branch path, return another layout and enter the collective with another
+    # shape.  The decision is taken once here, on the global masks, and forced into the shard's call; the layout below
+    # derives from the same flags on every rank (also an idle one).
+    keep = getattr(diffusion, "_all_ones_forced", None)
+    diffusion._all_ones_forced = bool(diffusion._all_ones(masks))
+    try:
+        if hi > lo:
+            out = _sample_shard(diffusion, lo, hi, C * H * H, lambda: diffusion.sample(
+                cond_img[lo:hi], None if gt is None else gt[lo:hi], batch_size=hi - lo,
+                mask=None if masks is None else masks[lo:hi], min_max_val=min_max_val, **sample_kw))
+        layout = diffusion.result_layout(masks)
+    finally:
+        diffusion._all_ones_forced = keep
+    as_list, stacked = layout == "list", layout == "stacked"
     dev = cond_img.device
     if out is None:
         out = torch.zeros((2, 0, C, H, H) if (as_list or stacked) else (0, C, H, H), dtype=torch.float32, device=dev)

@@ -719,23 +719,31 @@ class _Plan:
     def run_cond(self, st):
         self.cond_version = getattr(self, "cond_version", 0) + 1
         s = self.stats[:self.cond_slots]
-        cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
-        for op in self.ops_cond:
-            op(st)
+        self.lib.ld_range_push(b"encoder")
+        try:
+            cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
+            for op in self.ops_cond:
+                op(st)
+        finally:
+            self.lib.ld_range_pop()
 
     def run_main(self, st, skip_final=False, step_delta=0, idx_ptr=None, t_table=None):
         """One denoiser evaluation.  ``skip_final``: stop before final_conv (the caller runs ld_final_step).
         ``step_delta``: added to the device step counter by the evaluation's first launch (ld_step_begin zeroes the
         statistics slots this plan uses, the k-max arena if the unfused linear attention is on the plan, and moves
         the counter -- one launch where two memsets and ld_step_add were three)."""
-        if idx_ptr is not None:                    # strided sampling: t_dev = t_table[++idx] (ld_step_begin)
-            cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr, 0, idx_ptr, t_table, st), "step_begin")
-        else:
-            cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr if step_delta else None, int(step_delta),
-                                              None, None, st), "step_begin")
-        ops = self.ops_main[:-1] if skip_final else self.ops_main
-        for op in ops:
-            op(st)
+        self.lib.ld_range_push(b"step")            # roctx: host-side issue of one denoiser evaluation (or its capture)
+        try:
+            if idx_ptr is not None:                # strided sampling: t_dev = t_table[++idx] (ld_step_begin)
+                cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr, 0, idx_ptr, t_table, st), "step_begin")
+            else:
+                cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr if step_delta else None, int(step_delta),
+                                                  None, None, st), "step_begin")
+            ops = self.ops_main[:-1] if skip_final else self.ops_main
+            for op in ops:
+                op(st)
+        finally:
+            self.lib.ld_range_pop()
 
     def run_main_timed(self, st, acc):
         """Like run_main, inside a per-launch timing session of the library (ld_timing_*: every kernel launch carries

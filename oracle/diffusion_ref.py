@@ -116,6 +116,10 @@ class RefSampler:
         self.classifier = None
         self.classifier_flag = 0
         self.pred_cls = None
+        # config['mask_x'] as the reference carries it from one sample() call to the next: cleared by the fusion
+        # step (ddpm.py:780-781, 1023-1024) and by the all-ones fallback (:1114), set by a classifier rejection
+        # (:907-908), re-armed by sample() only when ood_AD / ood_confidence is on (:1106-1108).
+        self.mask_x_state = bool(opts.mask_x)
 
     # --- pointwise conversions (ddpm.py:631-653) ---
     def _c(self, name, t):
@@ -226,6 +230,7 @@ class RefSampler:
                     xs = [x, x]
                 if fuse and t <= o.start_timestep:
                     x, x0f, x_branchout = self._fuse_step(xs, cond, mask, t, lohi, mask_x, noise, sigma)
+                    self.mask_x_state = False        # ddpm.py:781
                     joint, xs = True, None          # (fusion() only does bookkeeping for this step: branch_cnt == 1, :877)
                     imgs.append(x)
                     x_start_lst.append(x0f)
@@ -258,8 +263,9 @@ class RefSampler:
                     if self.pred_cls > 0.0 or t == 0:
                         self.classifier_flag = 1
                     else:
-                        mask_x = True
+                        mask_x = True                # ddpm.py:908 sets the flag, the redo's fusion step clears it again
                         x, x0, x_branchout = self._fuse_step(x_branchout, cond, mask, t, lohi, mask_x, noise, sigma)
+                        self.mask_x_state = False
                 imgs.append(x)
                 x_start_lst.append(x0)
                 if record:
@@ -316,27 +322,41 @@ class RefSampler:
             x = torch.where(x == 0.0, parts[k], x)
         return x, x0
 
-    def p_sample_loop_kmask(self, cond, masks, lohi, shape, noise, fuse, mask_x, record=None):
+    def _kmask_fuse_step(self, xs, cond, masks, t, lohi, mask_x, noise, sigma):
+        """K-branch evaluation + fusion of one step -> (x_{t-1}, x0, [x_k m_k]): _fuse_step for K branches."""
+        binary, x0s = self.kmask_predict(xs, cond, masks, t, lohi, mask_x)
+        x, x0 = self.kmask_fuse(xs, x0s, binary, lohi)
+        kept = [xs[k] * binary[:, k:k + 1] for k in range(len(xs))]
+        z = noise(x.shape) if t > 0 else 0.0
+        return self.posterior_mean(x0, x, t) + sigma * z, x0, kept
+
+    def p_sample_loop_kmask(self, cond, masks, lohi, shape, noise, fuse, mask_x, record=None, return_all_outputs=False):
         """K branches with a shared draw per step (ddpm.py:852-858), fused at t <= start_timestep when ``fuse``, joint
-        single-branch steps afterwards; without ``fuse`` returns the K branch states stacked [K,B,C,H,W]."""
+        single-branch steps afterwards; without ``fuse`` returns the K branch states stacked [K,B,C,H,W].
+        ``return_all_outputs``: (ret, x_start_lst, []) as ddpm.py:971-972 -- a K-list of x0 per branch step (:869), the
+        fused / single x0 otherwise.  With o.classifier the joint steps run under the gate of fusion() (:883-916): a
+        rejected step is replaced by a K-branch evaluation + fusion at the same t from the masked branch states the
+        fusion step kept, with mask_x forced on -- the two-branch rule with "each further branch" for "in"."""
         o, K = self.o, masks.shape[1]
         x = noise(shape)
         xs = [x] * K
         joint = False
+        x_start_lst, kept = [], None
         for t in range(self.T - 1, -1, -1):
             sigma = (0.5 * self._c("posterior_log_variance_clipped", t)).exp()
             if not joint:
-                binary, x0s = self.kmask_predict(xs, cond, masks, t, lohi, mask_x)
                 if fuse and t <= o.start_timestep:
-                    x, x0 = self.kmask_fuse(xs, x0s, binary, lohi)
-                    z = noise(x.shape) if t > 0 else 0.0
-                    x = self.posterior_mean(x0, x, t) + sigma * z
+                    x, x0, kept = self._kmask_fuse_step(xs, cond, masks, t, lohi, mask_x, noise, sigma)
+                    self.mask_x_state = False
                     joint, xs = True, None
+                    x_start_lst.append(x0)
                     if record:
                         record(t, x)
                     continue
+                binary, x0s = self.kmask_predict(xs, cond, masks, t, lohi, mask_x)
                 z = noise(xs[0].shape) if t > 0 else 0.0
                 xs = [self.posterior_mean(x0s[k], xs[k], t) + sigma * z for k in range(K)]
+                x_start_lst.append(list(x0s))
                 if record:
                     record(t, xs)
             else:
@@ -344,9 +364,75 @@ class RefSampler:
                 x0 = x0.clamp(lohi[0], lohi[1])
                 z = noise(x.shape) if t > 0 else 0.0
                 x = self.posterior_mean(x0, x, t) + sigma * z
+                if o.classifier and fuse and kept is not None:
+                    if self.classifier_flag == 0:
+                        assert self.classifier is not None, "config['classifier'] needs a callable in .classifier"
+                        self.pred_cls = float(self.classifier(x0)[0])
+                    if self.pred_cls > 0.0 or t == 0:
+                        self.classifier_flag = 1
+                    else:
+                        mask_x = True
+                        x, x0, kept = self._kmask_fuse_step(kept, cond, masks, t, lohi, mask_x, noise, sigma)
+                        self.mask_x_state = False
+                x_start_lst.append(x0)
                 if record:
                     record(t, x)
-        return x if joint else torch.stack(xs, dim=0)
+        ret = x if joint else torch.stack(xs, dim=0)
+        if return_all_outputs:
+            return ret, x_start_lst, []
+        return ret
+
+    def ddim_sample_kmask(self, cond, masks, lohi, shape, noise, fuse, mask_x):
+        """ddim_sample (ddpm.py:980-1075) for K branches.  Per pair every branch is evaluated with clip_x_start
+        (:1005), eps re-derived from the clamped x0 (:745-746), one shared draw (:1020).  Fusion at t <= times[-s-2]
+        (:1022-1041 read per branch): x0 = clamp(x0_0 where it is non-zero, else the x0 of the IND branch that owns
+        the pixel -- the first k >= 1 with m_k >= 1, the last branch if none does); eps = first non-zero of
+        eps_k m_k (the last one if all are zero).  For K = 2 and m_1 = 1 - (m_0 >= 1) both rules are the reference's
+        where(x0_out == 0, x0_in, x0_out) and where(eps_out m == 0, eps_in (1 - m), eps_out m).  Never fused: the K
+        branch states come back as a list."""
+        o, K = self.o, masks.shape[1]
+        times = list(reversed(torch.linspace(-1, self.T - 1, steps=self.S + 1).int().tolist()))
+        pairs = list(zip(times[:-1], times[1:]))
+        t_fuse = times[-o.start_timestep - 2]
+        eta, abar = o.ddim_sampling_eta, self.buf["alphas_cumprod"]
+        x = noise(shape)
+        xs, joint = [x] * K, False
+        for t, t_next in pairs:
+            if not joint:
+                binary, x0s = self.kmask_predict(xs, cond, masks, t, lohi, mask_x)      # clamped per branch
+                eps = [self.eps_from_x0(xs[k], t, x0s[k]) for k in range(K)]
+                if t_next < 0:
+                    xs = x0s
+                    continue
+                a, an = abar[t], abar[t_next]
+                sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+                c = (1 - an - sigma ** 2).sqrt()
+                z = noise(xs[0].shape)
+                if fuse and t <= t_fuse:
+                    alt = x0s[K - 1]
+                    for k in range(K - 2, 0, -1):
+                        alt = torch.where(binary[:, k:k + 1] >= 1.0, x0s[k], alt)
+                    x0 = torch.where(x0s[0] == 0.0, alt, x0s[0]).clamp(lohi[0], lohi[1])
+                    e = eps[0] * binary[:, 0:1]
+                    for k in range(1, K):
+                        e = torch.where(e == 0.0, eps[k] * binary[:, k:k + 1], e)
+                    x = x0 * an.sqrt() + c * e + sigma * z
+                    self.mask_x_state = False
+                    joint, xs = True, None
+                else:
+                    xs = [x0s[k] * an.sqrt() + c * eps[k] + sigma * z for k in range(K)]
+            else:
+                e, x0 = self.predict_single(x, cond, t, lohi, True)
+                if o.branch_out:
+                    x0 = x0.clamp(lohi[0], lohi[1])
+                if t_next < 0:
+                    x = x0
+                    continue
+                a, an = abar[t], abar[t_next]
+                sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+                c = (1 - an - sigma ** 2).sqrt()
+                x = x0 * an.sqrt() + c * e + sigma * noise(x.shape)
+        return x if joint else list(xs)
 
     # --- DDIM (ddpm.py:980-1075) ---
     def ddim_sample(self, cond, mask, lohi, shape, noise, branch, fuse, mask_x, return_all_timesteps=False):
@@ -381,6 +467,7 @@ class RefSampler:
                     assert bool((po == 0).any()) and bool((pi == 0).any()), "x_out and x_in should be masked"
                     eps = torch.where(po == 0.0, pi, po)
                     x = x0 * an.sqrt() + c * eps + sigma * z
+                    self.mask_x_state = False        # ddpm.py:1024
                     joint, xs = True, None
                     imgs.append(x)
                 else:
@@ -406,13 +493,18 @@ class RefSampler:
 
     # --- dispatcher (ddpm.py:1078-1125) ---
     def sample(self, cond, mask, lohi, batch_size, noise, gt=None, return_all_timesteps=False, return_all_outputs=False):
+        """One call of the reference's sample().  branch_out / start_intermediate are restored from the constructor
+        copies at every call (:1093-1097); config['mask_x'] is NOT -- it carries over (``mask_x_state``)."""
         o = self.o
         branch, fuse = o.branch_out, o.start_intermediate
-        mask_x = o.mask_x or o.ood_AD or o.ood_confidence
+        if o.ood_AD or o.ood_confidence:               # :1106-1108
+            self.mask_x_state = True
+        mask_x = self.mask_x_state
         if branch and mask is not None:
             u = torch.unique(mask)
             if len(u) == 1 and float(u[0]) == 1.0:     # all-ones mask: plain reverse process (:1110-1117)
                 branch, fuse, mask_x = False, False, False
+                self.mask_x_state = False              # :1114, never restored
         shape = (batch_size, self.channels, self.image_size, self.image_size)
         if self.S < self.T:
             return self.ddim_sample(cond, mask, lohi, shape, noise, branch, fuse, mask_x,

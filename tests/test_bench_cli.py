@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -24,3 +26,48 @@ def test_more_gpus_than_devices_is_an_error():
 def test_world_size_must_match_gpus():
     r = _run(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_visible_gpus_counts_without_hip(monkeypatch):
+    """The launcher's device count reads the KFD topology and the *_VISIBLE_DEVICES variables; it never calls HIP."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n = bench.visible_gpus()
+    assert n >= 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.visible_gpus() == min(n, 1)
+
+
+def test_a_failing_rank_fails_the_run_and_its_stderr_is_shown(tmp_path):
+    """One rank dies before the rendezvous: the launcher reports ITS stderr tail, kills whatever is left after the
+    grace period (exact child PIDs) and exits non-zero; per-rank logs are kept."""
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+             {"LD_BENCH_SHARE_GPU": "1", "LD_BENCH_FAIL_RANK": "1", "LD_BENCH_HANG_RANK": "0", "LD_BENCH_GRACE": "2",
+              "LD_BENCH_LOG_DIR": str(tmp_path)})
+    assert r.returncode == 1, (r.returncode, r.stderr)
+    assert "injected failure on rank 1" in r.stderr and "bench_rank1.err" in r.stderr
+    assert "did not finish within" in r.stderr
+    assert os.path.exists(tmp_path / "bench_rank0.err") and os.path.exists(tmp_path / "bench_rank1.err")
+
+
+def test_a_hung_run_times_out_and_is_killed(tmp_path):
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+             {"LD_BENCH_SHARE_GPU": "1", "LD_BENCH_HANG_RANK": "all", "LD_BENCH_RANK_TIMEOUT": "3", "LD_BENCH_LOG_DIR": str(tmp_path)})
+    assert r.returncode == 1 and "timeout" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_over_gloo_print_one_line():
+    """The N > 1 control flow of bench.py end to end on a 1-GPU box: two rank processes share the GPU, gloo carries the
+    collectives (RCCL refuses two ranks on one device), rank 0 prints ONE JSON line with n_gpus == 2."""
+    import json
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-other-dtype"],
+             {"LD_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0 and j["scaling"] == "weak"
+    assert "functional test" in j["config"]["parallelism"]

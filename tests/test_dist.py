@@ -88,15 +88,27 @@ class _StubDiffusion:
         self.noise_offset, self.fuse = 0, fuse
         self.calls = []
 
-    def _flags(self, mask):
-        return True, self.fuse, True
+    _all_ones_forced = None
+
+    def _all_ones(self, mask):
+        """GaussianDiffusion._all_ones: the reference's 'mask is all ones -> plain reverse process' test (ddpm.py:1110)."""
+        if self._all_ones_forced is not None:
+            return self._all_ones_forced
+        return mask is not None and bool((mask == 1).all())
+
+    def result_layout(self, mask):
+        return "plain" if self.fuse else "stacked"
 
     def sample(self, cond, gt, batch_size=16, mask=None, min_max_val=None, **kw):
+        """The all-ones decision changes the RESULT (as it changes the reverse process in the real sampler): a shard
+        that took it on its own slice of the masks would differ from the unsharded batch."""
         from localdiffusion_hallucination_amd import rng
         assert cond.shape[0] == batch_size
         self.calls.append((batch_size, self.noise_offset))
         z = torch.from_numpy(rng.randn((batch_size, 3, 4, 4), 10, 0, self.noise_offset))
         x = cond * 2.0 + z + (0.0 if mask is None else mask)
+        if self._all_ones(mask):
+            x = x * 0.5 - 3.0
         return x if self.fuse else torch.stack([x, -x], 0)
 
 
@@ -108,6 +120,7 @@ def _sharded_worker(rank, world, port, n_items, q):
         torch.manual_seed(1)
         cond = torch.randn(n_items, 3, 4, 4)                  # identical on every rank
         masks = (torch.rand(n_items, 1, 4, 4) > 0.5).float()
+        masks[n_items // 2:] = 1.0        # the LAST rank's shard is all ones, the batch as a whole is not
         ok = True
         for fuse in (True, False):
             whole = _StubDiffusion(fuse).sample(cond, None, batch_size=n_items, mask=masks)       # the single-GPU answer

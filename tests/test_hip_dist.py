@@ -36,7 +36,7 @@ def test_a_shard_with_noise_offset_reproduces_the_unsharded_batch(noise):
     cond = torch.from_numpy(rng.uniform((B, 1, H, H), 41, 1, 0.0, 2.0)).cuda()
     mask = torch.zeros(B, 1, H, H)
     mask[:, :, :, :H // 4] = 1.0
-    kw = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True)
+    kw = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True, ood_AD=True)
     gd = make(dict(mode="mri"), kw, H, T)
     gd.noise_source, gd.sub_batches = noise, 1
     whole = gd.sample(cond, None, batch_size=B, mask=mask.cuda(), min_max_val=(0.0, 2.0)).cpu().numpy()
@@ -56,7 +56,7 @@ def test_sharded_drivers_world1(world1):
     cond = torch.from_numpy(rng.uniform((B, 1, H, H), 42, 1, 0.0, 2.0)).cuda()
     mask = torch.zeros(B, 1, H, H)
     mask[:, :, :, :H // 4] = 1.0
-    kw = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True)
+    kw = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True, ood_AD=True)
     gd = make(dict(mode="mri"), kw, H, T)
     gd.noise_source = "device"
     want = gd.sample(cond, None, batch_size=B, mask=mask.cuda(), min_max_val=(0.0, 2.0))
@@ -78,6 +78,34 @@ def test_sharded_drivers_world1(world1):
     x = gd3.sample(conds, None, batch_size=B * K, min_max_val=(0.0, 2.0)).reshape(B, K, 1, H, H)
     ref = (x * masks.cuda()[None]).sum(1)
     assert tuple(img.shape) == (B, 1, H, H) and float((img - ref).abs().max()) <= 1e-6
+
+
+def test_cfg4_shaped_patch_sharding_world1(world1):
+    """cfg4's unit of work through the sharded driver at world size 1: 8 images x 8 band masks of 3x256x256 in bf16,
+    ONE all-gather (RCCL) in the storage dtype, ld_recompose == sum_k x_k m_k of the plain batch."""
+    B, K, H, T = 8, 8, 256, 5
+    net = ldh.Unet(dim=32, init_dim=32, channels=3, out_dim=3, mode="mvtec", compute_dtype="bf16")
+    from localdiffusion_hallucination_amd import weights
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()})
+    cfg = dict(branch_out=False, start_intermediate=False, start_timestep=2, data="mvtec", mask_x=False, mask_cond=False,
+               ood_AD=False, ood_confidence=False, classifier=False, use_gt=False, use_gt_timestep=100)
+    gd = ldh.GaussianDiffusion(cfg, net, image_size=H, timesteps=T, beta_schedule="sigmoid", objective="pred_x0",
+                               auto_normalize=False).to("cuda")
+    gd.noise_source = "device"
+    masks = torch.zeros(K, 1, H, H)
+    for k in range(K):
+        masks[k, :, :, k * (H // K):(k + 1) * (H // K)] = 1.0
+    imgs = torch.from_numpy(rng.uniform((B, 3, H, H), 65, 1, 0.0, 2.0))
+    conds = torch.stack([imgs[i] * (masks[k] if k == 0 else torch.clip(masks[k], 0.95, 1.0))
+                         for i in range(B) for k in range(K)]).cuda()
+    x = gd.sample(conds, None, batch_size=B * K, min_max_val=(0.0, 2.0)).reshape(B, K, 3, H, H)
+    ref = (x * masks.cuda()[None]).sum(1)
+    img = ldist.sample_patches_sharded(gd, conds, (0.0, 2.0), B, K, masks)
+    assert tuple(img.shape) == (B, 3, H, H) and float((img - ref).abs().max()) <= 1e-6
+    # the storage dtype on the wire (SURVEY 8e): the samples are rounded to bf16 once, after the chain
+    img16 = ldist.sample_patches_sharded(gd, conds, (0.0, 2.0), B, K, masks, gather_dtype=torch.bfloat16)
+    ref16 = (x.to(torch.bfloat16).float() * masks.cuda()[None]).sum(1)
+    assert float((img16 - ref16).abs().max()) <= 1e-6 and float((img16 - ref).abs().max()) <= 2.0 * 2 ** -8
 
 
 def test_ld_allgather_world1_through_the_c_abi():

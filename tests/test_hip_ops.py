@@ -2,6 +2,7 @@
 (the building blocks of oracle/unet_ref.py), on seeded inputs, fp32, bf16 and fp16 storage."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -575,3 +576,58 @@ def test_conv1x1_gn_tail_epilogue(dtype):
     out = hh.conv1x1([hh.make_src(hh.nhwc(x1, dtype), c1), hh.make_src(hh.nhwc(x2, dtype), c2)], hh.pack(w, dtype, 1),
                      B, H, W, cout, dtype, bias=b.to(hh.DEV), epi=cabi.EPI_GN_TAIL, gn_tail=tail)
     assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
+
+
+def _c1_group_probe(path):
+    """Child process of test_conv1x1_grouped_staging_is_bitwise_the_plain_k_loop: every epilogue of ld_conv1x1 at K
+    extents that exercise full groups and the tail group (nch = 2, 3, 5, 13 chunks of 32 channels), results to ``path``."""
+    out = {}
+    B, H, W = 2, 16, 16
+    for nch in (2, 3, 5, 13):
+        cin = 32 * nch
+        for dtype in ("bf16", "fp32"):
+            x = hh.rand((B, cin, H, W), 900 + nch)
+            xs = hh.make_src(hh.nhwc(x, dtype), cin)
+            for epi, cout in ((cabi.EPI_PLAIN, 64), (cabi.EPI_RES, 64), (cabi.EPI_QKV_FULL, 384), (cabi.EPI_QKV_LINEAR, 384),
+                              (cabi.EPI_RMS_RES, 64), (cabi.EPI_GN_TAIL, 64)):
+                w = hh.rand((cout, cin, 1, 1), 910 + nch + epi, -0.2, 0.2)
+                kw = {}
+                if epi in (cabi.EPI_RES, cabi.EPI_RMS_RES):
+                    kw["residual"] = hh.nhwc(hh.rand((B, cout, H, W), 920 + nch), dtype)
+                if epi == cabi.EPI_RMS_RES:
+                    kw["g2"] = hh.rand((cout,), 921, 0.5, 1.5).to(hh.DEV)
+                if epi in (cabi.EPI_QKV_FULL, cabi.EPI_QKV_LINEAR):
+                    kw["rms_in"] = 1
+                if epi == cabi.EPI_QKV_LINEAR:
+                    kw["kmax_out"] = torch.zeros(B, cabi.STAT_STRIPES, 128, dtype=torch.int32, device=hh.DEV)
+                if epi == cabi.EPI_GN_TAIL:
+                    h = hh.rand((B, cout, H, W), 930 + nch)
+                    kw["gn_tail"] = hh.make_src(hh.nhwc(h, dtype), cout, gn=(hh.stats_striped(h, 8), hh.rand((cout,), 931, 0.5, 1.5).to(hh.DEV),
+                                                                      hh.rand((cout,), 932).to(hh.DEV), 8), act=cabi.ACT_SILU)
+                bias = None if epi in (cabi.EPI_QKV_FULL, cabi.EPI_QKV_LINEAR) else hh.rand((cout,), 940).to(hh.DEV)
+                y = hh.conv1x1([xs], hh.pack(w, dtype, 1), B, H, W, cout, dtype, bias=bias, epi=epi, **kw)
+                out[f"{dtype}_{nch}_{epi}"] = y.float().cpu().numpy()
+    torch.cuda.synchronize()
+    np.savez(path, **out)
+
+
+@pytest.mark.gpu
+def test_conv1x1_grouped_staging_is_bitwise_the_plain_k_loop(tmp_path):
+    """the grouped K staging (four chunks per barrier pair, pairs on mid-size maps) takes most small-map
+    launches by default, the plain loop only the large ones.  The same calls in two processes, LD_C1_GROUP=1 and =0, for
+    every epilogue and for K extents with a partial last group: the arithmetic order is unchanged, so bit-equal."""
+    import subprocess
+    import sys
+    res = {}
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"c1_{flag}.npz")
+        code = (f"import sys; sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); "
+                f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); "
+                f"import test_hip_ops as t; t._c1_group_probe({path!r})")
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LD_C1_GROUP=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[flag] = np.load(path)
+    assert len(res["1"].files) == 4 * 2 * 6
+    for k in res["1"].files:
+        assert np.isfinite(res["1"][k]).all(), k
+        assert np.array_equal(res["1"][k], res["0"][k]), (k, float(np.abs(res["1"][k] - res["0"][k]).max()))

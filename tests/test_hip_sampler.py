@@ -114,6 +114,31 @@ def test_fallback_and_objectives(golden):
         check("G8 " + obj, run(make(MNIST, dict(data="mnist"), 28, 20, objective=obj), cond, None, 2), g[obj + "_final"])
 
 
+@pytest.mark.parametrize("tag,kw,S,seq", [("ddpm_maskx", dict(mask_x=True), None, ("band", "band")),
+                                        ("ddpm_oodad", dict(ood_AD=True), None, ("band", "band")),
+                                        ("ddpm_ones_then_band", dict(mask_x=True), None, ("ones", "band")),
+                                        ("ddim_maskx", dict(mask_x=True), 10, ("band", "band")),
+                                        ("ddim_oodad", dict(ood_AD=True), 10, ("band", "band"))])
+def test_consecutive_calls_carry_mask_x_like_the_reference(golden, tag, kw, S, seq):
+    """G14 (from the real reference): consecutive sample() calls on ONE object.  The reference clears config['mask_x']
+    at the fusion step (ddpm.py:780-781, 1023-1024) and in the all-ones fallback (:1114) and re-arms it only under
+    ood_AD / ood_confidence (:1106-1108): with {mask_x: True, ood_AD: False} call 2 runs unmasked.  The opt-out
+    (first_call_semantics) makes every call behave like call 1."""
+    g = golden("g14_consecutive_calls")
+    cond, masks = torch.from_numpy(g["cond"]), {"band": torch.from_numpy(g["band"]), "ones": torch.ones(2, 1, 32, 32)}
+    conf = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=2, **kw)
+    gd = make(dict(mode="mri"), conf, 32, 50, S)
+    for i, m in enumerate(seq):
+        check(f"G14 {tag} call {i + 1}", run(gd, cond, masks[m], 2), g[f"{tag}_call{i + 1}"])
+    if tag.endswith("_maskx"):
+        gd.reset_call_state()
+        check(f"G14 {tag} after reset_call_state", run(gd, cond, masks["band"], 2), g[f"{tag}_call1"])
+        gd2 = make(dict(mode="mri"), conf, 32, 50, S)
+        gd2.first_call_semantics = True
+        for i in range(2):
+            check(f"G14 {tag} first_call_semantics call {i + 1}", run(gd2, cond, masks["band"], 2), g[f"{tag}_call1"])
+
+
 def test_use_gt_start_and_return_all(golden):
     """The use_gt start (q_sample of the HR image at use_gt_timestep, ddpm.py:937-944) and the history returns
     (return_all_timesteps: every x_t stacked on dim 1; return_all_outputs: (ret, x0 per step, [])), DDPM and DDIM,
@@ -157,6 +182,7 @@ def test_kmask_branching_k2_is_the_reference_path(golden, data, kw, H):
     masks = torch.cat([mask, 1.0 - (mask >= 1.0).float()], 1)
     gd = make(kw, dict(data=data, branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True), H, 50)
     two = run(gd, cond, mask, 2)
+    gd.reset_call_state()                    # mask_x carries over between calls on one object (G14): start afresh
     k2 = run(gd, cond, masks, 2)
     check(f"K-mask loop, K=2, {data}{H}", k2, g[f"{data}{H}_final"])
     assert np.array_equal(k2, two)
@@ -184,6 +210,71 @@ def test_kmask_branching_k4_matches_oracle():
                                           fuse, True).numpy()
         assert got.shape == ((B, 1, H, H) if fuse else (K, B, 1, H, H))
         check(f"K-mask loop, K=4, fuse={fuse} vs oracle", got, ref)
+
+
+def test_kmask_ddim_k2_is_the_reference_path(golden):
+    """The K-mask DDIM loop (ld_fuse_ddim_k) with K = 2 and masks [m, 1 - (m >= 1)] against the reference's DDIM goldens
+    (G7: 50 of 1000 with fusion; 10 of 50 kept apart) and bit for bit against the two-branch HIP path."""
+    g = golden("g7_ddim")
+    mask = torch.from_numpy(g["mask"])
+    H = mask.shape[-1]
+    cond = torch.from_numpy(rng.uniform((1, 1, H, H), 7, 1, 0.0, 2.0))
+    masks = torch.cat([mask, 1.0 - (mask >= 1.0).float()], 1)
+    for key, T, S, fuse in (("fused_final", 1000, 50, True), ("nofuse_final", 50, 10, False)):
+        conf = dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=2, mask_x=True)
+        gd = make(dict(mode="mri"), conf, H, T, S)
+        gd.sub_batches = 1                   # the eager batched two-branch loop: the same launches as the K-mask loop
+        two = run(gd, cond, mask, 1)
+        gd.reset_call_state()
+        k2 = run(gd, cond, masks, 1)
+        check(f"K-mask DDIM, K=2, {key}", k2, g[key])
+        assert np.array_equal(k2, two)
+
+
+def test_kmask_k4_ddim_histories_and_gate_match_oracle():
+    """K = 4 on the paths round 2 left to the two-branch form: the DDIM loop (fusion at times[-4] and kept apart), the x0
+    history of the DDPM loop (return_all_outputs) and the classifier gate with a K-branch redo, each against the
+    oracle's K-mask restatement on the host (which tests/test_oracle_golden.py pins to the reference for K = 2)."""
+    from oracle import diffusion_ref
+    H, B, K = 32, 2, 4
+    masks = torch.zeros(B, K, H, H)
+    for k in range(K):
+        masks[:, k, :, k * (H // K):(k + 1) * (H // K)] = 1.0
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 45, 1, 0.0, 2.0))
+
+    def oracle(gd, **kw):
+        sd = {k: v.detach().cpu() for k, v in gd.model.state_dict().items()}
+        o = diffusion_ref.SamplerOptions(branch_out=True, data="mri", mask_x=True, **kw)
+        ns = rng.NoiseStream(10)
+        return diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd, gd.model.cfg), o, 1, H), (lambda s: torch.from_numpy(ns.next(tuple(s))))
+    # DDIM, 10 of 50: fusion at times[-4], and never fused
+    for fuse in (True, False):
+        gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=2, mask_x=True), H, 50, 10)
+        got = run(gd, cond, masks, B)
+        smp, noise = oracle(gd, timesteps=50, sampling_timesteps=10, start_intermediate=fuse, start_timestep=2)
+        with torch.no_grad():
+            ref = smp.ddim_sample_kmask(cond, masks, (0.0, 2.0), (B, 1, H, H), noise, fuse, True)
+        ref = np.stack([t.numpy() for t in ref]) if isinstance(ref, list) else ref.numpy()
+        assert got.shape == ((B, 1, H, H) if fuse else (K, B, 1, H, H))
+        check(f"K-mask DDIM, K=4, fuse={fuse} vs oracle", got, ref)
+    # DDPM with the x0 history and the gate (stub classifier rejecting the first two fused predictions)
+    conf = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=6, mask_x=True, classifier=True)
+    gd = make(dict(mode="mri"), conf, H, 12)
+    gd.classifier = StubClassifier(2)
+    ret, x0s, _ = gd.sample(cond.cuda(), None, batch_size=B, mask=masks.cuda(), min_max_val=(0.0, 2.0), return_all_outputs=True)
+    smp, noise = oracle(gd, timesteps=12, start_intermediate=True, start_timestep=6, classifier=True)
+    stub = StubClassifier(2)
+    smp.classifier = lambda x0: stub(x0.cuda())
+    with torch.no_grad():
+        rret, rx0s, _ = smp.p_sample_loop_kmask(cond, masks, (0.0, 2.0), (B, 1, H, H), noise, True, True, return_all_outputs=True)
+    assert gd.classifier.calls == stub.calls and len(x0s) == len(rx0s) == 12
+    check("K-mask gate, K=4, final vs oracle", ret.cpu().numpy(), rret.numpy())
+    for i, (a, b) in enumerate(zip(x0s, rx0s)):
+        if isinstance(b, list):
+            assert isinstance(a, list) and len(a) == K
+            check(f"K-mask x0 history, branch step {i}", np.stack([u.numpy() for u in a]), np.stack([u.numpy() for u in b]))
+        else:
+            check(f"K-mask x0 history, step {i}", a.numpy(), b.numpy())
 
 
 class StubClassifier:
@@ -285,7 +376,8 @@ def test_branch_phase_as_concurrent_sub_batches(dtype, tol, fuse):
     cond = torch.from_numpy(rng.uniform((B, 1, H, H), 6, 1, 0.0, 2.0))
     mask = torch.zeros(B, 1, H, H)
     mask[:, :, :, :H // 4] = 1.0
-    gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=3, mask_x=True),
+    gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=3, mask_x=True,
+                                     ood_AD=True),          # ood_AD re-arms mask_x at every call (ddpm.py:1106-1108)
               H, 14, dtype=dtype)
     gd.noise_source = "device"
     gd.sub_batches = 1
@@ -309,8 +401,8 @@ def test_ddim_branch_phase_as_concurrent_sub_batches(dtype, tol, fuse, S, T):
     mask = torch.zeros(B, 1, H, H)
     mask[:, :, H // 4: H // 2, H // 4: H // 2] = 1.0
     for eta in (0.0, 0.5):
-        gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=2, mask_x=True),
-                  H, T, S, dtype=dtype)
+        gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=2, mask_x=True,
+                                         ood_AD=True), H, T, S, dtype=dtype)
         gd.ddim_sampling_eta = eta
         gd.noise_source = "device"
         gd.sub_batches = 1
@@ -349,7 +441,8 @@ def test_single_large_image_branches_run_as_sub_batches():
     yy, xx = np.mgrid[0:H, 0:H]
     mask = torch.from_numpy((((yy - H / 2) ** 2 + (xx - H / 2) ** 2) <= 64 ** 2).astype(np.float32))[None, None]
     cond = torch.from_numpy(rng.uniform((1, 1, H, H), 12, 1, 0.0, 2.0))
-    gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True), H, T)
+    gd = make(dict(mode="mri"), dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True,
+                                     ood_AD=True), H, T)
     gd.noise_source = "device"
     gd.sub_batches = 1
     single = run(gd, cond, mask, 1)
@@ -396,6 +489,55 @@ def test_cfg3_shape_sub_batches_and_batch_independence():
     gd.noise_source = lambda shape, k: torch.from_numpy(rng.randn((1,) + tuple(shape[1:]), 10, k)).expand(*shape)
     same = run(gd, cond[:1].repeat(4, 1, 1, 1), None, 4)
     assert float(np.abs(same - same[:1]).max()) == 0.0, "identical patches in one batch must give identical outputs"
+
+
+def test_cfg4_per_gpu_share_64_patches_runs_the_persistent_conv():
+    """BASELINE.json configs[3]'s per-GPU share at full size: 64 patches of 3x256x256 (8 images x 8 band masks), bf16,
+    as the bench's `--patches 64` runs them -- two concurrent sub-batches of 32, whose 32->32 @256^2 convolutions are
+    8,192-tile launches of the PERSISTENT LDS-DMA kernel (conv3x3_c32.hip), a launch mix the cfg3 timed region never
+    sees.  Size-independent properties: two sub-batches of 32 == one batch of 64 within the bf16 bound; the first
+    sub-batch == a plain batch of its 32 patches bit for bit; a replay is bitwise equal; and the launch counters show
+    that the persistent kernel ran."""
+    from localdiffusion_hallucination_amd import _cabi as cabi
+    H, B, T = 256, 64, 6
+    net = ldh.Unet(dim=32, init_dim=32, channels=3, out_dim=3, mode="mvtec", compute_dtype="bf16")
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()})
+    cfg = dict(branch_out=False, start_intermediate=False, start_timestep=2, data="mvtec", mask_x=False, mask_cond=False,
+               ood_AD=False, ood_confidence=False, classifier=False, use_gt=False, use_gt_timestep=100)
+    gd = ldh.GaussianDiffusion(cfg, net, image_size=H, timesteps=T, beta_schedule="sigmoid", objective="pred_x0",
+                               auto_normalize=False).to("cuda")
+    gd.noise_source = "device"
+    # 8 images x 8 band masks, per-patch conditioning as bench.py builds it (ddpm.py:677-688)
+    K = 8
+    masks = torch.zeros(K, 1, H, H)
+    for k in range(K):
+        masks[k, :, :, k * (H // K):(k + 1) * (H // K)] = 1.0
+    imgs = torch.from_numpy(rng.uniform((B // K, 3, H, H), 64, 1, 0.0, 2.0))
+    cond = torch.stack([imgs[i] * (masks[k] if k == 0 else torch.clip(masks[k], 0.95, 1.0))
+                        for i in range(B // K) for k in range(K)])
+    c32_before = cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32)
+    gd.sub_batches = 1
+    single = run(gd, cond, None, B)
+    assert cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32) > c32_before, "one batch of 64 did not use the persistent conv"
+    gd.sub_batches, gd.min_sub_batch = 2, 4
+    c32_before = cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32)
+    split = run(gd, cond, None, B)
+    sub = gd._subs[(id(net.plan(B, H, H, table_T=T)), 2)]
+    assert sub.b == 32 and len(sub.plans) == 2
+    assert cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32) > c32_before, "the 32-patch sub-batches did not use the persistent conv"
+    fams = [m.get("family", "") for m in sub.plans[0].meta.values()]
+    assert sum(f.startswith("conv3x3_c32") for f in fams) == 8, fams           # the eight 32->32 @256^2 convolutions
+
+    def close(tag, x, y):
+        d = np.abs(x - y)
+        print(f"{tag}: mean-abs {d.mean():.3e}  max-abs {d.max():.3e}")
+        assert d.mean() <= 2e-2 and d.max() <= 0.2, (tag, float(d.mean()), float(d.max()))
+    close("cfg4 share, two sub-batches of 32 vs one batch of 64", split, single)
+    assert np.isfinite(split).all() and split.min() >= 0.0 and split.max() <= 2.0
+    assert np.array_equal(run(gd, cond, None, B), split), "replay of the captured sub-batch graphs is not bitwise equal"
+    gd.sub_batches = 1
+    first32 = run(gd, cond[:32], None, 32)
+    assert np.array_equal(first32, split[:32]), float(np.abs(first32 - split[:32]).max())
 
 
 def test_cfg5_shape_ddim_branch_fusion_matches_oracle():
@@ -465,7 +607,7 @@ def test_cfg5_as_stated_fp16_ddim50_branch_fusion():
     yy, xx = np.mgrid[0:H, 0:H]
     mask = torch.from_numpy((((yy - H / 2) ** 2 + (xx - H / 2) ** 2) <= 64 ** 2).astype(np.float32))[None, None]
     cond = torch.from_numpy(rng.uniform((1, 1, H, H), 12, 1, 0.0, 2.0))
-    conf = dict(branch_out=True, start_intermediate=True, start_timestep=2, data="mri", mask_x=True)
+    conf = dict(branch_out=True, start_intermediate=True, start_timestep=2, data="mri", mask_x=True, ood_AD=True)
     out = {}
     for dtype in ("fp32", "fp16"):
         gd = make(kw, conf, H, T, S, dtype=dtype)

@@ -214,10 +214,10 @@ def test_kmask_generalisation_reduces_to_the_reference_for_two_branches(golden):
         mask[:, :, :, :H // 4] = 1.0
         masks = torch.cat([mask, 1.0 - (mask >= 1.0).float()], 1)
         o = diffusion_ref.SamplerOptions(timesteps=50, branch_out=True, start_intermediate=True, start_timestep=2, data=data, mask_x=True)
-        smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(cfg), cfg), o, 1, H)
+        fresh = lambda: diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(cfg), cfg), o, 1, H)   # mask_x carries over
         with torch.no_grad():
-            out = smp.p_sample_loop_kmask(cond, masks, (0.0, 2.0), (2, 1, H, H), Noise(), True, True)
-            two = smp.sample(cond, mask, (0.0, 2.0), 2, Noise())
+            out = fresh().p_sample_loop_kmask(cond, masks, (0.0, 2.0), (2, 1, H, H), Noise(), True, True)
+            two = fresh().sample(cond, mask, (0.0, 2.0), 2, Noise())
         assert torch.equal(out, two), tag                                  # same operations: bit-equal to the 2-branch oracle
         np.testing.assert_allclose(out.numpy(), g[tag + "_final"], atol=1e-6, rtol=0)    # and that is the reference golden
     g3 = golden("g3_three_step")
@@ -230,6 +230,56 @@ def test_kmask_generalisation_reduces_to_the_reference_for_two_branches(golden):
     np.testing.assert_allclose(out.numpy(), g3["branch_nofuse"], atol=1e-6, rtol=0)
 
 
+def test_kmask_ddim_histories_and_gate_reduce_to_the_reference_for_two_branches(golden):
+    """Round 3: the K-mask forms of the DDIM loop, of return_all_outputs and of the classifier gate, run with K = 2 and
+    masks [m, 1 - (m >= 1)], are the reference's two-branch paths bit for bit: G7 (DDIM 50 of 1000, fusion; DDIM 10
+    of 50 kept apart), G10 (history of a branch + fusion run), G9 (gate with a rejecting stub classifier)."""
+    g = golden("g7_ddim")
+    mask = torch.from_numpy(g["mask"])
+    H = mask.shape[-1]
+    cond = torch.from_numpy(rng.uniform((1, 1, H, H), 7, 1, 0.0, 2.0))
+    masks = torch.cat([mask, 1.0 - (mask >= 1.0).float()], 1)
+    mk = lambda **kw: diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(CFG_MRI), CFG_MRI),
+                                               diffusion_ref.SamplerOptions(data="mri", branch_out=True, mask_x=True, **kw), 1, H)
+    with torch.no_grad():
+        out = mk(timesteps=1000, sampling_timesteps=50, start_intermediate=True, start_timestep=2).ddim_sample_kmask(
+            cond, masks, (0.0, 2.0), (1, 1, H, H), Noise(), True, True)
+        np.testing.assert_allclose(out.numpy(), g["fused_final"], atol=1e-6, rtol=0)
+        out = mk(timesteps=50, sampling_timesteps=10, start_intermediate=False).ddim_sample_kmask(
+            cond, masks, (0.0, 2.0), (1, 1, H, H), Noise(), False, True)
+        np.testing.assert_allclose(np.stack([t.numpy() for t in out]), g["nofuse_final"], atol=1e-6, rtol=0)
+    # classifier gate (G9) and the x0 history: K = 2 == the two-branch oracle, which is pinned to the reference
+    g9 = golden("g9_classifier_gate")
+    cond, mask = torch.from_numpy(g9["cond32"]), torch.from_numpy(g9["mask32"])
+    masks = torch.cat([mask, 1.0 - (mask >= 1.0).float()], 1)
+
+    class Stub:
+        def __init__(self, reject):
+            self.reject, self.calls = reject, 0
+
+        def __call__(self, x0):
+            self.calls += 1
+            return (torch.tensor(-1.0 if self.calls <= self.reject else 1.0), None, None)
+    o = diffusion_ref.SamplerOptions(timesteps=12, branch_out=True, start_intermediate=True, start_timestep=7, data="mri",
+                                     mask_x=True, classifier=True)
+    smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(CFG_MRI), CFG_MRI), o, 1, 32)
+    smp.classifier = Stub(3)
+    with torch.no_grad():
+        ret, x0s, _ = smp.p_sample_loop_kmask(cond, masks, (0.0, 2.0), (2, 1, 32, 32), Noise(), True, True, return_all_outputs=True)
+    np.testing.assert_allclose(ret.numpy(), g9["mri32_reject3_final"], atol=1e-6, rtol=0)
+    assert smp.classifier.calls == int(g9["mri32_reject3_calls"][0])
+    smp2 = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(CFG_MRI), CFG_MRI), o, 1, 32)
+    smp2.classifier = Stub(3)
+    with torch.no_grad():
+        ret2, x0s2, _ = smp2.sample(cond, mask, (0.0, 2.0), 2, Noise(), return_all_outputs=True)
+    assert torch.equal(ret, ret2) and len(x0s) == len(x0s2) == 12
+    for a, b in zip(x0s, x0s2):
+        if isinstance(b, list):
+            assert isinstance(a, list) and all(torch.equal(u, v) for u, v in zip(a, b))
+        else:
+            assert torch.equal(a, b)
+
+
 def test_reference_self_distance_fixture(golden):
     """G13: the real reference on ONE thread vs the all-cores golden G5 (same code, weights, noise): the reproducibility
     floor of the 1e-3 gate on cfg2.  The numbers are data (made in the build container); this checks they are what
@@ -240,3 +290,26 @@ def test_reference_self_distance_fixture(golden):
     assert 5e-7 < float(d["maxabs_t100"]) < 5e-6
     assert 1e-4 < float(d["maxabs_t0"]) < 1e-3
     assert abs(float(np.abs(d["final_1thread"] - g5["final"]).max()) - float(d["maxabs_t0"])) < 1e-9
+
+
+G14_CASES = [("ddpm_maskx", dict(mask_x=True), None, ("band", "band")),
+             ("ddpm_oodad", dict(ood_AD=True), None, ("band", "band")),
+             ("ddpm_ones_then_band", dict(mask_x=True), None, ("ones", "band")),
+             ("ddim_maskx", dict(mask_x=True), 10, ("band", "band")),
+             ("ddim_oodad", dict(ood_AD=True), 10, ("band", "band"))]
+
+
+@pytest.mark.parametrize("tag,kw,S,seq", G14_CASES)
+def test_consecutive_calls_carry_mask_x_like_the_reference(golden, tag, kw, S, seq):
+    """G14: two sample() calls on ONE object (ddpm.py:780-781, 1023-1024, 1093-1117).  With {mask_x: True, ood_AD:
+    False} the reference's second call leaves the OOD prediction unmasked; ood_AD re-arms the flag every call; the
+    all-ones fallback clears it for later calls."""
+    g = golden("g14_consecutive_calls")
+    cond, masks = torch.from_numpy(g["cond"]), {"band": torch.from_numpy(g["band"]), "ones": torch.ones(2, 1, 32, 32)}
+    o = diffusion_ref.SamplerOptions(timesteps=50, sampling_timesteps=S, branch_out=True, start_intermediate=True,
+                                     start_timestep=2, data="mri", **kw)
+    smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd_of(CFG_MRI), CFG_MRI), o, 1, 32)
+    for i, m in enumerate(seq):
+        with torch.no_grad():
+            out = smp.sample(cond, masks[m], (0.0, 2.0), 2, Noise(10)).numpy()
+        np.testing.assert_allclose(out, g[f"{tag}_call{i + 1}"], atol=2e-5, rtol=0)

@@ -732,6 +732,46 @@ def g13(ddpm):
     save("g13_cfg2_reference_self_distance", **out)
 
 
+def g14(ddpm):
+    """Two (or three) consecutive sample() calls on ONE GaussianDiffusion object.  The reference clears
+    config['mask_x'] at the fusion step (ddpm.py:780-781, 1023-1024) and in the all-ones fallback (:1114) and
+    re-arms it in sample() only under ood_AD / ood_confidence (:1106-1108), so with {mask_x: True, ood_AD: False}
+    the SECOND call runs its branch steps without masking the OOD prediction.  Every call gets a fresh portable
+    noise stream (DDPM re-seeds per call, :934; for DDIM that is this fixture's convention)."""
+    print("G14 consecutive sample() calls on one object (mask_x call state), DDPM and DDIM")
+    cfg, H, B = CFG_MRI, 32, 2
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 14, 1, 0.0, 2.0))
+    band, ones = band_mask(B, H, H // 4), torch.ones(B, 1, H, H)
+    out = {"cond": cond.numpy(), "band": band.numpy()}
+    fuse = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=2)
+    cases = [("ddpm_maskx", dict(fuse, mask_x=True), 50, None, [band, band]),
+             ("ddpm_oodad", dict(fuse, ood_AD=True), 50, None, [band, band]),
+             ("ddpm_ones_then_band", dict(fuse, mask_x=True), 50, None, [ones, band]),
+             ("ddim_maskx", dict(fuse, mask_x=True), 50, 10, [band, band]),
+             ("ddim_oodad", dict(fuse, ood_AD=True), 50, 10, [band, band])]
+    for tag, kw, T, S, masks in cases:
+        sd = sd_torch(cfg)
+        gd = _ref_diffusion(ddpm, base_config(**kw), build_reference_unet(ddpm, cfg, sd), H, T, "sigmoid", "pred_x0", S).eval()
+        smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd, cfg), opts_from(base_config(**kw), T, S), cfg.channels, H)
+        refs = []
+        for i, m in enumerate(masks):
+            with reference_run(PortableNoise(10)):
+                with torch.inference_mode():
+                    r = gd.sample(cond.clone(), None, batch_size=B, mask=m.clone(), min_max_val=(0.0, 2.0))
+            with torch.no_grad():
+                o = smp.sample(cond, m, (0.0, 2.0), B, PortableNoise(10))
+            compare(f"G14 {tag} call {i + 1}", r, o, 2e-5)
+            refs.append(to_np(r))
+            out[f"{tag}_call{i + 1}"] = to_np(r)
+        d = float(np.abs(refs[-1] - refs[0]).max()) if refs[-1].shape == refs[0].shape else float("nan")
+        print(f"    last call vs first call: max-abs {d:.3e}")
+        if tag.endswith("_maskx"):
+            assert d > 1e-3, "the second call should differ (mask_x is disarmed by the first call's fusion step)"
+        if tag.endswith("_oodad"):
+            assert d == 0.0, "ood_AD re-arms mask_x: both calls must agree"
+    save("g14_consecutive_calls", **out)
+
+
 def g0_inventory(ddpm):
     print("G0 parameter inventory")
     lines = []
@@ -754,7 +794,7 @@ def main():
     ddpm = import_reference()
     os.makedirs(GOLD, exist_ok=True)
     todo = [("G0", g0_inventory), ("G1", g1), ("G2", g2), ("G3", g3), ("G4", g4), ("G6", g6),
-            ("G7", g7), ("G8", g8), ("G9", g9), ("G10", g10), ("G12", g12), ("G5", g5), ("G11", g11), ("G13", g13)]
+            ("G7", g7), ("G8", g8), ("G9", g9), ("G10", g10), ("G12", g12), ("G14", g14), ("G5", g5), ("G11", g11), ("G13", g13)]
     only = set(filter(None, a.only.split(",")))
     for name, fn in todo:
         if only and name not in only:
