@@ -85,6 +85,7 @@ int ld_stream_wait_event(void* stream, void* ev);
  * graph capture counts once, its replays do not): lets a test assert WHICH kernel a shape ran on. */
 #define LD_COUNTER_CONV3X3_C32 0      /* ld_conv3x3 calls taken by the persistent LDS-DMA kernel (conv3x3_c32.hip) */
 #define LD_COUNTER_CONV3X3_GENERIC 1  /* ... by the register-staged generic kernel (conv3x3.hip) */
+#define LD_COUNTER_CONV3X3_WS 2       /* ... by the small-map weights-in-registers kernel (conv3x3_ws.hip) */
 #define LD_COUNTER_MAX 8
 long long ld_counter(int which);
 int ld_range_push(const char* name /* host string */);

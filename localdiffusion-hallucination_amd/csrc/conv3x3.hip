@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st);   // conv3x3_c32.hip
+int ld_conv3x3_ws_try(const ld_conv3x3_args* p, hipStream_t st);    // conv3x3_ws.hip
 
 namespace {
 
@@ -556,6 +557,10 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
     const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages
+    if (rc != 0) return rc < 0 ? rc : LD_OK;
+  }
+  {
+    const int rc = ld_conv3x3_ws_try(p, st);         // small maps, 64-256 input channels: weights in registers, K split over waves
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }
   ld_count(LD_COUNTER_CONV3X3_GENERIC);

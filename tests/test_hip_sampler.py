@@ -525,8 +525,9 @@ def test_cfg4_per_gpu_share_64_patches_runs_the_persistent_conv():
     sub = gd._subs[(id(net.plan(B, H, H, table_T=T)), 2)]
     assert sub.b == 32 and len(sub.plans) == 2
     assert cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32) > c32_before, "the 32-patch sub-batches did not use the persistent conv"
-    fams = [m.get("family", "") for m in sub.plans[0].meta.values()]
-    assert sum(f.startswith("conv3x3_c32") for f in fams) == 8, fams           # the eight 32->32 @256^2 convolutions
+    fams = [(m.get("family", ""), m.get("shape", "")) for m in sub.plans[0].meta.values()]
+    # the eight 32->32 @256^2 convolutions (at 32 patches per launch the four 32->32 @128^2 ones qualify as well)
+    assert sum(f.startswith("conv3x3_c32") and s == "32->32@256x256" for f, s in fams) == 8, fams
 
     def close(tag, x, y):
         d = np.abs(x - y)
