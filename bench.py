@@ -440,6 +440,7 @@ def main():
                                beta_schedule="sigmoid").to(dev)
     gd.noise_source = "device"
     gd.noise_offset = rank * a.patches * 3 * a.size * a.size     # every rank draws its own slice of the job's noise stream
+    gd.sub_cu_mask = os.environ.get("LD_BENCH_CU_MASK") or None      # experiments: "xcd" = each sub-batch stream owns four XCDs
     gd.use_graph = a.graph == 1          # HIP-graph replay of the reverse step (measured: no gain, the step is GPU-bound)
 
     masks = band_masks(P, H)

@@ -16,7 +16,7 @@ EPI_PLAIN, EPI_QKV_LINEAR, EPI_QKV_FULL, EPI_RMS_RES, EPI_RES, EPI_GN_TAIL = 0, 
 OBJ = {"pred_x0": 0, "pred_noise": 1, "pred_v": 2}
 SCHED_COLS = 8
 STAT_STRIPES = 16      # LD_STAT_STRIPES
-COUNTER_CONV3X3_C32, COUNTER_CONV3X3_GENERIC, COUNTER_CONV3X3_WS = 0, 1, 2
+COUNTER_CONV3X3_C32, COUNTER_CONV3X3_GENERIC = 0, 1
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 
@@ -60,6 +60,11 @@ _SIGS = {
     "ld_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "ld_event_destroy": (C.c_int, [vp]),
     "ld_stream_wait_event": (C.c_int, [vp, vp]),
+    "ld_stage_begin": (C.c_int, []),
+    "ld_stage_end": (C.c_int, [C.POINTER(vp), C.POINTER(C.c_int)]),
+    "ld_stage_ctl_bytes": (C.c_size_t, []),
+    "ld_stage_launch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_stage_destroy": (C.c_int, [vp]),
     "ld_counter": (C.c_longlong, [C.c_int]),
     "ld_range_push": (C.c_int, [C.c_char_p]),
     "ld_range_pop": (C.c_int, []),

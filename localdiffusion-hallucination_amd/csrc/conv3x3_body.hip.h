@@ -1,0 +1,408 @@
+// Device side of the 3x3 convolution (conv3x3.hip has the description, the launch heuristics and the C entry point):
+// the argument block, the tile function and its __global__ wrapper.  Included by conv3x3.hip and by stage.hip.
+#pragma once
+#include "common.hip.h"
+
+namespace {
+
+struct Conv3Dev {
+  SrcDev s[2];
+  int nsrc;
+  const void* w;
+  const float* bias;
+  void* out;
+  double* ostats;
+  int ogroups;
+  int B, H, W, Cout;
+  const int* t_ptr;
+  const void* addend;
+  int tiles_x;
+  int dbg;     // ablation switches (LD_CONV_DEBUG env, 0 in production): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
+};
+
+// LD_CONV_DEBUG=64: cycle stamps of one workgroup from the middle of the launch (tools/trace_conv.py)
+__device__ unsigned long long g_conv_trace[16];
+#define TR_STAMP(k) do { if ((DBG & 64) && tracing) tr_t[k] = __builtin_readcyclecounter(); } while (0)
+
+// SK ("split-K halves", bf16 small-map launches): a 512-thread workgroup whose two halves each own every other
+// K-chunk with their own staging buffers.  The barrier schedule is shared and the halves run it in opposite phase:
+// while one half waits for its loads, transforms and writes them to LDS, the other reads fragments and issues MFMAs,
+// so every SIMD holds two waves whose staging and matrix phases overlap (a 256-thread workgroup alone on a CU is one
+// dependent chain per SIMD with the matrix pipe 25 % busy, DESIGN finding 24).  The halves' partial sums meet in LDS.
+// RAW: no source carries a GroupNorm prologue (32 of the 45 launches of a cfg3 step: block1 convolutions, resampling
+// convolutions and the 32^2 block2 convolutions whose input a separate gn_apply pass materialised).  The staging code of
+// the general kernel tests `stats != nullptr` and the activation kind per fragment at run time; with one wave per SIMD
+// those scalar tests, branches and register copies sit on the chunk loop's critical path (DESIGN finding 42).
+// The kernel body as a device function of the (virtual) workgroup index: conv3x3_kernel calls it with its own index,
+// the persistent stage kernel (stage.hip) with the tiles it takes from its work counter.
+template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
+__device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, const int by, const int bz, const int gdx, const int gdz,
+                                             char* smem) {
+  constexpr int E = DT<T>::E, CK = DT<T>::CK;
+  constexpr int TR = 4 * NW, TC = 16, HR = TR + 2, HC = TC + 2;
+  constexpr int NPIX = HR * HC, NPIXP = (NPIX + 15) / 16 * 16, PLANE = NPIXP * 16;
+  constexpr int ITER = (NPIXP + 63) / 64;
+  constexpr int UNITS = 9 * MT * 64, WU = (UNITS + 255) / 256;
+  constexpr bool P = DT<T>::precise;
+
+  constexpr int STAGE = 4 * PLANE + 9 * MT * 1024;         // one half's staging buffers
+  const int half = SK ? (int)(threadIdx.x >> 8) : 0;       // wave-uniform
+  char* s_x = smem + half * STAGE;
+  char* s_w = s_x + 4 * PLANE;
+  float* s_coef = reinterpret_cast<float*>(smem + (SK ? 2 : 1) * STAGE);
+  const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
+  // fp64 scratch: [4 waves][2][16*MT] per-wave channel sums (also the stripe-reduction scratch of
+  // build_gn_coef, 32 doubles).  Per-lane/per-wave partials are fp32 over <= 16*NW values; every
+  // sum across waves and workgroups is fp64, so E[x^2]-mean^2 does not see fp32 partial-sum rounding.
+  double* s_stat = reinterpret_cast<double*>(s_coef + 2 * ctot);
+
+  const int tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;   // within the half
+  unsigned long long tr_t[16] = {0};
+  const bool tracing = (DBG & 64) && threadIdx.x == 0 && bz == gdz / 2 && by == 0 &&
+                       bx == (gdx * 5) / 8;
+  TR_STAMP(0);
+  const int b = bz, m0 = by * MT;
+  const int ty0 = (bx / a.tiles_x) * TR, tx0 = (bx % a.tiles_x) * TC;
+  const int H = a.H, W = a.W;
+  const int nch0 = a.s[0].C / CK;
+  const int nch = nch0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
+  const int mt_total = a.Cout / 16;
+  const uint4* wg = reinterpret_cast<const uint4*>(a.w);
+
+  // ---- register-staged pipeline (cdna_hip_programming.md T14): the global loads of chunk k+1
+  // (halo fragments + weight fragments) are issued before the MFMAs of chunk k and written to LDS
+  // after them, so a workgroup pays ONE exposed global round trip instead of one per chunk.
+  uint4 hxA[ITER], wxA[WU], hxB[DEEP ? ITER : 1], wxB[DEEP ? WU : 1];   // B set: prefetch distance 2 (DEEP)
+  // Loop-invariant addressing (with one wave per SIMD every VALU instruction in the chunk loop is on the
+  // critical path, PMC: MFMA busy ~20 % of wave cycles): per-thread element offsets of the halo pixels for
+  // both source geometries and of the weight units are computed once; a chunk only adds a scalar stride.
+  // Addresses are a workgroup-uniform 64-bit base (scalar registers) plus a non-negative 32-bit per-lane byte
+  // offset built from 24-bit multiplies: the first version spent ~1,500 VALU instructions per wave around 72 MFMAs
+  // (3.5k cycles of 64-bit / quarter-rate integer address arithmetic before the first load), which made the
+  // single-chunk launches instruction-issue-bound (in-kernel trace, tools/trace_conv.py).
+  unsigned hvalid = 0;                                  // bit it: halo item `it` is inside the image
+  unsigned hoffb0[ITER], hoffb1[ITER];                  // byte offsets from sbase0 / sbase1
+  const char* sbase0;
+  const char* sbase1;
+  {
+    auto src_base = [&](const SrcDev& S, unsigned (&hoffb)[ITER]) -> const char* {
+      const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
+      const int row0 = S.ups ? (ty0 - 1) >> 1 : ty0 - 1, col0 = S.ups ? (tx0 - 1) >> 1 : tx0 - 1;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int q = (it * 4 + wv) * 16 + px;
+        const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;        // q / 18 for q < 400
+        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
+        const int r = (S.ups ? gy >> 1 : gy) - row0, c = (S.ups ? gx >> 1 : gx) - col0;   // 0 .. HR, 0 .. HC
+        hoffb[it] = (__umul24(__umul24(r, Ws) + c, S.ld) + kq * E) * (unsigned)sizeof(T);
+      }
+      return reinterpret_cast<const char*>(S.data) + (((long)b * Hs + row0) * Ws + col0) * S.ld * (long)sizeof(T);
+    };
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int q = (it * 4 + wv) * 16 + px;
+      const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;
+      const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
+      if (q < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && !(DBG & 1)) hvalid |= 1u << it;
+    }
+    sbase0 = src_base(a.s[0], hoffb0);
+    sbase1 = sbase0;
+    if (a.nsrc > 1) sbase1 = src_base(a.s[1], hoffb1);
+    else {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) hoffb1[it] = hoffb0[it];
+    }
+  }
+  unsigned woffb[WU];                                   // byte offsets into a chunk's packed weights; ~0u = none
+#pragma unroll
+  for (int k = 0; k < WU; ++k) {
+    const int u = k * 256 + tid;
+    const int tap = u / (MT * 64), r = u - tap * (MT * 64);
+    woffb[k] = (u < UNITS && !(DBG & 2)) ? (__umul24(tap, mt_total) + m0) * 1024u + r * 16u : ~0u;
+  }
+  const long wstride = 9L * mt_total * 1024;            // bytes per chunk
+  auto issue_loads = [&](int ch, uint4 (&hx)[ITER], uint4 (&wx)[WU]) {
+    const int si = ch >= nch0 ? 1 : 0;
+    const char* sp = (si ? sbase1 : sbase0) + (long)(ch - si * nch0) * CK * (long)sizeof(T);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      hx[it] = make_uint4(0u, 0u, 0u, 0u);
+      if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sp + (si ? hoffb1[it] : hoffb0[it]));
+    }
+    const char* wc = reinterpret_cast<const char*>(wg) + (long)ch * wstride;
+#pragma unroll
+    for (int k = 0; k < WU; ++k) {
+      wx[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (woffb[k] != ~0u) wx[k] = *reinterpret_cast<const uint4*>(wc + woffb[k]);
+    }
+  };
+  auto write_lds = [&](int ch, const uint4 (&hx)[ITER], const uint4 (&wx)[WU]) {
+    const int si = ch >= nch0 ? 1 : 0;
+    const SrcDev S = si ? a.s[1] : a.s[0];
+    const int c0 = (ch - si * nch0) * CK;
+    const int coef_off = si ? 2 * a.s[0].C : 0;
+    const bool has_coef = !RAW && S.stats != nullptr;
+    // this thread always stages the same E channels of the chunk: keep their (a, s) in registers
+    float ca[E], cs[E];
+    if (has_coef) {
+      const float* cap = s_coef + coef_off + c0 + kq * E;
+#pragma unroll
+      for (int e = 0; e < E; ++e) { ca[e] = cap[e]; cs[e] = cap[S.C + e]; }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int q = (it * 4 + wv) * 16 + px;
+      if (q < NPIXP) {
+        uint4 raw = hx[it];
+        if (has_coef && ((hvalid >> it) & 1u)) {        // zero padding stays exactly zero
+          float v[E];
+          unpack16<T>(raw, v);
+          affine_act_n<P, E>(v, ca, cs, S.act);
+          raw = pack16<T>(v);
+        }
+        *reinterpret_cast<uint4*>(s_x + kq * PLANE + q * 16) = raw;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WU; ++k) {
+      const int u = k * 256 + tid;
+      if (u < UNITS) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wx[k];
+    }
+  };
+
+  TR_STAMP(1);
+  if (!SK || half < nch) issue_loads(half, hxA, wxA);     // half h owns chunks h, h+2, ...
+  TR_STAMP(2);
+  float4 bias[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + (m0 + m) * 16 + kq * 4);
+
+  // ---- prologue coefficients (overlaps the loads above)
+  {
+    const bool any = !RAW && (a.s[0].stats != nullptr || (a.nsrc > 1 && a.s[1].stats != nullptr));
+    if (any) {
+      const int trow = a.t_ptr ? *a.t_ptr : 0;
+      int off = 0;
+      for (int s = 0; s < a.nsrc; ++s) {
+        const SrcDev S = s ? a.s[1] : a.s[0];
+        if (S.stats) {
+          const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
+          build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, (int)threadIdx.x, SK ? 512 : 256);
+        }
+        off += 2 * S.C;
+      }
+    }
+  }
+
+  TR_STAMP(3);
+  f32x4 acc[MT][NW];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // LDS fragment reads are software-pipelined against the MFMAs: all fragments of tap column dx+1 (3*MT
+  // weight + NW+2 activation fragments) are requested before the MFMAs of column dx issue, so the ~100-cycle
+  // ds_read latency is paid once per chunk instead of once per activation fragment (PMC on 256->256@32^2:
+  // 38 % of wave cycles were s_waitcnt stalls with the read-then-use order).
+  auto compute = [&]() {
+    if (DBG & 4) return;
+    uint4 A[2][3][MT], Bq[2][NW + 2];
+    auto load_frags = [&](int dx, int set) {
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          A[set][dy][m] = *reinterpret_cast<const uint4*>(s_w + ((dy * 3 + dx) * MT + m) * 1024 + lane * 16);
+#pragma unroll
+      for (int rr = 0; rr < NW + 2; ++rr)
+        Bq[set][rr] = *reinterpret_cast<const uint4*>(s_x + kq * PLANE + (((wv * NW + rr) * HC + dx + px) * 16));
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      if (dx + 1 < 3) load_frags(dx + 1, (dx + 1) & 1);
+#pragma unroll
+      for (int rr = 0; rr < NW + 2; ++rr) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int j = rr - dy;
+          if (j >= 0 && j < NW) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[dx & 1][dy][m], Bq[dx & 1][rr]);
+          }
+        }
+      }
+    }
+  };
+  if constexpr (SK) {
+    for (int k = 0; k <= nch; ++k) {
+      __syncthreads();               // first time: coefficients visible; then: the other half's phase is complete
+      if ((k & 1) == half) {         // staging phase: chunk k (mine) into my buffers, request chunk k+2
+        if (k < nch) {
+          write_lds(k, hxA, wxA);
+          if (k + 2 < nch) issue_loads(k + 2, hxA, wxA);
+        }
+      } else if (k >= 1) {           // matrix phase: chunk k-1 (mine, staged in the previous interval)
+        compute();
+      }
+    }
+    // join the partial sums: half 1 -> LDS (its own staging buffers are dead) -> half 0
+    __syncthreads();
+    float4* s_red = reinterpret_cast<float4*>(smem + STAGE);
+    if (half == 1) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+          s_red[(m * NW + j) * 256 + tid] = make_float4(acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]);
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const float4 o = s_red[(m * NW + j) * 256 + tid];
+          acc[m][j][0] += o.x; acc[m][j][1] += o.y; acc[m][j][2] += o.z; acc[m][j][3] += o.w;
+        }
+    }
+  } else if constexpr (!DEEP) {
+    for (int ch = 0; ch < nch; ++ch) {
+      __syncthreads();               // previous chunk fully consumed (first time: coefficients visible)
+      if (ch == 0) TR_STAMP(4);
+      if (ch == 2) TR_STAMP(11);     // 11..15: one steady-state chunk (tools/trace_conv.py)
+      write_lds(ch, hxA, wxA);
+      if (ch == 0) TR_STAMP(5);
+      if (ch == 2) TR_STAMP(12);
+      __syncthreads();
+      if (ch == 0) TR_STAMP(6);
+      if (ch == 2) TR_STAMP(13);
+      if (ch + 1 < nch) issue_loads(ch + 1, hxA, wxA);
+      if (ch == 2) TR_STAMP(14);
+      compute();
+      if (ch == 0) TR_STAMP(7);
+      if (ch == 2) TR_STAMP(15);
+    }
+    TR_STAMP(8);
+  } else {
+    // prefetch distance 2 with two register sets (the launches that use this variant run one wave per SIMD,
+    // so the 512-entry register file is theirs): chunk k+2 is requested before chunk k is computed
+    if (nch > 1) issue_loads(1, hxB, wxB);
+    for (int ch = 0; ch < nch; ch += 2) {
+      __syncthreads();
+      write_lds(ch, hxA, wxA);
+      __syncthreads();
+      if (ch + 2 < nch) issue_loads(ch + 2, hxA, wxA);
+      compute();
+      if (ch + 1 < nch) {
+        __syncthreads();
+        write_lds(ch + 1, hxB, wxB);
+        __syncthreads();
+        if (ch + 3 < nch) issue_loads(ch + 3, hxB, wxB);
+        compute();
+      }
+    }
+  }
+
+  // ---- epilogue: bias, statistics, NHWC store.  lane holds channels 16m+4kq..+3 of pixel px.
+  const int gx = tx0 + px;
+  // uniform base of the tile + one 32-bit lane offset; rows and m-tiles add constants
+  const long obase = (((long)b * H + ty0) * W + tx0) * a.Cout + m0 * 16;
+  char* outb = reinterpret_cast<char*>(a.out) + obase * (long)sizeof(T);
+  const char* addb = reinterpret_cast<const char*>(a.addend) + obase * (long)sizeof(T);
+  const unsigned lane_off = (__umul24(__umul24(wv * NW, W) + px, a.Cout) + kq * 4) * (unsigned)sizeof(T);
+  const unsigned row_off = __umul24(W, a.Cout) * (unsigned)sizeof(T);
+  float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const float4 bv = bias[m];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int gy = ty0 + wv * NW + j;
+      const bool valid = gy < H && gx < W && half == 0;   // (SK: half 0 holds the joined sums)
+      const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
+      float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
+      if (valid && a.addend) {
+        float ad[4];
+        load4<T>(reinterpret_cast<const T*>(addb + off), ad);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += ad[r];
+      }
+      if (valid) {
+        if (!(DBG & 8)) store4<T>(reinterpret_cast<T*>(outb + off), v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
+      }
+    }
+  }
+  TR_STAMP(9);
+  if (a.ostats) {
+    __syncthreads();                            // s_stat may still be read as build_gn_coef scratch
+    const int gs = a.Cout / a.ogroups;          // channels per group; gs <= 16*MT by construction
+    const int ngrp_blk = (16 * MT) / gs;
+    const int stripe = bx % LD_STAT_STRIPES;
+    if (!P && (gs & 3) == 0) {
+      // a lane's four channels (4kq .. 4kq+3 of m-tile m) always fall into ONE group when gs is a multiple of 4:
+      // add them before the cross-lane reduction -- 4*MT row reductions and LDS values per wave instead of 16*MT
+      // (the statistics were 20 % of a workgroup's cycles, tools/trace_conv.py).  bf16 storage only: the fp32
+      // path keeps its short fp32 partial sums.
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float s1 = wave16_sum((ssum[m][0] + ssum[m][1]) + (ssum[m][2] + ssum[m][3]));
+        const float s2 = wave16_sum((ssq[m][0] + ssq[m][1]) + (ssq[m][2] + ssq[m][3]));
+        if (px == 0 && half == 0) {
+          s_stat[(wv * 2 + 0) * 4 * MT + m * 4 + kq] = (double)s1;
+          s_stat[(wv * 2 + 1) * 4 * MT + m * 4 + kq] = (double)s2;
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * ngrp_blk && half == 0) {
+        const int gi = tid >> 1, k = tid & 1, q4 = gs >> 2;
+        double acc1 = 0.0;
+        for (int w4 = 0; w4 < 4; ++w4)
+          for (int c = 0; c < q4; ++c) acc1 += s_stat[(w4 * 2 + k) * 4 * MT + gi * q4 + c];
+        const int g = (m0 * 16) / gs + gi;
+        atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + g) * 2 + k], acc1);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s1 = wave16_sum(ssum[m][r]), s2 = wave16_sum(ssq[m][r]);
+          if (px == 0 && half == 0) {
+            s_stat[(wv * 2 + 0) * 16 * MT + m * 16 + kq * 4 + r] = (double)s1;
+            s_stat[(wv * 2 + 1) * 16 * MT + m * 16 + kq * 4 + r] = (double)s2;
+          }
+        }
+      __syncthreads();
+      if (tid < 2 * ngrp_blk && half == 0) {
+        const int gi = tid >> 1, k = tid & 1;
+        double acc1 = 0.0;
+        for (int w4 = 0; w4 < 4; ++w4)
+          for (int c = 0; c < gs; ++c) acc1 += s_stat[(w4 * 2 + k) * 16 * MT + gi * gs + c];
+        const int g = (m0 * 16) / gs + gi;
+        atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + g) * 2 + k], acc1);
+      }
+    }
+  }
+  if ((DBG & 64) && tracing) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores have left
+    tr_t[10] = __builtin_readcyclecounter();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g_conv_trace[k] = tr_t[k];
+  }
+}
+
+template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
+__global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(SK ? 2 : (MT == 2 ? 3 : 1), SK ? 2 : (MT == 2 ? 3 : 2)))) void conv3x3_kernel(Conv3Dev a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  conv3x3_tile<T, MT, NW, DEEP, DBG, SK, RAW>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z, smem);
+}
+
+}  // namespace

@@ -1,0 +1,103 @@
+// Device side of gn_apply (gn_apply.hip has the description and the C entry point).  Included by gn_apply.hip and stage.hip.
+#pragma once
+#include "common.hip.h"
+
+namespace {
+struct GnDev {
+  SrcDev a, b;
+  int has_b, final_act, pool;
+  void* out;
+  int B, H, W;
+  const int* t_ptr;
+};
+
+// HAS_B / POOL are template parameters and, when the fragments-per-pixel count divides the block size, every
+// thread owns ONE channel fragment for the whole launch: its coefficients live in registers and the pixel index
+// advances by a constant -- no 64-bit division, no LDS coefficient reads and no feature branches in the
+// streaming loop (measured on the generic loop: 8-10 us for 8 MB launches whose traffic is worth 3 us).
+template <typename T, bool HAS_B>
+__device__ __forceinline__ void eval_pixel(const GnDev& g, const float* ca, const float* sa, const float* cb, const float* sb,
+                                           size_t elem, float* v) {
+  constexpr int E = DT<T>::E;
+  constexpr bool P = DT<T>::precise;
+  const T* xa = reinterpret_cast<const T*>(g.a.data);
+  uint4 ra = *reinterpret_cast<const uint4*>(xa + elem);
+  uint4 rb = make_uint4(0u, 0u, 0u, 0u);
+  if (HAS_B) rb = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.b.data) + elem);
+  unpack16<T>(ra, v);
+  affine_act_n<P, E>(v, ca, sa, g.a.act);
+  if (HAS_B) {
+    float u[E];
+    unpack16<T>(rb, u);
+    if (g.b.stats) affine_act_n<P, E>(u, cb, sb, g.b.act);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] += u[e];
+  }
+  act_n<P, E>(v, g.final_act);
+}
+
+// The kernel body as a device function of the (virtual) workgroup index (gn_apply_kernel: its own index; stage.hip: the
+// blocks a persistent workgroup takes from its work counter).  bx / gdx: block and number of blocks of image `b`.
+template <typename T, bool HAS_B, bool POOL>
+__device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, const int gdx, const int b, float* s_coef) {
+  constexpr int E = DT<T>::E;
+  const int C = g.a.C, tid = threadIdx.x;
+  const int trow = g.t_ptr ? *g.t_ptr : 0;
+  const long npix_in = (long)g.H * g.W;
+  double* red = reinterpret_cast<double*>(s_coef + 4 * C);
+  build_gn_coef(g.a, b, trow, npix_in, s_coef, red, tid, 256);
+  if (HAS_B && g.b.stats) build_gn_coef(g.b, b, trow, npix_in, s_coef + 2 * C, red, tid, 256);
+  const int fpp = C / E;                               // fragments per pixel
+  const int Ho = POOL ? g.H / 2 : g.H, Wo = POOL ? g.W / 2 : g.W;
+  const int npix_out = Ho * Wo;
+  T* out = reinterpret_cast<T*>(g.out) + (size_t)b * npix_out * C;
+  const size_t in0 = (size_t)b * npix_in * C;
+  auto one = [&](int opix, int c, const float* ca, const float* sa, const float* cb, const float* sb) {
+    float v[E];
+    if (!POOL) {
+      eval_pixel<T, HAS_B>(g, ca, sa, cb, sb, in0 + (size_t)opix * C + c, v);
+    } else {
+      const int oy = opix / Wo, ox = opix - oy * Wo;
+      float u[E];
+      eval_pixel<T, HAS_B>(g, ca, sa, cb, sb, in0 + ((size_t)(2 * oy) * g.W + 2 * ox) * C + c, v);
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        eval_pixel<T, HAS_B>(g, ca, sa, cb, sb, in0 + ((size_t)(2 * oy + (k >> 1)) * g.W + 2 * ox + (k & 1)) * C + c, u);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = fmaxf(v[e], u[e]);
+      }
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)opix * C + c) = pack16<T>(v);
+  };
+  if (256 % fpp == 0) {
+    const int c = (tid % fpp) * E, ppb = 256 / fpp;    // pixels per block-iteration
+    float ca[E], sa[E], cb[E], sb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      ca[e] = s_coef[c + e]; sa[e] = s_coef[C + c + e];
+      cb[e] = HAS_B ? s_coef[2 * C + c + e] : 0.f; sb[e] = HAS_B ? s_coef[3 * C + c + e] : 0.f;
+    }
+    const int step = gdx * ppb;
+    int opix = bx * ppb + tid / fpp;
+    // two pixels per iteration: both fragments' loads are in flight before the first is consumed
+    for (; opix + step < npix_out; opix += 2 * step) {
+      one(opix, c, ca, sa, cb, sb);
+      one(opix + step, c, ca, sa, cb, sb);
+    }
+    if (opix < npix_out) one(opix, c, ca, sa, cb, sb);
+  } else {
+    const int nfrag = npix_out * fpp;
+    for (int f = bx * 256 + tid; f < nfrag; f += gdx * 256) {
+      const int opix = f / fpp, c = (f - opix * fpp) * E;
+      one(opix, c, s_coef + c, s_coef + C + c, s_coef + 2 * C + c, s_coef + 3 * C + c);
+    }
+  }
+}
+
+template <typename T, bool HAS_B, bool POOL>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnDev g) {
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];   // [2C] for a, [2C] for b
+  gn_apply_tile<T, HAS_B, POOL>(g, blockIdx.x, gridDim.x, blockIdx.y, s_coef);
+}
+
+}  // namespace

@@ -87,6 +87,8 @@ class _SubBatches:
         # plans are cached per shape: instances 1..S of this batch size belong to the sub-batch runners
         self.plans = [gd.model.plan(self.b, H, W, table_T=gd.num_timesteps_ori, instance=instance_base + i + 1)
                       for i in range(S)]
+        for i, sp in enumerate(self.plans):        # stage programs: the sub-batches settle on disjoint halves of the XCDs
+            sp.xcd_base = (4 * i) % 8
         self.streams = gd._sub_streams(S)
         self.shared_noise = shared_noise
         self.masks = {i: torch.ones(self.b, H * W, dtype=torch.float32, device=jp.x_in.device) for i in masked}
@@ -242,6 +244,8 @@ class _DdimBranches:
         self.gd, self.B, self.mask_x, self.shared = gd, B, mask_x and shared, shared
         dev = gd.device
         self.plans = [gd.model.plan(B, H, W, table_T=gd.num_timesteps_ori, instance=200 + i) for i in range(2)]
+        for i, sp in enumerate(self.plans):
+            sp.xcd_base = 4 * i
         self.streams = gd._sub_streams(2)
         self.idx = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
         self.times = torch.tensor(times, dtype=torch.int32, device=dev)

@@ -73,58 +73,6 @@ def test_conv3x3_gn_film_prologue(dtype, act, groups, use_film):
     assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
 
 
-@pytest.mark.parametrize("dtype", LOWP)
-@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 256, 256, 32, 32), (3, 128, 128, 32, 32), (1, 64, 64, 64, 64), (2, 128, 256, 16, 32),
-                                            (1, 256, 32, 8, 16), (2, 64, 96, 24, 48)])
-def test_conv3x3_ws_small_map_kernel(dtype, B, cin, cout, H, W):
-    """conv3x3_ws.hip (weights in registers, whole K in LDS, K split over the waves of a workgroup): the launches of
-    the 32^2 / 64^2 stages -- plain with statistics, with an addend, with a nearest-x2 upsampled source, and with the
-    GroupNorm + FiLM + SiLU prologue applied in place in LDS -- against F.conv2d, and the counters show it ran."""
-    lib = cabi.lib()
-    n0 = lib.ld_counter(cabi.COUNTER_CONV3X3_WS)
-    x, w, b = _q(hh.rand((B, cin, H, W), 1), dtype), _q(hh.rand((cout, cin, 3, 3), 2, -0.05, 0.05), dtype), hh.rand((cout,), 3)
-    ref = F.conv2d(x, w, b, padding=1)
-    groups = 8
-    stats = hh.stats_buffer(B, groups)
-    wp = hh.pack(w, dtype, 3)
-    out = hh.conv3x3([hh.make_src(hh.nhwc(x, dtype), cin)], wp, b.to(hh.DEV), B, H, W, cout, dtype, stats=stats, groups=groups)
-    assert lib.ld_counter(cabi.COUNTER_CONV3X3_WS) == n0 + 1, "the small-map kernel did not take the launch"
-    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
-    assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, groups)) < 1e-2
-    # replay: bitwise (the K-slices are joined in a fixed order)
-    out2 = hh.conv3x3([hh.make_src(hh.nhwc(x, dtype), cin)], wp, b.to(hh.DEV), B, H, W, cout, dtype)
-    assert torch.equal(out, out2)
-    # addend (conv_fusion's precomputed conditioning half enters before the statistics)
-    ad = _q(hh.rand((B, cout, H, W), 4), dtype)
-    a = cabi.Conv3x3Args()
-    a.src[0] = hh.make_src(hh.nhwc(x, dtype), cin)
-    a.nsrc = 1
-    bd, adn = b.to(hh.DEV), hh.nhwc(ad, dtype)
-    o3 = torch.empty(B, H, W, cout, dtype=hh.TDT[dtype], device=hh.DEV)
-    st3 = hh.stats_buffer(B, groups)
-    a.weight, a.bias, a.out, a.addend = wp.data_ptr(), bd.data_ptr(), o3.data_ptr(), adn.data_ptr()
-    a.out_stats, a.out_groups = st3.data_ptr(), groups
-    a.B, a.H, a.W, a.Cout, a.dtype = B, H, W, cout, cabi.dtype_code(dtype)
-    cabi.check(lib.ld_conv3x3(C.byref(a), hh.st()), "conv3x3")
-    assert hh.rel_err(hh.nchw(o3), ref + ad) < hh.RTOL[dtype]
-    assert hh.rel_err(st3.sum(1).cpu(), hh.gn_stats_ref(ref + ad, groups)) < 1e-2
-    # nearest-x2 upsampled source (Upsample, ddpm.py:114-118)
-    xs = _q(hh.rand((B, cin, H // 2, W // 2), 5), dtype)
-    refu = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w, b, padding=1)
-    ou = hh.conv3x3([hh.make_src(hh.nhwc(xs, dtype), cin, ups=1)], wp, b.to(hh.DEV), B, H, W, cout, dtype)
-    assert hh.rel_err(hh.nchw(ou), refu) < hh.RTOL[dtype]
-    # GroupNorm + FiLM + SiLU prologue of the producer, applied in LDS
-    xg = _q(hh.rand((B, cin, H, W), 8, -2.0, 3.0), dtype)
-    gamma, beta, film = hh.rand((cin,), 9, 0.5, 1.5), hh.rand((cin,), 10, -0.3, 0.3), hh.rand((B, 2 * cin), 11, -0.5, 0.5)
-    y = F.group_norm(xg, groups, gamma, beta, eps=1e-5) * (film[:, :cin, None, None] + 1) + film[:, cin:, None, None]
-    refg = F.conv2d(F.silu(y), w, b, padding=1)
-    src = hh.make_src(hh.nhwc(xg, dtype), cin, gn=(hh.stats_striped(xg, groups), gamma.to(hh.DEV), beta.to(hh.DEV), groups),
-                      act=cabi.ACT_SILU, film=film.to(hh.DEV), film_b=2 * cin)
-    og = hh.conv3x3([src], wp, b.to(hh.DEV), B, H, W, cout, dtype)
-    assert hh.rel_err(hh.nchw(og), refg) < hh.RTOL[dtype] * 2
-    assert lib.ld_counter(cabi.COUNTER_CONV3X3_WS) == n0 + 5
-
-
 # ------------------------------------------------------------------------------ conv1x1
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 32, 16, 16), (1, 384, 256, 8, 8), (1, 96, 64, 14, 14),

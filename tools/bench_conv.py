@@ -33,7 +33,7 @@ def bench(B, cin, cout, H, W, dtype="bf16", stats=False, reps=50, prologue=False
 if __name__ == "__main__":
     shapes = [(8, 32, 32, 256, 256), (8, 64, 32, 256, 256), (8, 32, 32, 128, 128), (8, 64, 64, 128, 128),
               (8, 64, 64, 64, 64), (8, 128, 128, 64, 64), (8, 128, 128, 32, 32), (8, 256, 256, 32, 32), (8, 512, 256, 32, 32)]
-    print("NO_WS", os.environ.get("LD_CONV_NO_WS", "-"), "MT", os.environ.get("LD_CONV_MT", "-"), "NW", os.environ.get("LD_CONV_NW", "-"), "NO_C32", os.environ.get("LD_CONV_NO_C32", "-"), "DB", os.environ.get("LD_CONV_DB", "-"))
+    print("KSPLIT", os.environ.get("LD_CONV_KSPLIT", "-"), "MT", os.environ.get("LD_CONV_MT", "-"), "NW", os.environ.get("LD_CONV_NW", "-"), "NO_C32", os.environ.get("LD_CONV_NO_C32", "-"), "DB", os.environ.get("LD_CONV_DB", "-"))
     sel = shapes[:3] if not os.environ.get("LD_BENCH_SMALL") else shapes[3:]
     if os.environ.get("LD_BENCH_SHAPES"):          # "B,cin,cout,H,W;B,cin,cout,H,W;..."
         sel = [tuple(int(v) for v in t.split(",")) for t in os.environ["LD_BENCH_SHAPES"].split(";")]
