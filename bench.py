@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5"],
                     help="cfg3 (default, the headline metric) | cfg5: BASELINE configs[4] as stated -- one 1x512x512 image per GPU, "
                          "DDIM 50 of 1000 steps, OOD/IND branches with a circular mask, fusion at times[-4]; reports images/s")
+    ap.add_argument("--weight-split-levels", type=int, default=0,
+                    help="two-term (hi + lo) convolution weights on the first N resolution levels (accuracy mode, DESIGN section 2); "
+                         "the default line is measured with 0 and reports the cost of 2 in `two_term_weights`")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the reverse step from a captured HIP graph (default: eager launches)")
     a = ap.parse_args()
     if a.dtype is None:
@@ -434,6 +437,7 @@ def main():
     sd = {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()}
     net.load_state_dict(sd)
     net = net.to(dev)
+    net.set_weight_split_levels(a.weight_split_levels)
     config = dict(branch_out=False, start_intermediate=False, start_timestep=2, data="mvtec", mask_x=False,
                   ood_AD=False, ood_confidence=False, classifier=False, use_gt=False)
     gd = ldh.GaussianDiffusion(config, net, image_size=H, timesteps=T_STEPS, objective="pred_x0",
@@ -523,7 +527,8 @@ def main():
                    # regime, _SubBatches), as ONE replayed graph of the whole batch (--graph 1), or eagerly
                    "step_graph_replay": bool(gd.timed_plan(jp) is not jp or gd.use_graph),
                    "whole_batch_graph_flag": bool(gd.use_graph),
-                   "concurrent_sub_batches": (gd.sub_batches if gd.timed_plan(jp) is not jp else 1)},
+                   "concurrent_sub_batches": (gd.sub_batches if gd.timed_plan(jp) is not jp else 1),
+                   "weight_split_levels": a.weight_split_levels},
     }
 
     if rank == 0 and not a.no_roofline:
@@ -538,6 +543,14 @@ def main():
         out["other_dtype"] = {"dtype": other, "value": P * k2 / (T_STEPS * e2), "unit": "patches/s", "steps": k2,
                               "ms_per_step": 1e3 * e2 / k2}
         net.set_compute_dtype(a.dtype)
+        if a.weight_split_levels == 0:
+            # the accuracy mode: two-term weights on the full- and half-resolution layers (the weight rounding of those
+            # layers is what separates a 16-bit chain from the fp32 reference: 4x closer at t = 100 for this cost)
+            net.set_weight_split_levels(2)
+            e3, _, _ = measure(k2, min(a.warmup, 10))
+            out["two_term_weights"] = {"levels": 2, "dtype": a.dtype, "value": P * k2 / (T_STEPS * e3), "unit": "patches/s",
+                                       "steps": k2, "ms_per_step": 1e3 * e3 / k2}
+            net.set_weight_split_levels(0)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:        # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(net.cfg, sd, H)
     if rank == 0:

@@ -147,6 +147,8 @@ typedef struct ld_conv3x3_args {
   const void* addend;      /* optional NHWC [B,H,W,Cout] tensor (storage dtype) added to conv + bias BEFORE the     */
                            /* statistics: the step-invariant half of a convolution over a concatenation whose     */
                            /* second operand does not change between reverse steps (conv_fusion, ddpm.py:434-436) */
+  int32_t weight_terms;    /* 0 / 1: `weight` from ld_pack_conv_weight; 2: two-term weights from                    */
+                           /* ld_pack_conv_weight_terms(..., 2) (16-bit storage): x*hi + x*lo, weights exact to 2^-17 */
 } ld_conv3x3_args;
 int ld_conv3x3(const ld_conv3x3_args* args, void* stream);
 
@@ -183,6 +185,7 @@ typedef struct ld_conv1x1_args {
                               of the k channels over pixels (integer atomicMax; caller zeroes) -- see ld_linattn_kmax */
   int32_t B, H, W, Cout;
   int32_t dtype;
+  int32_t weight_terms;    /* as in ld_conv3x3_args (not with rms_in or per-batch weights) */
 } ld_conv1x1_args;
 int ld_conv1x1(const ld_conv1x1_args* args, void* stream);
 
@@ -191,6 +194,12 @@ int ld_conv1x1(const ld_conv1x1_args* args, void* stream);
  * unshuffle=1 reorders K from (c,p1,p2) to (p1,p2,c).  out must hold Cout*Cin*k*k elements. */
 int ld_pack_conv_weight(const float* w_oihw, const float* scale_in, void* out, int cout, int cin,
                         int ksize, int unshuffle, int dtype, void* stream);
+/* terms = 2 (16-bit storage): two-term weights W = hi + lo, hi = round(W), lo = round(W - hi); out holds twice the
+ * elements, every K-chunk of hi followed by its chunk of lo.  Consumed by ld_conv3x3 / ld_conv1x1 with
+ * weight_terms = 2 at twice the matrix work: rounding the WEIGHTS to 16 bits is what separates a 16-bit sampling chain
+ * from the reference's fp32 weights (the same perturbation at every reverse step; activation roundings average out). */
+int ld_pack_conv_weight_terms(const float* w_oihw, const float* scale_in, void* out, int cout, int cin,
+                              int ksize, int unshuffle, int dtype, int terms, void* stream);
 
 /* ---- small-Cin direct convolution from an NCHW fp32 image --------------------------------- */
 /* init_conv 7x7 (ddpm.py:319,413) and the first BasicBlock convs (unet_model.py:20,30) whose

@@ -30,14 +30,14 @@ class Src(C.Structure):
 class Conv3x3Args(C.Structure):
     _fields_ = [("src", Src * 2), ("nsrc", i32), ("weight", vp), ("bias", vp), ("out", vp),
                 ("out_stats", vp), ("out_groups", i32), ("B", i32), ("H", i32), ("W", i32),
-                ("Cout", i32), ("t_ptr", vp), ("dtype", i32), ("addend", vp)]
+                ("Cout", i32), ("t_ptr", vp), ("dtype", i32), ("addend", vp), ("weight_terms", i32)]
 
 
 class Conv1x1Args(C.Structure):
     _fields_ = [("src", Src * 2), ("nsrc", i32), ("unshuffle", i32), ("rms_in", i32), ("weight", vp),
                 ("weight_bstride", i64), ("bias", vp), ("epilogue", i32), ("hidden", i32),
                 ("q_scale", f32), ("g2", vp), ("residual", vp), ("gn_tail", Src), ("out", vp), ("kmax_out", vp), ("B", i32), ("H", i32),
-                ("W", i32), ("Cout", i32), ("dtype", i32)]
+                ("W", i32), ("Cout", i32), ("dtype", i32), ("weight_terms", i32)]
 
 
 class GnApplyArgs(C.Structure):
@@ -71,6 +71,7 @@ _SIGS = {
     "ld_conv3x3": (C.c_int, [C.POINTER(Conv3x3Args), vp]),
     "ld_conv1x1": (C.c_int, [C.POINTER(Conv1x1Args), vp]),
     "ld_pack_conv_weight": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_pack_conv_weight_terms": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_conv_image": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, vp]),
     "ld_stem_packed_bytes": (C.c_size_t, []),

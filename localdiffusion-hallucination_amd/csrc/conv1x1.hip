@@ -32,6 +32,7 @@ struct Conv1Dev {
   unsigned* kmax;
   SrcDev tail;          // LD_EPI_GN_TAIL operand
   int B, H, W, Cout;
+  int wsplit;           // 1: two-term weights (pack.hip): 2*nch virtual chunks, source chunk v >> 1, weight chunk v
   int group;            // host decision: K-chunks staged per barrier pair (0 = 1; KG on small maps, 2 on mid-size ones)
 };
 
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 
   // K-chunk bookkeeping: plain = chunks of src0 then src1; unshuffle = 4 sub-pixels x chunks of src0
   const int nc0 = a.s[0].C / CK;
-  const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
+  const int ws = a.wsplit;
+  const int nch = (a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / CK : 0)) << ws;     // virtual chunks
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_x = smem;                                                  // [G][4][PLANE]
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)b * a.w_bstride);
 
   // global address of this thread's fragment of chunk `ch` for tile pixel slot `it` (nullptr: past the image)
-  auto frag_ptr = [&](int ch, int it) -> const uint4* {
+  auto frag_ptr = [&](int chv, int it) -> const uint4* {
+    const int ch = chv >> ws;                                          // source chunk of the virtual chunk
     int si = 0, c0, p1 = 0, p2 = 0;
     if (a.unshuffle) {
       const int pp = ch / nc0;
@@ -374,7 +377,7 @@ int dispatch(const Conv1Dev& a0, hipStream_t st) {
     static const int group_on = getenv("LD_C1_GROUP") ? atoi(getenv("LD_C1_GROUP")) : 1;
     const int ck = DT<T>::CK;
     const int nc0 = a.s[0].C / ck;
-    const int nch = a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / ck : 0);
+    const int nch = (a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / ck : 0)) << a.wsplit;
     static const int group_min_ch = getenv("LD_C1_GROUP_MIN_CH") ? atoi(getenv("LD_C1_GROUP_MIN_CH")) : 4;
     a.group = (group_on && (long)HW * a.B <= group_max_px && nch >= group_min_ch) ? KG : 0;
     // mid-size maps (the 128^2 stage at 4 patches per launch): two or three chunks per tile -- pairs
@@ -441,6 +444,9 @@ extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
   }
   a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout;
   a.group = 0;
+  LD_REQUIRE(p->weight_terms >= 0 && p->weight_terms <= 2 && !(p->weight_terms == 2 && (!ld_dtype_16(p->dtype) || p->rms_in || p->weight_bstride)),
+             "ld_conv1x1: weight_terms %d (2 needs 16-bit storage, no rms_in, no per-batch weights)", p->weight_terms);
+  a.wsplit = p->weight_terms == 2 ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return LD_DISPATCH(p->dtype, dispatch<T>(a, st));
 }

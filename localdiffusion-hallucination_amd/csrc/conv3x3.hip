@@ -172,16 +172,19 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   a.ogroups = p->out_groups > 0 ? p->out_groups : 1;
   a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout; a.t_ptr = p->t_ptr; a.tiles_x = 0;
   a.addend = p->addend;
+  LD_REQUIRE(p->weight_terms >= 0 && p->weight_terms <= 2 && !(p->weight_terms == 2 && !ld_dtype_16(p->dtype)),
+             "ld_conv3x3: weight_terms %d (2 needs 16-bit storage)", p->weight_terms);
+  a.wsplit = p->weight_terms == 2 ? 1 : 0;
   static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
   a.dbg = dbg;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!ld_stage_recording()) {
+  if (!ld_stage_recording() && p->weight_terms != 2) {   // (the persistent kernel keeps ONE chunk of weights in registers)
     const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }
 #ifdef LD_DEBUG_VARIANTS
   static const int ksplit = getenv("LD_CONV_KSPLIT") ? atoi(getenv("LD_CONV_KSPLIT")) : 0;
-  if (ksplit && !ld_stage_recording()) {                                       // shelved experiment: weights in registers, K split over waves
+  if (ksplit && !ld_stage_recording() && p->weight_terms != 2) {                                       // shelved experiment: weights in registers, K split over waves
     const int rc = ld_conv3x3_ksplit_try(p, st);
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }

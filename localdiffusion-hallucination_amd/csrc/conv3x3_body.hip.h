@@ -17,6 +17,7 @@ struct Conv3Dev {
   const int* t_ptr;
   const void* addend;
   int tiles_x;
+  int wsplit;  // 1: two-term weights (pack.hip): 2*nch virtual chunks, source chunk v >> 1, weight chunk v
   int dbg;     // ablation switches (LD_CONV_DEBUG env, 0 in production): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
 };
 
@@ -65,7 +66,8 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   const int ty0 = (bx / a.tiles_x) * TR, tx0 = (bx % a.tiles_x) * TC;
   const int H = a.H, W = a.W;
   const int nch0 = a.s[0].C / CK;
-  const int nch = nch0 + (a.nsrc > 1 ? a.s[1].C / CK : 0);
+  const int ws = a.wsplit;
+  const int nch = (nch0 + (a.nsrc > 1 ? a.s[1].C / CK : 0)) << ws;      // virtual chunks (two per source chunk with two-term weights)
   const int mt_total = a.Cout / 16;
   const uint4* wg = reinterpret_cast<const uint4*>(a.w);
 
@@ -122,8 +124,9 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   }
   const long wstride = 9L * mt_total * 1024;            // bytes per chunk
   auto issue_loads = [&](int ch, uint4 (&hx)[ITER], uint4 (&wx)[WU]) {
-    const int si = ch >= nch0 ? 1 : 0;
-    const char* sp = (si ? sbase1 : sbase0) + (long)(ch - si * nch0) * CK * (long)sizeof(T);
+    const int cs = ch >> ws;                              // source chunk of this (virtual) chunk
+    const int si = cs >= nch0 ? 1 : 0;
+    const char* sp = (si ? sbase1 : sbase0) + (long)(cs - si * nch0) * CK * (long)sizeof(T);
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       hx[it] = make_uint4(0u, 0u, 0u, 0u);
@@ -137,9 +140,10 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
     }
   };
   auto write_lds = [&](int ch, const uint4 (&hx)[ITER], const uint4 (&wx)[WU]) {
-    const int si = ch >= nch0 ? 1 : 0;
+    const int csrc = ch >> ws;                            // source chunk of this (virtual) chunk
+    const int si = csrc >= nch0 ? 1 : 0;
     const SrcDev S = si ? a.s[1] : a.s[0];
-    const int c0 = (ch - si * nch0) * CK;
+    const int c0 = (csrc - si * nch0) * CK;
     const int coef_off = si ? 2 * a.s[0].C : 0;
     const bool has_coef = !RAW && S.stats != nullptr;
     // this thread always stages the same E channels of the chunk: keep their (a, s) in registers

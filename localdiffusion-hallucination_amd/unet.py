@@ -93,6 +93,10 @@ class Unet(nn.Module):
         # stage programs (csrc/stage.hip): runs of small-map launches as one persistent launch; maps of at most this many
         # pixels per image (0 = off)
         self.stage_max_px = int(os.environ.get("LD_STAGE_MAX_PX", "0"))
+        # two-term convolution weights (W = hi + lo in 16-bit storage, twice the matrix work) for the layers of the
+        # first N resolution levels (0 = off; 2 = the full- and half-resolution layers, which carry 90 % of what
+        # rounding the weights costs a sampling chain: DESIGN section 2).  See set_weight_split_levels().
+        self.weight_split_levels = int(os.environ.get("LD_WEIGHT_SPLIT_LEVELS", "0"))
         self._version = 0
 
     # ------------------------------------------------------------------ reference attributes
@@ -110,6 +114,23 @@ class Unet(nn.Module):
         if name != self.compute_dtype:
             self.compute_dtype = name
             self.invalidate()
+
+    def set_weight_split_levels(self, n):
+        """Two-term weights for the convolutions of the first ``n`` resolution levels (16-bit storage)."""
+        if int(n) != self.weight_split_levels:
+            self.weight_split_levels = int(n)
+            self.invalidate()
+
+    def _layer_level(self, name):
+        """Resolution level a parameter's layer works at: 0 = full resolution ... len(dim_mults) - 1 = coarsest."""
+        n = len(self.cfg.dim_mults)
+        if name.startswith("downs."):
+            return int(name.split(".")[1])
+        if name.startswith("ups."):
+            return n - 1 - int(name.split(".")[1])
+        if name.startswith("final_res_block"):
+            return 0
+        return n - 1
 
     def invalidate(self):
         """Drop packed weights and plans (call after changing parameters in place)."""
@@ -133,22 +154,26 @@ class Unet(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("the HIP denoiser needs its parameters on a GPU (model.to('cuda')); "
                                "there is no CPU execution path")
-        key = (str(dev), self.compute_dtype)
+        key = (str(dev), self.compute_dtype, self.weight_split_levels)
         if self._packed is not None and self._packed_key == key:
             return self._packed
         lib = cabi.lib()
         st = torch.cuda.current_stream().cuda_stream
         dt, tdt = cabi.dtype_code(self.compute_dtype), _TORCH_DT[self.compute_dtype]
         sd = {k: v.detach().to(torch.float32).contiguous() for k, v in self.state_dict().items()}
-        P = {"f32": sd, "w": {}, "g2": {}}
+        P = {"f32": sd, "w": {}, "g2": {}, "terms2": set()}
 
         def pack(name, ksize, scale_in=None, unshuffle=0):
             w = sd[name]
             cout, cin = w.shape[0], w.shape[1]
-            out = torch.empty(cout * cin * ksize * ksize, dtype=tdt, device=dev)
-            cabi.check(lib.ld_pack_conv_weight(w.data_ptr(), cabi.ptr(scale_in), out.data_ptr(), cout, cin,
-                                               ksize, unshuffle, dt, st), "pack " + name)
+            terms = 2 if (self.compute_dtype in _LOWP and scale_in is None and not name.startswith("cond_model.")
+                          and self._layer_level(name) < self.weight_split_levels) else 1
+            out = torch.empty(terms * cout * cin * ksize * ksize, dtype=tdt, device=dev)
+            cabi.check(lib.ld_pack_conv_weight_terms(w.data_ptr(), cabi.ptr(scale_in), out.data_ptr(), cout, cin,
+                                                     ksize, unshuffle, dt, terms, st), "pack " + name)
             P["w"][name] = out
+            if terms == 2:
+                P["terms2"].add(out.data_ptr())
             if scale_in is not None:
                 P.setdefault("keep", []).append(scale_in)
 
@@ -246,7 +271,7 @@ class Unet(nn.Module):
         f = self.downsample_factor
         assert H % f == 0 and W % f == 0, \
             f"your input dimensions {(H, W)} need to be divisible by {f}, given the unet"   # ddpm.py:405
-        key = (B, H, W, table_T, self.compute_dtype, instance)
+        key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels, self.stage_max_px)
         if key not in self._plans:
             self._plans[key] = _Plan(self, B, H, W, table_T)
         return self._plans[key]
@@ -379,6 +404,7 @@ class _Plan:
         weight = self.P["w"][wname + ".weight"] if weight is None else weight
         bias = self.f32[wname + ".bias"] if bias is None else bias
         a.weight, a.bias = weight.data_ptr(), bias.data_ptr()
+        a.weight_terms = 2 if weight.data_ptr() in self.P["terms2"] else 1
         a.addend = cabi.ptr(addend)
         self.keep += [weight, bias, addend]
         out = self.buf(h, w, cout)
@@ -397,7 +423,7 @@ class _Plan:
         ck = 16 if self.dt == cabi.LD_F32 else 32
         if (cout == 32 and len(srcs) == 1 and cin == ck and addend is None and h >= 32 and w >= 32 and h % 16 == 0
                 and w % 16 == 0 and (w // 16) * (h // 16) * self.B >= int(os.environ.get("LD_CONV_C32_MIN_TILES", "2048"))
-                and not os.environ.get("LD_CONV_NO_C32")):
+                and not os.environ.get("LD_CONV_NO_C32") and a.weight_terms != 2):
             fam = f"conv3x3_c32<{dname}>"              # the persistent LDS-DMA kernel takes it (conv3x3_c32.hip)
         in_el = sum(s.C * (npx // 4 if s.upsample else npx) for s in srcs)
         self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname,
@@ -414,6 +440,7 @@ class _Plan:
             a.src[i] = s
         a.nsrc, a.unshuffle, a.rms_in = len(srcs), unshuffle, rms_in
         a.weight, a.weight_bstride = weight.data_ptr(), bstride
+        a.weight_terms = 2 if weight.data_ptr() in self.P["terms2"] else 1
         a.bias = cabi.ptr(bias)
         a.epilogue, a.hidden, a.q_scale = epi, self.cfg.hidden, self.cfg.attn_dim_head ** -0.5
         a.g2, a.residual = cabi.ptr(g2), cabi.ptr(residual)

@@ -25,7 +25,14 @@ from test_hip_sampler import make, run                            # noqa: E402
 RECORDS = (999, 750, 500, 250, 100, 10, 0)
 # (max-abs, mean-abs); measured on MI355X (round 2): bf16 t=100 2.9e-2 / 3.2e-3, final 1.98 / 0.128;
 #                                                    fp16 t=100 3.9e-3 / 4.6e-4, final 0.95 / 2.0e-2
-BOUND_T100 = {"bf16": (6e-2, 6e-3), "fp16": (8e-3, 1e-3)}
+# Round 3 (tools/exp_error_budget.py, profiles/r03_error_budget_*.txt): with the roundings emulated on the oracle one
+# storage class at a time, rounding the WEIGHTS alone gives 3.39e-2 / 4.38e-3 (bf16) and 3.51e-3 / 3.93e-4 (fp16) at
+# t = 100 -- the whole of the "all classes" figure (3.39e-2 / 4.41e-3, 3.83e-3 / 3.98e-4); every activation class is
+# 10-20x below (all of them together 6.4e-3 / 5.0e-4 in bf16).  The distance to the reference is the distance between
+# the network with fp32 weights and the network with 16-bit weights, not error the kernels accumulate: the bound is
+# therefore stated against that figure (W_ONLY_T100 x 1.5) and tightened from round 2's 6e-2 / 6e-3, 8e-3 / 1e-3.
+W_ONLY_T100 = {"bf16": (3.39e-2, 4.38e-3), "fp16": (3.51e-3, 3.93e-4)}
+BOUND_T100 = {"bf16": (4.5e-2, 4.5e-3), "fp16": (5.3e-3, 5.9e-4)}
 BOUND_FINAL_MEAN = {"bf16": 0.2, "fp16": 4e-2}
 # DDIM S=50 of 1000 (G7, 64x64, branch + fusion at times[-4]): measured bf16 0.33 / 1.8e-2, fp16 0.54 / 8.3e-3
 BOUND_G7_MEAN = {"bf16": 4e-2, "fp16": 2e-2}
@@ -52,10 +59,37 @@ def test_cfg2_chain_16bit_vs_reference_golden(golden, dtype):
               f"output rounded to {dtype}: max-abs {f[t][0]:.3e} mean-abs {f[t][1]:.3e}")
     for t in (999, 750, 500, 250, 100):
         assert e[t][0] <= BOUND_T100[dtype][0] and e[t][1] <= BOUND_T100[dtype][1], (dtype, t, e[t])
+    # the kernels add (almost) nothing to what rounding the weights to 16 bits costs
+    assert e[100][1] <= 1.5 * W_ONLY_T100[dtype][1], (dtype, e[100], W_ONLY_T100[dtype])
     assert e[0][1] <= BOUND_FINAL_MEAN[dtype], (dtype, e[0])
     growth_hip, growth_ref = e[0][1] / e[100][1], f[0][1] / f[100][1]
     print(f"G5 cfg2 {dtype}: mean-abs growth over the last 100 steps: HIP x{growth_hip:.0f}, output-rounded reference x{growth_ref:.0f}")
     assert growth_hip <= 2.0 * growth_ref, (dtype, growth_hip, growth_ref)
+
+
+# Two-term weights on the full- and half-resolution layers (Unet.set_weight_split_levels(2), +10 % step time): measured
+# round 3 at t = 100: bf16 6.8e-3 / 7.8e-4 (one-term 2.6e-2 / 3.2e-3), fp16 1.2e-3 / 1.2e-4 (4.0e-3 / 4.6e-4)
+BOUND_T100_SPLIT = {"bf16": (1.4e-2, 1.3e-3), "fp16": (2.5e-3, 2.0e-4)}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_cfg2_chain_with_two_term_weights(golden, dtype):
+    """The accuracy mode of the 16-bit storage types: W = hi + lo for the convolutions of the first two resolution levels
+    (the weights whose rounding tools/exp_error_budget.py found to carry 90 % of the chain's distance to the reference).
+    Same run and golden as above; the distance must come down by at least 2.5x at t = 100 and stay below its own bounds."""
+    g = golden("g5_cfg2_mri128")
+    cond = torch.from_numpy(rng.uniform((1, 1, 128, 128), 5, 1, 0.0, 2.0))
+    gd = make(dict(mode="mri"), dict(data="mri"), 128, 1000, dtype=dtype)
+    gd.model.set_weight_split_levels(2)
+    hist = gd.sample(cond.cuda(), None, batch_size=1, min_max_val=(0.0, 2.0), return_all_timesteps=True).cpu().numpy()
+    assert np.isfinite(hist).all()
+    e = {t: err(hist[:, 1000 - t], g[f"x_after_t{t}"]) for t in RECORDS}
+    for t in RECORDS:
+        print(f"G5 cfg2 {dtype}, two-term weights on 2 levels, x after t={t:3d}: max-abs {e[t][0]:.3e} mean-abs {e[t][1]:.3e}")
+    for t in (999, 750, 500, 250, 100):
+        assert e[t][0] <= BOUND_T100_SPLIT[dtype][0] and e[t][1] <= BOUND_T100_SPLIT[dtype][1], (dtype, t, e[t])
+    assert e[100][1] <= W_ONLY_T100[dtype][1] / 2.5, (dtype, e[100])
+    assert e[0][1] <= 0.5 * BOUND_FINAL_MEAN[dtype], (dtype, e[0])
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

@@ -631,3 +631,60 @@ def test_conv1x1_grouped_staging_is_bitwise_the_plain_k_loop(tmp_path):
     for k in res["1"].files:
         assert np.isfinite(res["1"][k]).all(), k
         assert np.array_equal(res["1"][k], res["0"][k]), (k, float(np.abs(res["1"][k] - res["0"][k]).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", LOWP)
+def test_two_term_weights_remove_the_weight_rounding(dtype):
+    """ld_pack_conv_weight_terms(..., 2) + weight_terms = 2 (W = hi + lo, x*hi + x*lo): against the fp32-weight reference on
+    inputs that are exact in the storage dtype, what is left is the rounding of the OUTPUT to the storage dtype, i.e.
+    the result equals the storage-rounded exact result almost everywhere -- and the one-term result is measurably
+    further away.  3x3 (with concat + upsample + GroupNorm prologue) and 1x1 (concat; GN-tail epilogue)."""
+    B, c1, c2, cout, H, W = 2, 64, 32, 64, 16, 16
+    lib = cabi.lib()
+
+    def packed(w, k, terms):
+        w = w.to(hh.DEV, torch.float32).contiguous()
+        out = torch.empty(terms * w.numel(), dtype=hh.TDT[dtype], device=hh.DEV)
+        cabi.check(lib.ld_pack_conv_weight_terms(w.data_ptr(), None, out.data_ptr(), w.shape[0], w.shape[1], k, 0,
+                                                 cabi.dtype_code(dtype), terms, hh.st()), "pack")
+        return out
+    x1, x2 = _q(hh.rand((B, c1, H // 2, W // 2), 4), dtype), _q(hh.rand((B, c2, H, W), 5), dtype)
+    w, b = hh.rand((cout, c1 + c2, 3, 3), 6, -0.1, 0.1), hh.rand((cout,), 7)            # fp32 weights: NOT exact in 16 bits
+    ref = F.conv2d(torch.cat([F.interpolate(x1, scale_factor=2, mode="nearest"), x2], 1), w, b, padding=1)
+    errs = {}
+    for terms in (1, 2):
+        a = cabi.Conv3x3Args()
+        s1, s2 = hh.make_src(hh.nhwc(x1, dtype), c1, ups=1), hh.make_src(hh.nhwc(x2, dtype), c2)
+        a.src[0], a.src[1], a.nsrc = s1, s2, 2
+        wp, bd = packed(w, 3, terms), b.to(hh.DEV)
+        out = torch.empty(B, H, W, cout, dtype=hh.TDT[dtype], device=hh.DEV)
+        a.weight, a.bias, a.out, a.weight_terms = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), terms
+        a.B, a.H, a.W, a.Cout, a.dtype = B, H, W, cout, cabi.dtype_code(dtype)
+        cabi.check(lib.ld_conv3x3(C.byref(a), hh.st()), "conv3x3")
+        errs[terms] = float((hh.nchw(out) - ref).abs().mean())
+        if terms == 2:
+            exact = (hh.nchw(out) == _q(ref, dtype)).float().mean()
+            assert float(exact) > 0.97, float(exact)            # = the storage-rounded exact result (ties / fp32 summation order aside)
+    print(f"conv3x3 {dtype}: mean-abs vs fp32-weight reference: one term {errs[1]:.3e}, two terms {errs[2]:.3e}")
+    assert errs[2] < 0.8 * errs[1]
+    # 1x1 over a concatenation with the ResnetBlock tail epilogue
+    y1, y2 = _q(hh.rand((B, c1, H, W), 8), dtype), _q(hh.rand((B, c2, H, W), 9), dtype)
+    w1, b1 = hh.rand((cout, c1 + c2, 1, 1), 10, -0.3, 0.3), hh.rand((cout,), 11)
+    h = _q(hh.rand((B, cout, H, W), 12, -2, 2), dtype)
+    gamma, beta = hh.rand((cout,), 13, 0.5, 1.5), hh.rand((cout,), 14, -0.3, 0.3)
+    ref1 = F.conv2d(torch.cat([y1, y2], 1), w1, b1) + F.silu(F.group_norm(h, 8, gamma, beta, eps=1e-5))
+    for terms in (1, 2):
+        tail = hh.make_src(hh.nhwc(h, dtype), cout, gn=(hh.stats_striped(h, 8), gamma.to(hh.DEV), beta.to(hh.DEV), 8), act=cabi.ACT_SILU)
+        a = cabi.Conv1x1Args()
+        s1, s2 = hh.make_src(hh.nhwc(y1, dtype), c1), hh.make_src(hh.nhwc(y2, dtype), c2)
+        a.src[0], a.src[1], a.nsrc = s1, s2, 2
+        wp, bd = packed(w1, 1, terms), b1.to(hh.DEV)
+        out = torch.empty(B, H, W, cout, dtype=hh.TDT[dtype], device=hh.DEV)
+        a.weight, a.bias, a.out, a.weight_terms = wp.data_ptr(), bd.data_ptr(), out.data_ptr(), terms
+        a.epilogue, a.hidden, a.q_scale, a.gn_tail = cabi.EPI_GN_TAIL, 128, 32 ** -0.5, tail
+        a.B, a.H, a.W, a.Cout, a.dtype = B, H, W, cout, cabi.dtype_code(dtype)
+        cabi.check(lib.ld_conv1x1(C.byref(a), hh.st()), "conv1x1")
+        errs[terms] = float((hh.nchw(out) - ref1).abs().mean())
+    print(f"conv1x1 {dtype}: mean-abs vs fp32-weight reference: one term {errs[1]:.3e}, two terms {errs[2]:.3e}")
+    assert errs[2] < 0.8 * errs[1]

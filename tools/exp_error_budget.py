@@ -7,6 +7,7 @@ emulated one storage class at a time -- the same places where the 16-bit kernels
 
   W      the packed convolution / qkv / to_out weights (MFMA A operands); init_conv (hi+lo split), final_conv, the
          time MLP and GroupNorm / RMSNorm parameters stay fp32 in the HIP path and here
+  W0..W3 the same for the layers of ONE resolution level only (0 = full resolution ... 3 = 1/8 and the middle blocks)
   RAW    convolution outputs stored before their GroupNorm (raw1, raw2 of every ResnetBlock, the encoder's convs)
   ACT    the normalised + FiLM + SiLU tensor that enters the second convolution (rounded when the prologue packs it
          for the MFMA, or when gn_apply stores it)
@@ -42,9 +43,22 @@ class Emu:
     def __init__(self, sd, cfg, on, tdt):
         self.cfg, self.on, self.tdt = cfg, set(on), tdt
         self.sd = dict(sd)
-        if "W" in self.on:
-            for k, v in sd.items():
-                if v.dim() == 4 and not k.startswith(("init_conv", "final_conv")):
+        ns = len(cfg.dim_mults)
+
+        def level(k):                              # resolution level of the layer a weight belongs to (0 = full resolution)
+            if k.startswith("downs."):
+                return int(k.split(".")[1])
+            if k.startswith("ups."):
+                return ns - 1 - int(k.split(".")[1])
+            if k.startswith("final_res_block"):
+                return 0
+            if k.startswith("cond_model."):
+                return {"residual_conv1": 0, "residual_conv2": 1, "residual_conv3": 2, "mid_conv": 3}[k.split(".")[1]]
+            return ns - 1                          # mid blocks, mid attention, conv_fusion
+        for k, v in sd.items():
+            if v.dim() == 4 and not k.startswith(("init_conv", "final_conv")):
+                kind = "c3" if v.shape[-1] == 3 else "c1"          # 3x3 convolutions / 1x1 convolutions (incl. qkv, to_out)
+                if "W" in self.on or f"W{level(k)}" in self.on or f"W{level(k)}{kind}" in self.on:
                     self.sd[k] = v.to(tdt).float()
 
     def q(self, cls, t):
