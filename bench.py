@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5"],
                     help="cfg3 (default, the headline metric) | cfg5: BASELINE configs[4] as stated -- one 1x512x512 image per GPU, "
                          "DDIM 50 of 1000 steps, OOD/IND branches with a circular mask, fusion at times[-4]; reports images/s")
-    ap.add_argument("--weight-split-levels", type=int, default=0,
+    ap.add_argument("--weight-split-levels", type=int, default=None,
                     help="two-term (hi + lo) convolution weights on the first N resolution levels (accuracy mode, DESIGN section 2); "
                          "the default line is measured with 0 and reports the cost of 2 in `two_term_weights`")
     ap.add_argument("--graph", type=int, default=-1, help="1: replay the reverse step from a captured HIP graph (default: eager launches)")
@@ -437,6 +437,8 @@ def main():
     sd = {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()}
     net.load_state_dict(sd)
     net = net.to(dev)
+    if a.weight_split_levels is None:                       # default: the Unet's own default (0, or LD_WEIGHT_SPLIT_LEVELS)
+        a.weight_split_levels = net.weight_split_levels
     net.set_weight_split_levels(a.weight_split_levels)
     config = dict(branch_out=False, start_intermediate=False, start_timestep=2, data="mvtec", mask_x=False,
                   ood_AD=False, ood_confidence=False, classifier=False, use_gt=False)

@@ -127,10 +127,14 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
     const int cs = ch >> ws;                              // source chunk of this (virtual) chunk
     const int si = cs >= nch0 ? 1 : 0;
     const char* sp = (si ? sbase1 : sbase0) + (long)(cs - si * nch0) * CK * (long)sizeof(T);
+    // two-term weights: the lo pass (odd virtual chunk) multiplies the SAME halo tile, which is still in LDS
+    const bool same_halo = !SK && !DEEP && ws && (ch & 1);
+    if (!same_halo) {
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      hx[it] = make_uint4(0u, 0u, 0u, 0u);
-      if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sp + (si ? hoffb1[it] : hoffb0[it]));
+      for (int it = 0; it < ITER; ++it) {
+        hx[it] = make_uint4(0u, 0u, 0u, 0u);
+        if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sp + (si ? hoffb1[it] : hoffb0[it]));
+      }
     }
     const char* wc = reinterpret_cast<const char*>(wg) + (long)ch * wstride;
 #pragma unroll
@@ -153,10 +157,11 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
 #pragma unroll
       for (int e = 0; e < E; ++e) { ca[e] = cap[e]; cs[e] = cap[S.C + e]; }
     }
+    const bool same_halo = !SK && !DEEP && ws && (ch & 1);
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int q = (it * 4 + wv) * 16 + px;
-      if (q < NPIXP) {
+      if (q < NPIXP && !same_halo) {
         uint4 raw = hx[it];
         if (has_coef && ((hvalid >> it) & 1u)) {        // zero padding stays exactly zero
           float v[E];

