@@ -129,3 +129,31 @@ def test_cfg1_and_branch_fusion_16bit_vs_reference_golden(golden, dtype):
         mx, mean = err(run(gd, cond, mask, 2), g6[tag + "_final"])
         print(f"G6 {tag} (T=50, branch + fusion) {dtype}: max-abs {mx:.3e} mean-abs {mean:.3e}")
         assert mean <= bound, (dtype, tag, mx, mean)
+
+
+def test_two_term_weights_at_the_bench_shape():
+    """The accuracy mode at BASELINE.json configs[2]'s shape (3x256x256 patches, the 12.1M-parameter denoiser), where no
+    reference golden exists: a T = 300 chain of two patches in fp32 storage on the HIP path (the mode the 1e-3 gate pins to
+    the oracle) against the same chain in bf16 with one-term and with two-term weights on two levels.  Size-independent
+    property: the two-term chain is the closer one at every recorded state before the chaotic tail."""
+    from localdiffusion_hallucination_amd import weights
+    import localdiffusion_hallucination_amd as ldh
+    H, B, T = 256, 2, 300
+    cond = torch.from_numpy(rng.uniform((B, 3, H, H), 33, 1, 0.0, 2.0))
+    cfg = dict(branch_out=False, start_intermediate=False, start_timestep=2, data="mvtec", mask_x=False, mask_cond=False,
+               ood_AD=False, ood_confidence=False, classifier=False, use_gt=False, use_gt_timestep=100)
+    hist = {}
+    for tag, dtype, levels in (("fp32", "fp32", 0), ("bf16", "bf16", 0), ("bf16x2", "bf16", 2)):
+        net = ldh.Unet(dim=32, init_dim=32, channels=3, out_dim=3, mode="mvtec", compute_dtype=dtype)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()})
+        net.set_weight_split_levels(levels)
+        gd = ldh.GaussianDiffusion(cfg, net, image_size=H, timesteps=T, beta_schedule="sigmoid", objective="pred_x0",
+                                   auto_normalize=False).to("cuda")
+        gd.noise_source = "device"
+        hist[tag] = gd.sample(cond.cuda(), None, batch_size=B, min_max_val=(0.0, 2.0), return_all_timesteps=True).cpu().numpy()
+        assert np.isfinite(hist[tag]).all()
+    for t in (250, 150, 100, 50):
+        e1 = float(np.abs(hist["bf16"][:, T - t] - hist["fp32"][:, T - t]).mean())
+        e2 = float(np.abs(hist["bf16x2"][:, T - t] - hist["fp32"][:, T - t]).mean())
+        print(f"3x256^2, T={T}, x after t={t:3d}: bf16 one-term {e1:.3e}, two-term weights on 2 levels {e2:.3e} (mean-abs vs fp32 storage)")
+        assert e2 < 0.45 * e1, (t, e1, e2)          # measured (round 3): 0.33, 0.24, 0.23, 0.23

@@ -7,7 +7,8 @@ emulated one storage class at a time -- the same places where the 16-bit kernels
 
   W      the packed convolution / qkv / to_out weights (MFMA A operands); init_conv (hi+lo split), final_conv, the
          time MLP and GroupNorm / RMSNorm parameters stay fp32 in the HIP path and here
-  W0..W3 the same for the layers of ONE resolution level only (0 = full resolution ... 3 = 1/8 and the middle blocks)
+  W0..W3 the same for the layers of ONE resolution level only (0 = full resolution ... 3 = 1/8 and the middle blocks);
+         W0c3 / W0c1 / W0at: only that level's 3x3 convolutions / 1x1 convolutions / attention projections
   RAW    convolution outputs stored before their GroupNorm (raw1, raw2 of every ResnetBlock, the encoder's convs)
   ACT    the normalised + FiLM + SiLU tensor that enters the second convolution (rounded when the prologue packs it
          for the MFMA, or when gn_apply stores it)
@@ -57,7 +58,10 @@ class Emu:
             return ns - 1                          # mid blocks, mid attention, conv_fusion
         for k, v in sd.items():
             if v.dim() == 4 and not k.startswith(("init_conv", "final_conv")):
-                kind = "c3" if v.shape[-1] == 3 else "c1"          # 3x3 convolutions / 1x1 convolutions (incl. qkv, to_out)
+                # 3x3 convolutions / attention projections (to_qkv; to_out stays fp32 in the HIP path) / other 1x1 convolutions
+                kind = "c3" if v.shape[-1] == 3 else ("at" if (".to_qkv" in k or ".to_out" in k) else "c1")
+                if ".to_out" in k and "W" not in self.on:
+                    continue
                 if "W" in self.on or f"W{level(k)}" in self.on or f"W{level(k)}{kind}" in self.on:
                     self.sd[k] = v.to(tdt).float()
 
