@@ -279,6 +279,14 @@ int ld_linattn_kvctx(const void* x, const void* wkv_packed, const float* kshift,
 int ld_linattn_out(const void* x, const void* wq_packed, const float* qshift, const void* mfold,
                    const float* bias, const float* g2, void* out, int B, int n, int C, float q_scale,
                    int dtype, void* stream);
+/* Two-term weights (ld_pack_conv_weight_terms(..., 2) of the same rows, with the RMSNorm scale) for the fused linear
+ * attention of the full- and half-resolution blocks (C = 32 / 64, heads = 4): W_kv / W_q enter the matrix pipe as hi + lo.
+ * weight_terms = 1 is ld_linattn_kvctx / ld_linattn_out. */
+int ld_linattn_kvctx_terms(const void* x, const void* wkv_packed, const float* kshift, float* ctx_part, int B, int n, int C,
+                           int heads, int dim_head, int nchunks, int dtype, int weight_terms, void* stream);
+int ld_linattn_out_terms(const void* x, const void* wq_packed, const float* qshift, const void* mfold, const float* bias,
+                         const float* g2, void* out, int B, int n, int C, float q_scale, int dtype, int weight_terms,
+                         void* stream);
 size_t ld_linattn_ctx_part_floats(int B, int heads, int dim_head, int nchunks);
 
 /* Full softmax attention (attend.py:84-113) on qkv [B, n, 3*hidden] with q pre-scaled;

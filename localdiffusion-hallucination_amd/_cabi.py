@@ -85,6 +85,8 @@ _SIGS = {
     "ld_linattn_ctxfold": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_linattn_kvctx": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_linattn_out": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, C.c_int, vp]),
+    "ld_linattn_kvctx_terms": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_linattn_out_terms": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, f32, C.c_int, C.c_int, vp]),
     "ld_linattn_ctx_part_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ld_attention": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_time_mlp": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),

@@ -34,7 +34,8 @@ struct KvCtxArgs {
   const uint4* wkv;     // [heads][NCH][4 tiles: k0 k1 v0 v1][64] fragments (g*sqrt(C) folded in)
   float* ctx_part;
   int n, C, heads, nchunks;
-  const float* kshift;   // optional [heads*32]: softmax_n(k) shift per k-channel (>= max_n k): single-sweep mode
+  const float* kshift;  // optional [heads*32]: softmax_n(k) shift per k-channel (>= max_n k): single-sweep mode
+  int wsplit;           // 1: two-term weights (wave-per-head kernel, C = 32 / 64)
 };
 
 template <typename T, int NCH>
@@ -207,8 +208,10 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
 constexpr int SROW = 32;                  // pixels per wave-private P/V strip (= one MFMA K-step)
 
 // SINGLE (caller-supplied shift): the max sweep, its registers and its code are compiled out.
-template <typename T, int NCH, bool SINGLE>
+// WS = 1: two-term weights (ld_pack_conv_weight_terms): 2 * NCH weight chunks, chunk v multiplies x chunk v >> 1.
+template <typename T, int NCH, bool SINGLE, int WS = 0>
 __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
+  constexpr int NCW = NCH << WS;                        // weight chunks
   constexpr int PLANE = KTN * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_x = smem;                                     // [NCH][4][KTN][16 B]
@@ -220,11 +223,11 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
   const int n = a.n, C = a.C;
   const int npc = (n + a.nchunks - 1) / a.nchunks;
   const int lo = ck * npc, hi = min(n, lo + npc);
-  uint4 A[4][NCH];
+  uint4 A[4][NCW];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c)
+  for (int c = 0; c < NCW; ++c)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) A[m][c] = a.wkv[(((size_t)h * NCH + c) * 4 + m) * 64 + lane];
+    for (int m = 0; m < 4; ++m) A[m][c] = a.wkv[(((size_t)h * NCW + c) * 4 + m) * 64 + lane];
   float cmax[2][4], mloc[2][4], zs[2][4];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -303,8 +306,8 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
           const int qq = g * 16 + li;
           f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
+          for (int c = 0; c < NCW; ++c) {
+            const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + ((c >> WS) * 4 + kq) * PLANE + qq * 16);
             mma16<T>(k0, A[0][c], Bf);
             mma16<T>(k1, A[1][c], Bf);
           }
@@ -331,8 +334,8 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
               for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-              for (int c = 0; c < NCH; ++c) {
-                const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
+              for (int c = 0; c < NCW; ++c) {
+                const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + ((c >> WS) * 4 + kq) * PLANE + qq * 16);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) mma16<T>(acc[m], A[m][c], Bf);
               }
@@ -415,22 +418,24 @@ struct LinOutArgs {
   int n, C;
   float q_scale;
   const float* qshift;   // optional [4]: per head an upper bound of q (softmax_d shift): skips the max reduction
+  int wsplit;            // 1: two-term W_q (C = 32 / 64)
 };
 
-template <typename T, int NCH>
+template <typename T, int NCH, int WS = 0>
 __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
   constexpr int NW = 2, NPT = 64 * NW, PLANE = NPT * 16, MT2 = 2 * NCH;
+  constexpr int NCW = NCH << WS;                         // weight chunks of W_q (two per x chunk with two-term weights)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_x = smem;                                      // [NCH][4][NPT][16 B]
-  char* s_wq = s_x + NCH * 4 * PLANE;                    // [NCH][8][1 KiB]
-  char* s_mf = s_wq + NCH * 8 * 1024;                    // [4][MT2][1 KiB]
+  char* s_wq = s_x + NCH * 4 * PLANE;                    // [NCW][8][1 KiB]
+  char* s_mf = s_wq + NCW * 8 * 1024;                    // [4][MT2][1 KiB]
   float* s_rinv = reinterpret_cast<float*>(s_mf + 4 * MT2 * 1024);
   const int b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kq = lane >> 4;
   const int n = a.n, C = a.C;
   const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * n * C;
   // W_q and M_b are staged once per workgroup and reused for LINOUT_TPB consecutive pixel tiles
-  for (int u = tid; u < NCH * 8 * 64; u += 256) *reinterpret_cast<uint4*>(s_wq + u * 16) = a.wq[u];
+  for (int u = tid; u < NCW * 8 * 64; u += 256) *reinterpret_cast<uint4*>(s_wq + u * 16) = a.wq[u];
   const uint4* mf = a.mfold + (size_t)b * 4 * MT2 * 64;
   for (int u = tid; u < 4 * MT2 * 64; u += 256) *reinterpret_cast<uint4*>(s_mf + u * 16) = mf[u];
   // bias and the RMSNorm gain of this lane's output channels: loaded once, not inside the per-pixel epilogue
@@ -483,8 +488,8 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) q[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + (c * 4 + kq) * PLANE + qq * 16);
+    for (int c = 0; c < NCW; ++c) {
+      const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + ((c >> WS) * 4 + kq) * PLANE + qq * 16);
 #pragma unroll
       for (int m = 0; m < 8; ++m)
         mma16<T>(q[m], *reinterpret_cast<const uint4*>(s_wq + (c * 8 + m) * 1024 + lane * 16), Bf);
@@ -567,7 +572,16 @@ int kvctx_launch(const KvCtxArgs& a, int B, hipStream_t st) {
   if (heads == 4 && (!no_wph || kshift)) {               // wave-per-head schedule
     const size_t lds2 = (size_t)nch * 4 * KTN * 16 + KTN * sizeof(float) + 4 * 2 * SROW * PROW;
     dim3 grid2(nchunks, B);
-    if (nch == 1) {
+    if (a.wsplit) {                                        // two-term weights: the full- and half-resolution blocks
+      LD_REQUIRE(nch <= 2, "ld_linattn_kvctx: two-term weights are built for C = 32 / 64 (got %d)", a.C);
+      if (nch == 1) {
+        if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 1, true, 1>), grid2, dim3(256), lds2, st, a);
+        else LD_LAUNCH((kvctx_wph_kernel<T, 1, false, 1>), grid2, dim3(256), lds2, st, a);
+      } else {
+        if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 2, true, 1>), grid2, dim3(256), lds2, st, a);
+        else LD_LAUNCH((kvctx_wph_kernel<T, 2, false, 1>), grid2, dim3(256), lds2, st, a);
+      }
+    } else if (nch == 1) {
       if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 1, true>), grid2, dim3(256), lds2, st, a);
       else LD_LAUNCH((kvctx_wph_kernel<T, 1, false>), grid2, dim3(256), lds2, st, a);
     } else if (nch == 2) {
@@ -582,6 +596,7 @@ int kvctx_launch(const KvCtxArgs& a, int B, hipStream_t st) {
     LD_LAUNCH_CHECK("linattn_kvctx(wave-per-head)");
     return LD_OK;
   }
+  LD_REQUIRE(!a.wsplit, "ld_linattn_kvctx: two-term weights need heads == 4 (the wave-per-head kernel)");
   dim3 grid(nchunks, heads, B);
   const size_t lds = (size_t)nch * 4 * KTN * 16 + 2 * KTN * PROW + KTN * sizeof(float) + 128 * sizeof(float);
   if (nch == 1) {
@@ -601,8 +616,12 @@ template <typename T>
 int linout_launch(const LinOutArgs& a, int B, hipStream_t st) {
   const int n = a.n, nch = a.C / 32;
   dim3 grid((n + 128 * LINOUT_TPB - 1) / (128 * LINOUT_TPB), B);
-  const size_t lds = (size_t)nch * 4 * 128 * 16 + (size_t)nch * 8 * 1024 + (size_t)4 * 2 * nch * 1024 + 128 * sizeof(float);
-  if (nch == 1) {
+  const size_t lds = (size_t)nch * 4 * 128 * 16 + ((size_t)nch << a.wsplit) * 8 * 1024 + (size_t)4 * 2 * nch * 1024 + 128 * sizeof(float);
+  if (a.wsplit) {
+    LD_REQUIRE(nch <= 2, "ld_linattn_out: two-term weights are built for C = 32 / 64 (got %d)", a.C);
+    if (nch == 1) LD_LAUNCH((linout_kernel<T, 1, 1>), grid, dim3(256), lds, st, a);
+    else LD_LAUNCH((linout_kernel<T, 2, 1>), grid, dim3(256), lds, st, a);
+  } else if (nch == 1) {
     LD_LAUNCH((linout_kernel<T, 1>), grid, dim3(256), lds, st, a);
   } else if (nch == 2) {
     LD_LAUNCH((linout_kernel<T, 2>), grid, dim3(256), lds, st, a);
@@ -617,11 +636,18 @@ int linout_launch(const LinOutArgs& a, int B, hipStream_t st) {
 
 extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const float* kshift, float* ctx_part, int B,
                                 int n, int C, int heads, int dim_head, int nchunks, int dtype, void* stream) {
+  return ld_linattn_kvctx_terms(x, wkv_packed, kshift, ctx_part, B, n, C, heads, dim_head, nchunks, dtype, 1, stream);
+}
+
+extern "C" int ld_linattn_kvctx_terms(const void* x, const void* wkv_packed, const float* kshift, float* ctx_part, int B,
+                                      int n, int C, int heads, int dim_head, int nchunks, int dtype, int weight_terms,
+                                      void* stream) {
+  LD_REQUIRE(weight_terms == 1 || weight_terms == 2, "ld_linattn_kvctx: weight_terms %d", weight_terms);
   LD_REQUIRE(x && wkv_packed && ctx_part && B > 0 && n > 0 && nchunks > 0, "ld_linattn_kvctx: bad args");
   LD_REQUIRE(ld_dtype_16(dtype), "ld_linattn_kvctx: 16-bit storage only (fp32 uses the unfused path)");
   LD_REQUIRE(dim_head == 32 && (C == 32 || C == 64 || C == 128), "ld_linattn_kvctx: dim_head 32, C in {32,64,128}");
   LD_REQUIRE(kshift == nullptr || heads == 4, "ld_linattn_kvctx: the single-sweep mode (kshift) needs heads == 4");
-  KvCtxArgs a{x, (const uint4*)wkv_packed, ctx_part, n, C, heads, nchunks, kshift};
+  KvCtxArgs a{x, (const uint4*)wkv_packed, ctx_part, n, C, heads, nchunks, kshift, weight_terms == 2 ? 1 : 0};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return LD_DISPATCH16(dtype, kvctx_launch<T>(a, B, st));
 }
@@ -629,9 +655,16 @@ extern "C" int ld_linattn_kvctx(const void* x, const void* wkv_packed, const flo
 extern "C" int ld_linattn_out(const void* x, const void* wq_packed, const float* qshift, const void* mfold,
                               const float* bias, const float* g2, void* out, int B, int n, int C, float q_scale,
                               int dtype, void* stream) {
+  return ld_linattn_out_terms(x, wq_packed, qshift, mfold, bias, g2, out, B, n, C, q_scale, dtype, 1, stream);
+}
+
+extern "C" int ld_linattn_out_terms(const void* x, const void* wq_packed, const float* qshift, const void* mfold,
+                                    const float* bias, const float* g2, void* out, int B, int n, int C, float q_scale,
+                                    int dtype, int weight_terms, void* stream) {
+  LD_REQUIRE(weight_terms == 1 || weight_terms == 2, "ld_linattn_out: weight_terms %d", weight_terms);
   LD_REQUIRE(x && wq_packed && mfold && bias && g2 && out && B > 0 && n > 0, "ld_linattn_out: bad args");
   LD_REQUIRE(ld_dtype_16(dtype), "ld_linattn_out: 16-bit storage only (fp32 uses the unfused path)");
   LD_REQUIRE(C == 32 || C == 64 || C == 128, "ld_linattn_out: C in {32,64,128}");
-  LinOutArgs a{x, (const uint4*)wq_packed, (const uint4*)mfold, bias, g2, out, n, C, q_scale, qshift};
+  LinOutArgs a{x, (const uint4*)wq_packed, (const uint4*)mfold, bias, g2, out, n, C, q_scale, qshift, weight_terms == 2 ? 1 : 0};
   return LD_DISPATCH16(dtype, linout_launch<T>(a, B, reinterpret_cast<hipStream_t>(stream)));
 }

@@ -208,13 +208,16 @@ class Unet(nn.Module):
                 if c not in (32, 64, 128):
                     continue
 
-                def pack_rows(rows):
-                    out = torch.empty(rows.numel(), dtype=tdt, device=dev)
+                terms = 2 if (c in (32, 64) and heads == 4 and self._layer_level(name) < self.weight_split_levels) else 1
+
+                def pack_rows(rows, terms=terms):
+                    out = torch.empty(terms * rows.numel(), dtype=tdt, device=dev)
                     rows = rows.contiguous()
-                    cabi.check(lib.ld_pack_conv_weight(rows.data_ptr(), scale.data_ptr(), out.data_ptr(), rows.shape[0],
-                                                       c, 1, 0, dt, st), "pack " + name)
+                    cabi.check(lib.ld_pack_conv_weight_terms(rows.data_ptr(), scale.data_ptr(), out.data_ptr(), rows.shape[0],
+                                                             c, 1, 0, dt, terms, st), "pack " + name)
                     P.setdefault("keep", []).append(rows)
                     return out
+                P.setdefault("attn_terms", {})[base] = terms
                 P["wq"][base] = pack_rows(w[:hid])
                 per_head = []
                 for h in range(heads):
@@ -576,15 +579,16 @@ class _Plan:
         out = self.buf(h, w, c)
         self.keep += [ctx, wfold, wout, wq, wkv, kshift, qshift, bias, g2, out, x]
         npx = B * n
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_kvctx(x.data_ptr(), wkv.data_ptr(), ksp, ctx.data_ptr(), B, n, c,
-                                                                  heads, 32, nchunks, dt, st), "linattn_kvctx"),
+        terms = self.P.get("attn_terms", {}).get(p, 1)
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_kvctx_terms(x.data_ptr(), wkv.data_ptr(), ksp, ctx.data_ptr(), B, n, c,
+                                                                        heads, 32, nchunks, dt, terms, st), "linattn_kvctx"),
                   "linattn_kvctx", nbytes=npx * c * es, flops=2 * npx * c * 2 * hid * (1 if kshift is not None else 2) + 2 * npx * hid * 32)
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctxfold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold.data_ptr(), B, c,
                                                                     heads, 32, 1, dt, st), "linattn_ctxfold"),
                   "linattn_ctxfold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
         scale = cfg.attn_dim_head ** -0.5
-        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_out(x.data_ptr(), wq.data_ptr(), qsp, wfold.data_ptr(), bias.data_ptr(),
-                                                                g2.data_ptr(), out.data_ptr(), B, n, c, scale, dt, st),
+        self._raw(ops, lambda st: cabi.check(lib.ld_linattn_out_terms(x.data_ptr(), wq.data_ptr(), qsp, wfold.data_ptr(), bias.data_ptr(),
+                                                                      g2.data_ptr(), out.data_ptr(), B, n, c, scale, dt, terms, st),
                                              "linattn_out"),
                   "linattn_out", nbytes=2 * npx * c * es, flops=2 * npx * hid * c * 2)
         return out

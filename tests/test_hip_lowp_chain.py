@@ -67,16 +67,17 @@ def test_cfg2_chain_16bit_vs_reference_golden(golden, dtype):
     assert growth_hip <= 2.0 * growth_ref, (dtype, growth_hip, growth_ref)
 
 
-# Two-term weights on the full- and half-resolution layers (Unet.set_weight_split_levels(2), +10 % step time): measured
-# round 3 at t = 100: bf16 6.8e-3 / 7.8e-4 (one-term 2.6e-2 / 3.2e-3), fp16 1.2e-3 / 1.2e-4 (4.0e-3 / 4.6e-4)
-BOUND_T100_SPLIT = {"bf16": (1.4e-2, 1.3e-3), "fp16": (2.5e-3, 2.0e-4)}
+# Two-term weights on the full- and half-resolution layers -- 3x3 / 1x1 convolutions and the linear-attention projections
+# (Unet.set_weight_split_levels(2), +10 % step time): measured round 3 at t = 100: bf16 7.4e-3 / 5.6e-4 (one-term
+# 2.6e-2 / 3.2e-3), fp16 7.1e-4 / 7.0e-5 (4.0e-3 / 4.6e-4); what is left is the activation roundings' floor
+BOUND_T100_SPLIT = {"bf16": (1.4e-2, 9e-4), "fp16": (1.5e-3, 1.2e-4)}
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_cfg2_chain_with_two_term_weights(golden, dtype):
     """The accuracy mode of the 16-bit storage types: W = hi + lo for the convolutions of the first two resolution levels
     (the weights whose rounding tools/exp_error_budget.py found to carry 90 % of the chain's distance to the reference).
-    Same run and golden as above; the distance must come down by at least 2.5x at t = 100 and stay below its own bounds."""
+    Same run and golden as above; the distance must come down by at least 3.5x at t = 100 and stay below its own bounds."""
     g = golden("g5_cfg2_mri128")
     cond = torch.from_numpy(rng.uniform((1, 1, 128, 128), 5, 1, 0.0, 2.0))
     gd = make(dict(mode="mri"), dict(data="mri"), 128, 1000, dtype=dtype)
@@ -88,7 +89,7 @@ def test_cfg2_chain_with_two_term_weights(golden, dtype):
         print(f"G5 cfg2 {dtype}, two-term weights on 2 levels, x after t={t:3d}: max-abs {e[t][0]:.3e} mean-abs {e[t][1]:.3e}")
     for t in (999, 750, 500, 250, 100):
         assert e[t][0] <= BOUND_T100_SPLIT[dtype][0] and e[t][1] <= BOUND_T100_SPLIT[dtype][1], (dtype, t, e[t])
-    assert e[100][1] <= W_ONLY_T100[dtype][1] / 2.5, (dtype, e[100])
+    assert e[100][1] <= W_ONLY_T100[dtype][1] / 3.5, (dtype, e[100])
     assert e[0][1] <= 0.5 * BOUND_FINAL_MEAN[dtype], (dtype, e[0])
 
 
