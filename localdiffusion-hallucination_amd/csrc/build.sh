@@ -31,11 +31,13 @@ for f in runtime collective pack stage conv3x3 conv3x3_c32 conv1x1 conv_image gn
   fi
 done
 case "$FLAGS" in *LD_DEBUG_VARIANTS*)   # shelved experiments that a --debug-variants library can switch on
-  if [ ! -f build/conv3x3_ksplit.o ] || [ ../../tools/experiments/conv3x3_ksplit.hip -nt build/conv3x3_ksplit.o ] || [ common.hip.h -nt build/conv3x3_ksplit.o ]; then
-    $HIPCC $FLAGS -mllvm -amdgpu-mfma-vgpr-form -c ../../tools/experiments/conv3x3_ksplit.hip -o build/conv3x3_ksplit.o &
-    pids+=($!)
-  fi ;;
-  *) rm -f build/conv3x3_ksplit.o ;;
+  for x in conv3x3_ksplit conv3x3_ring; do
+    if [ ! -f build/$x.o ] || [ ../../tools/experiments/$x.hip -nt build/$x.o ] || [ common.hip.h -nt build/$x.o ]; then
+      $HIPCC $FLAGS -mllvm -amdgpu-mfma-vgpr-form -c ../../tools/experiments/$x.hip -o build/$x.o &
+      pids+=($!)
+    fi
+  done ;;
+  *) rm -f build/conv3x3_ksplit.o build/conv3x3_ring.o ;;
 esac
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC build/*.o -ldl -o liblocaldiff_hip.so

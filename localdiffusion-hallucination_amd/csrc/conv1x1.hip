@@ -18,6 +18,8 @@
 
 namespace {
 
+constexpr int EPI_GN_TAIL_RES = 6;   // internal: LD_EPI_GN_TAIL with the `residual` operand set (conv_fusion's invariant half of res_conv)
+
 struct Conv1Dev {
   SrcDev s[2];
   int nsrc, unshuffle, rms_in;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   const int HW = a.H * a.W, p0 = blockIdx.x * NPT;
   const int mt_total = a.Cout / 16;
 
-  if (EPI == LD_EPI_GN_TAIL)
+  if (EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES)
     build_gn_coef(a.tail, b, 0, (long)HW, s_tcoef, reinterpret_cast<double*>(s_tcoef + 2 * a.Cout), tid, 256);
 
   f32x4 acc[MT][NW];
@@ -81,10 +83,11 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 
   // The epilogue's second operand (residual / GroupNorm-tail input) does not depend on the GEMM: request it now,
   // so its global round trip overlaps the K loop instead of following it.
-  constexpr bool HAS_OP2 = EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES || EPI == LD_EPI_GN_TAIL;
+  constexpr bool TAIL = EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES;
+  constexpr bool HAS_OP2 = EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES || TAIL;
   float op2[HAS_OP2 ? MT : 1][HAS_OP2 ? NW : 1][4];
   if constexpr (HAS_OP2) {
-    const T* src2 = reinterpret_cast<const T*>(EPI == LD_EPI_GN_TAIL ? a.tail.data : a.res);
+    const T* src2 = reinterpret_cast<const T*>(TAIL ? a.tail.data : a.res);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int p = p0 + (wv * NW + j) * 16 + px;
@@ -95,7 +98,6 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
       }
     }
   }
-
   const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)b * a.w_bstride);
 
   // global address of this thread's fragment of chunk `ch` for tile pixel slot `it` (nullptr: past the image)
@@ -211,6 +213,36 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   }
 
   // ---- epilogue: lane holds channels (m0+m)*16 + 4kq + r of pixel p0 + (wv*NW+j)*16 + px
+  // The other operands of the epilogue -- bias, the RMSNorm gain g2, the step-invariant half of res_conv (conv_fusion):
+  // loaded inside the store loop, each of them put a wait BEHIND the stores of the previous pixel row (the
+  // vector-memory counter is in order and counts stores: a store round trip exposed per row,
+  // tools/scan_store_waits.py).  They are requested together here -- after the K loop, whose staging registers are
+  // dead by now: held across the loop they cost 8-100 registers -- and retired before the first store.
+  float bv[MT][4], g2v[EPI == LD_EPI_RMS_RES ? MT : 1][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int co = (m0 + m) * 16 + kq * 4;
+    const float4 t = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bv[m][0] = t.x; bv[m][1] = t.y; bv[m][2] = t.z; bv[m][3] = t.w;
+    if constexpr (EPI == LD_EPI_RMS_RES) {
+      const float4 g = *reinterpret_cast<const float4*>(a.g2 + co);
+      g2v[m][0] = g.x; g2v[m][1] = g.y; g2v[m][2] = g.z; g2v[m][3] = g.w;
+    }
+  }
+  constexpr bool HAS_OP3 = EPI == EPI_GN_TAIL_RES;      // (its own instantiation: 4*MT*NW registers only conv_fusion needs)
+  float op3[HAS_OP3 ? MT : 1][HAS_OP3 ? NW : 1][4];
+  if constexpr (HAS_OP3) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int p = p0 + (wv * NW + j) * 16 + px;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        op3[m][j][0] = op3[m][j][1] = op3[m][j][2] = op3[m][j][3] = 0.f;
+        if (p < HW) load4<T>(reinterpret_cast<const T*>(a.res) + ((size_t)b * HW + p) * a.Cout + (m0 + m) * 16 + kq * 4, op3[m][j]);
+      }
+    }
+  }
+
   T* out = reinterpret_cast<T*>(a.out);
   const bool q_part = (m0 * 16) < a.hidden;
   const bool k_part = a.kmax != nullptr && (m0 * 16) >= a.hidden && (m0 * 16) < 2 * a.hidden;
@@ -219,6 +251,19 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) cmax[m][r] = -INFINITY;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {                       // every epilogue operand has landed before the first store
+    asm volatile("" ::"v"(bv[m][0]), "v"(bv[m][1]), "v"(bv[m][2]), "v"(bv[m][3]));
+    if constexpr (EPI == LD_EPI_RMS_RES) asm volatile("" ::"v"(g2v[m][0]), "v"(g2v[m][1]), "v"(g2v[m][2]), "v"(g2v[m][3]));
+    if constexpr (HAS_OP2) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(op2[m][j][0]), "v"(op2[m][j][1]), "v"(op2[m][j][2]), "v"(op2[m][j][3]));
+    }
+    if constexpr (HAS_OP3) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(op3[m][j][0]), "v"(op3[m][j][1]), "v"(op3[m][j][2]), "v"(op3[m][j][3]));
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     const int qq = (wv * NW + j) * 16 + px;
@@ -230,7 +275,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
     for (int m = 0; m < MT; ++m) {
       const int co = (m0 + m) * 16 + kq * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[m][r] = acc[m][j][r] * rinv + (a.bias ? a.bias[co + r] : 0.f);
+      for (int r = 0; r < 4; ++r) v[m][r] = acc[m][j][r] * rinv + bv[m][r];
     }
     if (EPI == LD_EPI_QKV_LINEAR && q_part) {
       // softmax over the 32 channels of each head = 2 channel tiles x 4 regs x 4 kq lanes
@@ -270,9 +315,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
       const float inv = rms_rinv<DT<T>::precise>(ss);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int co = (m0 + m) * 16 + kq * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[m][r] = v[m][r] * inv * a.g2[co + r];
+        for (int r = 0; r < 4; ++r) v[m][r] = v[m][r] * inv * g2v[m][r];
       }
     }
     if (k_part && valid) {
@@ -289,16 +333,14 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
         if constexpr (EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[m][r] += op2[m][j][r];
-        } else if constexpr (EPI == LD_EPI_GN_TAIL) {
+        } else if constexpr (TAIL) {
           float rv[4] = {op2[m][j][0], op2[m][j][1], op2[m][j][2], op2[m][j][3]};
           affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
-          if (a.res) {                                   // step-invariant half of res_conv (conv_fusion)
-            float r2[4];
-            load4<T>(reinterpret_cast<const T*>(a.res) + o, r2);
+          if constexpr (HAS_OP3) {                       // step-invariant half of res_conv (conv_fusion)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[m][r] += r2[r];
+            for (int r = 0; r < 4; ++r) v[m][r] += op3[m][j][r];
           }
         }
         store4<T>(out + o, v[m]);
@@ -331,7 +373,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 template <typename T, int MT, int NW, int EPI>
 int launch_epi(const Conv1Dev& a, hipStream_t st) {
   constexpr int NPT = 64 * NW;
-  const size_t tail = NPT * sizeof(float) + (EPI == LD_EPI_GN_TAIL ? 2 * a.Cout * sizeof(float) + 64 * sizeof(double) : 0);
+  const size_t tail = NPT * sizeof(float) + (EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES ? 2 * a.Cout * sizeof(float) + 64 * sizeof(double) : 0);
   const size_t chunk = 4 * NPT * 16 + MT * 1024;
   const int HW = a.H * a.W;
   dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
@@ -362,7 +404,7 @@ int launch(const Conv1Dev& a, hipStream_t st) {
     case LD_EPI_QKV_FULL: return launch_epi<T, MT, NW, LD_EPI_QKV_FULL>(a, st);
     case LD_EPI_RMS_RES: return launch_epi<T, MT, NW, LD_EPI_RMS_RES>(a, st);
     case LD_EPI_RES: return launch_epi<T, MT, NW, LD_EPI_RES>(a, st);
-    default: return launch_epi<T, MT, NW, LD_EPI_GN_TAIL>(a, st);
+    default: return a.res ? launch_epi<T, MT, NW, EPI_GN_TAIL_RES>(a, st) : launch_epi<T, MT, NW, LD_EPI_GN_TAIL>(a, st);
   }
 }
 
@@ -417,6 +459,8 @@ extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
     LD_REQUIRE(p->hidden > 0 && p->hidden % 64 == 0 && p->Cout == 3 * p->hidden,
                "ld_conv1x1: QKV epilogue needs Cout == 3*hidden, hidden %% 64 == 0");
   if (p->epilogue == LD_EPI_RMS_RES) LD_REQUIRE(p->g2 && p->residual, "ld_conv1x1: RMS_RES needs g2/residual");
+  LD_REQUIRE((reinterpret_cast<uintptr_t>(p->bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(p->g2) & 15) == 0,
+             "ld_conv1x1: bias / g2 must be 16-byte aligned (read as float4)");
   if (p->epilogue == LD_EPI_RES) LD_REQUIRE(p->residual, "ld_conv1x1: RES needs residual");
   Conv1Dev a;
   for (int s = 0; s < p->nsrc; ++s) {

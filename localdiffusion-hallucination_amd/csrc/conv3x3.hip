@@ -25,6 +25,7 @@
 int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st);   // conv3x3_c32.hip
 #ifdef LD_DEBUG_VARIANTS
 int ld_conv3x3_ksplit_try(const ld_conv3x3_args* p, hipStream_t st);   // tools/experiments/conv3x3_ksplit.hip (shelved, finding 52)
+int ld_conv3x3_ring_try(const ld_conv3x3_args* p, hipStream_t st);     // tools/experiments/conv3x3_ring.hip (finding 58)
 #endif
 
 #include "conv3x3_body.hip.h"
@@ -183,6 +184,10 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }
 #ifdef LD_DEBUG_VARIANTS
+  if (!ld_stage_recording()) {               // experiment: both operands by LDS-DMA, one barrier per chunk
+    const int rc = ld_conv3x3_ring_try(p, st);
+    if (rc != 0) return rc < 0 ? rc : LD_OK;
+  }
   static const int ksplit = getenv("LD_CONV_KSPLIT") ? atoi(getenv("LD_CONV_KSPLIT")) : 0;
   if (ksplit && !ld_stage_recording() && p->weight_terms != 2) {                                       // shelved experiment: weights in registers, K split over waves
     const int rc = ld_conv3x3_ksplit_try(p, st);

@@ -327,20 +327,43 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.f;
+  // Every load of the epilogue is retired BEFORE its first store.  The vector-memory counter is in order and counts
+  // stores too: hipcc placed its wait for bias[m] (requested before the chunk loop, long since landed) in front of
+  // m-tile m's first use, behind the stores of the m-tiles before it, and across the `if (valid)` branches its
+  // bookkeeping falls back to small counts -- vmcnt(1) behind four stores, vmcnt(0) behind six in the 64-channel
+  // tile: a store round trip exposed per pair of m-tiles; with an addend, one load -> wait -> store chain per fragment
+  // (tools/scan_store_waits.py on the hipcc -S output).
+#pragma unroll
+  for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(bias[m].x), "v"(bias[m].y), "v"(bias[m].z), "v"(bias[m].w));
+  const bool rows_in = ty0 + TR <= H && tx0 + TC <= W;      // workgroup-uniform: no ragged row / column in this tile
+  float ad[MT][NW][4];
+  if (a.addend) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int gy = ty0 + wv * NW + j;
+        const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
+        ad[m][j][0] = ad[m][j][1] = ad[m][j][2] = ad[m][j][3] = 0.f;
+        if (rows_in || (gy < H && gx < W)) load4<T>(reinterpret_cast<const T*>(addb + off), ad[m][j]);
+      }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(ad[m][j][0]), "v"(ad[m][j][1]), "v"(ad[m][j][2]), "v"(ad[m][j][3]));
+  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const float4 bv = bias[m];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int gy = ty0 + wv * NW + j;
-      const bool valid = gy < H && gx < W && half == 0;   // (SK: half 0 holds the joined sums)
+      const bool valid = (rows_in || (gy < H && gx < W)) && half == 0;   // (SK: half 0 holds the joined sums)
       const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
       float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
-      if (valid && a.addend) {
-        float ad[4];
-        load4<T>(reinterpret_cast<const T*>(addb + off), ad);
+      if (a.addend) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += ad[r];
+        for (int r = 0; r < 4; ++r) v[r] += ad[m][j][r];
       }
       if (valid) {
         if (!(DBG & 8)) store4<T>(reinterpret_cast<T*>(outb + off), v);

@@ -354,7 +354,9 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
   if (tracing) tr_t[13] = __builtin_readcyclecounter();
 
   if (a.ostats) {                                                 // one flush per workgroup
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (every DMA of this wave has landed -- each item waited for its own -- so only stores are outstanding: they need
+    //  no wait here; a vmcnt(0) would expose their round trip in front of the statistics)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < MT; ++m)

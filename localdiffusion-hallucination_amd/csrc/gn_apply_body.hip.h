@@ -16,14 +16,16 @@ struct GnDev {
 // advances by a constant -- no 64-bit division, no LDS coefficient reads and no feature branches in the
 // streaming loop (measured on the generic loop: 8-10 us for 8 MB launches whose traffic is worth 3 us).
 template <typename T, bool HAS_B>
-__device__ __forceinline__ void eval_pixel(const GnDev& g, const float* ca, const float* sa, const float* cb, const float* sb,
-                                           size_t elem, float* v) {
+__device__ __forceinline__ void load_pixel(const GnDev& g, size_t elem, uint4& ra, uint4& rb) {
+  ra = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.a.data) + elem);
+  rb = make_uint4(0u, 0u, 0u, 0u);
+  if (HAS_B) rb = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.b.data) + elem);
+}
+template <typename T, bool HAS_B>
+__device__ __forceinline__ void finish_pixel(const GnDev& g, const float* ca, const float* sa, const float* cb, const float* sb,
+                                             const uint4& ra, const uint4& rb, float* v) {
   constexpr int E = DT<T>::E;
   constexpr bool P = DT<T>::precise;
-  const T* xa = reinterpret_cast<const T*>(g.a.data);
-  uint4 ra = *reinterpret_cast<const uint4*>(xa + elem);
-  uint4 rb = make_uint4(0u, 0u, 0u, 0u);
-  if (HAS_B) rb = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(g.b.data) + elem);
   unpack16<T>(ra, v);
   affine_act_n<P, E>(v, ca, sa, g.a.act);
   if (HAS_B) {
@@ -34,6 +36,13 @@ __device__ __forceinline__ void eval_pixel(const GnDev& g, const float* ca, cons
     for (int e = 0; e < E; ++e) v[e] += u[e];
   }
   act_n<P, E>(v, g.final_act);
+}
+template <typename T, bool HAS_B>
+__device__ __forceinline__ void eval_pixel(const GnDev& g, const float* ca, const float* sa, const float* cb, const float* sb,
+                                           size_t elem, float* v) {
+  uint4 ra, rb;
+  load_pixel<T, HAS_B>(g, elem, ra, rb);
+  finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, ra, rb, v);
 }
 
 // The kernel body as a device function of the (virtual) workgroup index (gn_apply_kernel: its own index; stage.hip: the
@@ -79,10 +88,24 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, cons
     }
     const int step = gdx * ppb;
     int opix = bx * ppb + tid / fpp;
-    // two pixels per iteration: both fragments' loads are in flight before the first is consumed
+    // two pixels per iteration, every load of the pair requested before the first store: written as two calls of
+    // one(), hipcc kept the second pixel's loads BEHIND the first pixel's store (it cannot prove that `out` does not
+    // alias the inputs), and the wait for them then also drains that store -- the vector-memory counter is in order and
+    // counts stores (tools/scan_store_waits.py)
     for (; opix + step < npix_out; opix += 2 * step) {
-      one(opix, c, ca, sa, cb, sb);
-      one(opix + step, c, ca, sa, cb, sb);
+      if constexpr (!POOL) {
+        uint4 ra0, rb0, ra1, rb1;
+        load_pixel<T, HAS_B>(g, in0 + (size_t)opix * C + c, ra0, rb0);
+        load_pixel<T, HAS_B>(g, in0 + (size_t)(opix + step) * C + c, ra1, rb1);
+        float v0[E], v1[E];
+        finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, ra0, rb0, v0);
+        finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, ra1, rb1, v1);
+        *reinterpret_cast<uint4*>(out + (size_t)opix * C + c) = pack16<T>(v0);
+        *reinterpret_cast<uint4*>(out + (size_t)(opix + step) * C + c) = pack16<T>(v1);
+      } else {
+        one(opix, c, ca, sa, cb, sb);
+        one(opix + step, c, ca, sa, cb, sb);
+      }
     }
     if (opix < npix_out) one(opix, c, ca, sa, cb, sb);
   } else {

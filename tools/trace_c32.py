@@ -30,5 +30,7 @@ def run(B, cin, cout, H, W, dtype="bf16", prologue=False, stats=True):
     print("  " + " ".join(f"{n}:{t[k] - t[0]}" for k, n in enumerate(names) if t[k]))
 
 if __name__ == "__main__":
-    run(8, 32, 32, 256, 256, stats=False)
-    run(8, 32, 32, 256, 256, prologue=True)
+    for B in [int(v) for v in os.environ.get("LD_TRACE_B", "8").split(",")]:
+        run(B, 32, 32, 256, 256, stats=False)
+        run(B, 32, 32, 256, 256, stats=True)
+        run(B, 32, 32, 256, 256, prologue=True)
