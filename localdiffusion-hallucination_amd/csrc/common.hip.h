@@ -334,6 +334,23 @@ __device__ __forceinline__ float wave16_sum(float v) {
   return v;
 }
 
+// fp64 value of another lane of the same 16-lane row (DPP on the two halves: VALU speed, no LDS crossbar)
+template <int CTRL> __device__ __forceinline__ double dpp_mov_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum over aligned groups of n = 1, 2, 4, 8 or 16 consecutive lanes of a 16-lane row; every lane of a group ends with
+// the group's total.  All 16 lanes of the row must be active.
+__device__ __forceinline__ double row_group_sum_d(double v, int n) {
+  if (n >= 2) v += dpp_mov_d<0xB1>(v);     // quad_perm [1,0,3,2]: lane ^ 1
+  if (n >= 4) v += dpp_mov_d<0x4E>(v);     // quad_perm [2,3,0,1]: lane ^ 2
+  if (n >= 8) v += dpp_mov_d<0x141>(v);    // row_half_mirror: the other quad of the 8 (whose lanes all hold its total)
+  if (n >= 16) v += dpp_mov_d<0x128>(v);   // row_ror:8: the other half of the row
+  return v;
+}
+
 __device__ __forceinline__ double wave16_sum_d(double v) {
   v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
   return v;

@@ -137,10 +137,10 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
 
 }  // namespace
 
-// Debug hook (not part of the public ABI): cycle stamps of the last LD_CONV_DEBUG=64 launch (16 uint64).
+// Debug hook (not part of the public ABI): cycle stamps of the last LD_CONV_DEBUG=64 launch (24 uint64).
 extern "C" int ld_debug_conv_trace(unsigned long long* host) {
   LD_HIP(hipDeviceSynchronize());
-  LD_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * 16));
+  LD_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * 24));
   return LD_OK;
 }
 

@@ -22,7 +22,7 @@ struct Conv3Dev {
 };
 
 // LD_CONV_DEBUG=64: cycle stamps of one workgroup from the middle of the launch (tools/trace_conv.py)
-__device__ unsigned long long g_conv_trace[16];
+__device__ unsigned long long g_conv_trace[24];
 #define TR_STAMP(k) do { if ((DBG & 64) && tracing) tr_t[k] = __builtin_readcyclecounter(); } while (0)
 
 // SK ("split-K halves", bf16 small-map launches): a 512-thread workgroup whose two halves each own every other
@@ -58,7 +58,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   double* s_stat = reinterpret_cast<double*>(s_coef + 2 * ctot);
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;   // within the half
-  unsigned long long tr_t[16] = {0};
+  unsigned long long tr_t[24] = {0};
   const bool tracing = (DBG & 64) && threadIdx.x == 0 && bz == gdz / 2 && by == 0 &&
                        bx == (gdx * 5) / 8;
   TR_STAMP(0);
@@ -375,6 +375,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   TR_STAMP(9);
   if (a.ostats) {
     __syncthreads();                            // s_stat may still be read as build_gn_coef scratch
+    TR_STAMP(16);
     const int gs = a.Cout / a.ogroups;          // channels per group; gs <= 16*MT by construction
     const int ngrp_blk = (16 * MT) / gs;
     const int stripe = bx % LD_STAT_STRIPES;
@@ -392,9 +393,30 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
           s_stat[(wv * 2 + 1) * 4 * MT + m * 4 + kq] = (double)s2;
         }
       }
+      TR_STAMP(17);
       __syncthreads();
-      if (tid < 2 * ngrp_blk && half == 0) {
-        const int gi = tid >> 1, k = tid & 1, q4 = gs >> 2;
+      TR_STAMP(18);
+      const int q4 = gs >> 2;                     // tile entries (m, kq) per group
+      if ((q4 & (q4 - 1)) == 0) {
+        // Lanes 0-15 of wave 0 take the sums, lanes 16-31 the sums of squares; lane e owns tile entry e = 4m + kq: four
+        // independent LDS reads (one per wave), then the group's q4 entries meet by DPP inside the 16-lane row.  One
+        // thread per group walking its 4*q4 values (up to 32 dependent LDS read -> fp64 add pairs) took 1,400-2,000
+        // cycles of a workgroup's ~5,000-cycle epilogue (tools/trace_conv.py).
+        if (tid < 32 && half == 0) {
+          const int k = tid >> 4, e = tid & 15;
+          double v = 0.0;
+          if (e < 4 * MT) {
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) v += s_stat[(w4 * 2 + k) * 4 * MT + e];
+          }
+          v = row_group_sum_d(v, q4);
+          if (e < 4 * MT && (e & (q4 - 1)) == 0) {
+            const int g = (m0 * 16) / gs + e / q4;
+            atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + g) * 2 + k], v);
+          }
+        }
+      } else if (tid < 2 * ngrp_blk && half == 0) {
+        const int gi = tid >> 1, k = tid & 1;
         double acc1 = 0.0;
         for (int w4 = 0; w4 < 4; ++w4)
           for (int c = 0; c < q4; ++c) acc1 += s_stat[(w4 * 2 + k) * 4 * MT + gi * q4 + c];
@@ -424,10 +446,11 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
     }
   }
   if ((DBG & 64) && tracing) {
+    tr_t[19] = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores have left
     tr_t[10] = __builtin_readcyclecounter();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) g_conv_trace[k] = tr_t[k];
+    for (int k = 0; k < 24; ++k) g_conv_trace[k] = tr_t[k];
   }
 }
 

@@ -370,12 +370,24 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
       }
     __syncthreads();
     const int gs = 32 / a.ogroups;
-    if (tid < 2 * a.ogroups) {
+    const int stripe = blockIdx.x % LD_STAT_STRIPES;
+    if (gs <= 16) {
+      // lanes 0-31 of wave 0: the sums of channel `lane`, lanes 32-63: the sums of squares; eight independent LDS reads
+      // (one per wave), then the gs channels of a group meet by DPP inside their 16-lane row (conv3x3_body.hip.h)
+      if (tid < 64) {
+        const int k = tid >> 5, ch = tid & 31;
+        double v = 0.0;
+#pragma unroll
+        for (int w8 = 0; w8 < NWAVE; ++w8) v += s_stat[(w8 * 2 + k) * 32 + ch];
+        v = row_group_sum_d(v, gs);
+        if ((ch & (gs - 1)) == 0)
+          atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + ch / gs) * 2 + k], v);
+      }
+    } else if (tid < 2 * a.ogroups) {
       const int gi = tid >> 1, k = tid & 1;
       double acc1 = 0.0;
       for (int w8 = 0; w8 < NWAVE; ++w8)
         for (int c = 0; c < gs; ++c) acc1 += s_stat[(w8 * 2 + k) * 32 + gi * gs + c];
-      const int stripe = blockIdx.x % LD_STAT_STRIPES;
       atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + gi) * 2 + k], acc1);
     }
   }

@@ -25,17 +25,20 @@ def run(B, cin, cout, H, W, dtype="bf16", prologue=False, stats=True):
     for _ in range(5):
         hh.conv3x3([src], w, b, B, H, W, cout, dtype, stats=st)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 24)()
     fn = cabi.lib().ld_debug_conv_trace
     fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_ulonglong)]
     assert fn(buf) == 0
-    t = [buf[k] for k in range(16)]
+    t = [buf[k] for k in range(24)]
     print(f"== {cin}->{cout}@{H}x{W} B{B} prologue={prologue} stats={stats}")
     prev = t[0]
     for k, n in enumerate(NAMES):
         if t[k]:
             print(f"   {n:32s} +{t[k] - prev:6d}   (at {t[k] - t[0]})")
             prev = t[k]
+    if t[16] and t[19]:      # the statistics epilogue
+        print(f"   statistics: barrier +{t[16] - t[9]}, 16-lane sums + LDS +{t[17] - t[16]}, barrier +{t[18] - t[17]}, "
+              f"fp64 group sums + atomics +{t[19] - t[18]}, store drain +{t[10] - t[19]}")
     if t[11] and t[15]:      # steady state: chunk 2 of the loop
         for k, n in ((12, "chunk 2: LDS written (vmcnt wait + transform + writes)"), (13, "chunk 2: barrier"),
                      (14, "chunk 2: next chunk's loads issued"), (15, "chunk 2: fragment reads + MFMAs")):
