@@ -267,6 +267,10 @@ static inline SrcDev to_dev(const ld_src& s) {
 // (GroupNorm eps 1e-5, biased variance: ddpm.py:174 / unet_model.py:21; FiLM: ddpm.py:181-183).
 // npix = pixels the statistics were accumulated over (the producer's H*W).
 // `red` is LDS scratch for 2*groups doubles.  Contains two __syncthreads(): call from all threads.
+// PRECISE (fp32 storage, the parity mode): IEEE fp64 divide and square root for 1/n and 1/sqrt(var + eps).  16-bit
+// storage: v_rcp_f32 / v_rsq_f32 (1 ulp of fp32 each, four orders below the storage rounding) -- the two fp64 divisions
+// and the square root are ~100 dependent instructions at the head of every consumer workgroup.
+template <bool PRECISE = true>
 __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, long npix, float* coef,
                                               double* red, int tid, int nthreads) {
   const int C = S.C, G = S.groups, gs = C / G;
@@ -292,11 +296,11 @@ __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, 
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int s = 0; s < LD_STAT_STRIPES; ++s) { s1 += st1[s]; s2 += st2[s]; }
-    const double inv_n = 1.0 / ((double)npix * gs);
+    const double inv_n = PRECISE ? 1.0 / ((double)npix * gs) : (double)__builtin_amdgcn_rcpf((float)npix * (float)gs);
     const double mean = s1 * inv_n;
     double var = s2 * inv_n - mean * mean;
     var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float rstd = PRECISE ? (float)(1.0 / sqrt(var + 1e-5)) : __builtin_amdgcn_rsqf((float)(var + 1e-5));
     gstat[tid] = (float)mean;
     gstat[G + tid] = rstd;
   }

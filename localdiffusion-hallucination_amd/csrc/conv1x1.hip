@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   const int mt_total = a.Cout / 16;
 
   if (EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES)
-    build_gn_coef(a.tail, b, 0, (long)HW, s_tcoef, reinterpret_cast<double*>(s_tcoef + 2 * a.Cout), tid, 256);
+    build_gn_coef<DT<T>::precise>(a.tail, b, 0, (long)HW, s_tcoef, reinterpret_cast<double*>(s_tcoef + 2 * a.Cout), tid, 256);
 
   f32x4 acc[MT][NW];
 #pragma unroll

@@ -196,7 +196,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
         const SrcDev S = s ? a.s[1] : a.s[0];
         if (S.stats) {
           const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
-          build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, (int)threadIdx.x, SK ? 512 : 256);
+          build_gn_coef<DT<T>::precise>(S, b, trow, npix, s_coef + off, s_stat, (int)threadIdx.x, SK ? 512 : 256);
         }
         off += 2 * S.C;
       }

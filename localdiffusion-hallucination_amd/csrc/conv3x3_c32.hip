@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
       const SrcDev S = s ? a.s[1] : a.s[0];
       if (S.stats) {
         const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
-        build_gn_coef(S, b, trow, npix, s_coef + off, s_stat, tid, 512);
+        build_gn_coef<DT<T>::precise>(S, b, trow, npix, s_coef + off, s_stat, tid, 512);
       }
       off += 2 * S.C;
     }

@@ -54,8 +54,8 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, cons
   const int trow = g.t_ptr ? *g.t_ptr : 0;
   const long npix_in = (long)g.H * g.W;
   double* red = reinterpret_cast<double*>(s_coef + 4 * C);
-  build_gn_coef(g.a, b, trow, npix_in, s_coef, red, tid, 256);
-  if (HAS_B && g.b.stats) build_gn_coef(g.b, b, trow, npix_in, s_coef + 2 * C, red, tid, 256);
+  build_gn_coef<DT<T>::precise>(g.a, b, trow, npix_in, s_coef, red, tid, 256);
+  if (HAS_B && g.b.stats) build_gn_coef<DT<T>::precise>(g.b, b, trow, npix_in, s_coef + 2 * C, red, tid, 256);
   const int fpp = C / E;                               // fragments per pixel
   const int Ho = POOL ? g.H / 2 : g.H, Wo = POOL ? g.W / 2 : g.W;
   const int npix_out = Ho * Wo;
