@@ -129,18 +129,18 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
     const char* sp = (si ? sbase1 : sbase0) + (long)(cs - si * nch0) * CK * (long)sizeof(T);
     // two-term weights: the lo pass (odd virtual chunk) multiplies the SAME halo tile, which is still in LDS
     const bool same_halo = !SK && !DEEP && ws && (ch & 1);
+    const char* wc = reinterpret_cast<const char*>(wg) + (long)ch * wstride;
+#pragma unroll
+    for (int k = 0; k < WU; ++k) {
+      wx[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (woffb[k] != ~0u) wx[k] = *reinterpret_cast<const uint4*>(wc + woffb[k]);
+    }
     if (!same_halo) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         hx[it] = make_uint4(0u, 0u, 0u, 0u);
         if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sp + (si ? hoffb1[it] : hoffb0[it]));
       }
-    }
-    const char* wc = reinterpret_cast<const char*>(wg) + (long)ch * wstride;
-#pragma unroll
-    for (int k = 0; k < WU; ++k) {
-      wx[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (woffb[k] != ~0u) wx[k] = *reinterpret_cast<const uint4*>(wc + woffb[k]);
     }
   };
   auto write_lds = [&](int ch, const uint4 (&hx)[ITER], const uint4 (&wx)[WU]) {
@@ -159,6 +159,11 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
     }
     const bool same_halo = !SK && !DEEP && ws && (ch & 1);
 #pragma unroll
+    for (int k = 0; k < WU; ++k) {
+      const int u = k * 256 + tid;
+      if (u < UNITS) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wx[k];
+    }
+#pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int q = (it * 4 + wv) * 16 + px;
       if (q < NPIXP && !same_halo) {
@@ -171,11 +176,6 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
         }
         *reinterpret_cast<uint4*>(s_x + kq * PLANE + q * 16) = raw;
       }
-    }
-#pragma unroll
-    for (int k = 0; k < WU; ++k) {
-      const int u = k * 256 + tid;
-      if (u < UNITS) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wx[k];
     }
   };
 
