@@ -336,42 +336,53 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
 #pragma unroll
   for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(bias[m].x), "v"(bias[m].y), "v"(bias[m].z), "v"(bias[m].w));
   const bool rows_in = ty0 + TR <= H && tx0 + TC <= W;      // workgroup-uniform: no ragged row / column in this tile
-  float ad[MT][NW][4];
-  if (a.addend) {
+  // FULL: every pixel of the tile is inside the image and there is no addend (all but one launch of a cfg3 step): the
+  // stores and the statistics run without per-fragment execution masks and selects.
+  auto emit = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    float ad[FULL ? 1 : MT][FULL ? 1 : NW][4];
+    if constexpr (!FULL) {
+      if (a.addend) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < NW; ++j) {
+            const int gy = ty0 + wv * NW + j;
+            const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
+            ad[m][j][0] = ad[m][j][1] = ad[m][j][2] = ad[m][j][3] = 0.f;
+            if (rows_in || (gy < H && gx < W)) load4<T>(reinterpret_cast<const T*>(addb + off), ad[m][j]);
+          }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(ad[m][j][0]), "v"(ad[m][j][1]), "v"(ad[m][j][2]), "v"(ad[m][j][3]));
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 bv = bias[m];
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         const int gy = ty0 + wv * NW + j;
+        const bool valid = FULL || ((rows_in || (gy < H && gx < W)) && half == 0);   // (SK: half 0 holds the joined sums)
         const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
-        ad[m][j][0] = ad[m][j][1] = ad[m][j][2] = ad[m][j][3] = 0.f;
-        if (rows_in || (gy < H && gx < W)) load4<T>(reinterpret_cast<const T*>(addb + off), ad[m][j]);
-      }
+        float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
+        if constexpr (!FULL) {
+          if (a.addend) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+            for (int r = 0; r < 4; ++r) v[r] += ad[m][j][r];
+          }
+        }
+        if (valid) {
+          if (!(DBG & 8)) store4<T>(reinterpret_cast<T*>(outb + off), v);
 #pragma unroll
-      for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(ad[m][j][0]), "v"(ad[m][j][1]), "v"(ad[m][j][2]), "v"(ad[m][j][3]));
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const float4 bv = bias[m];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int gy = ty0 + wv * NW + j;
-      const bool valid = (rows_in || (gy < H && gx < W)) && half == 0;   // (SK: half 0 holds the joined sums)
-      const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
-      float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
-      if (a.addend) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += ad[m][j][r];
-      }
-      if (valid) {
-        if (!(DBG & 8)) store4<T>(reinterpret_cast<T*>(outb + off), v);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
+          for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
+        }
       }
     }
-  }
+  };
+  if (rows_in && !a.addend && half == 0) emit(std::true_type{});
+  else emit(std::false_type{});
   TR_STAMP(9);
   if (a.ostats) {
     __syncthreads();                            // s_stat may still be read as build_gn_coef scratch
