@@ -169,6 +169,26 @@ template <> __device__ __forceinline__ void load4<f16>(const f16* p, float* v) {
   uint2 r = *reinterpret_cast<const uint2*>(p);
   unpack_f16x2(r.x, v[0], v[1]); unpack_f16x2(r.y, v[2], v[3]);
 }
+// Four consecutive elements as they sit in memory (no conversion): a load whose conversion is written next to it
+// inside an `if (in range)` branch is waited for INSIDE that branch -- one dependent round trip per load.  Load raw
+// (from a clamped, always-valid address), convert where the value is used.
+template <typename T> struct Raw4 { typedef uint2 type; };
+template <> struct Raw4<float> { typedef float4 type; };
+template <typename T> __device__ __forceinline__ typename Raw4<T>::type load4_raw(const T* p) {
+  return *reinterpret_cast<const typename Raw4<T>::type*>(p);
+}
+template <typename T> __device__ __forceinline__ void unpack4(const typename Raw4<T>::type& r, float* v);
+template <> __device__ __forceinline__ void unpack4<float>(const float4& r, float* v) { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+template <> __device__ __forceinline__ void unpack4<bf16>(const uint2& r, float* v) {
+  v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+  v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack4<f16>(const uint2& r, float* v) {
+  unpack_f16x2(r.x, v[0], v[1]); unpack_f16x2(r.y, v[2], v[3]);
+}
+template <typename R> __device__ __forceinline__ void pin_raw4(const R& r);
+template <> __device__ __forceinline__ void pin_raw4<uint2>(const uint2& r) { asm volatile("" ::"v"(r.x), "v"(r.y)); }
+template <> __device__ __forceinline__ void pin_raw4<float4>(const float4& r) { asm volatile("" ::"v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w)); }
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return (float)v; }

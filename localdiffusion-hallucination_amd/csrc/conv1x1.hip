@@ -85,17 +85,18 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   // so its global round trip overlaps the K loop instead of following it.
   constexpr bool TAIL = EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES;
   constexpr bool HAS_OP2 = EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES || TAIL;
-  float op2[HAS_OP2 ? MT : 1][HAS_OP2 ? NW : 1][4];
+  // Raw and from a clamped address (pixels past the image are never stored): as `if (p < HW) load4(...)` every one of
+  // the MT * NW loads was waited for inside its own branch -- 8-16 dependent round trips (3-6 us) in front of the K loop
+  // of every launch with a second operand (tools/scan_serial_loads.py).
+  typedef typename Raw4<T>::type R4;
+  R4 op2[HAS_OP2 ? MT : 1][HAS_OP2 ? NW : 1];
   if constexpr (HAS_OP2) {
     const T* src2 = reinterpret_cast<const T*>(TAIL ? a.tail.data : a.res);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const int p = p0 + (wv * NW + j) * 16 + px;
+      const int p = min(p0 + (wv * NW + j) * 16 + px, HW - 1);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        if (p < HW) load4<T>(src2 + ((size_t)b * HW + p) * a.Cout + (m0 + m) * 16 + kq * 4, op2[m][j]);
-        else op2[m][j][0] = op2[m][j][1] = op2[m][j][2] = op2[m][j][3] = 0.f;
-      }
+      for (int m = 0; m < MT; ++m) op2[m][j] = load4_raw<T>(src2 + ((size_t)b * HW + p) * a.Cout + (m0 + m) * 16 + kq * 4);
     }
   }
   const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)b * a.w_bstride);
@@ -230,16 +231,14 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
     }
   }
   constexpr bool HAS_OP3 = EPI == EPI_GN_TAIL_RES;      // (its own instantiation: 4*MT*NW registers only conv_fusion needs)
-  float op3[HAS_OP3 ? MT : 1][HAS_OP3 ? NW : 1][4];
+  R4 op3[HAS_OP3 ? MT : 1][HAS_OP3 ? NW : 1];
   if constexpr (HAS_OP3) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const int p = p0 + (wv * NW + j) * 16 + px;
+      const int p = min(p0 + (wv * NW + j) * 16 + px, HW - 1);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        op3[m][j][0] = op3[m][j][1] = op3[m][j][2] = op3[m][j][3] = 0.f;
-        if (p < HW) load4<T>(reinterpret_cast<const T*>(a.res) + ((size_t)b * HW + p) * a.Cout + (m0 + m) * 16 + kq * 4, op3[m][j]);
-      }
+      for (int m = 0; m < MT; ++m)
+        op3[m][j] = load4_raw<T>(reinterpret_cast<const T*>(a.res) + ((size_t)b * HW + p) * a.Cout + (m0 + m) * 16 + kq * 4);
     }
   }
 
@@ -257,11 +256,11 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
     if constexpr (EPI == LD_EPI_RMS_RES) asm volatile("" ::"v"(g2v[m][0]), "v"(g2v[m][1]), "v"(g2v[m][2]), "v"(g2v[m][3]));
     if constexpr (HAS_OP2) {
 #pragma unroll
-      for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(op2[m][j][0]), "v"(op2[m][j][1]), "v"(op2[m][j][2]), "v"(op2[m][j][3]));
+      for (int j = 0; j < NW; ++j) pin_raw4(op2[m][j]);
     }
     if constexpr (HAS_OP3) {
 #pragma unroll
-      for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(op3[m][j][0]), "v"(op3[m][j][1]), "v"(op3[m][j][2]), "v"(op3[m][j][3]));
+      for (int j = 0; j < NW; ++j) pin_raw4(op3[m][j]);
     }
   }
 #pragma unroll
@@ -331,16 +330,21 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
         const int co = (m0 + m) * 16 + kq * 4;
         const size_t o = ((size_t)b * HW + p) * a.Cout + co;
         if constexpr (EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES) {
+          float o2[4];
+          unpack4<T>(op2[m][j], o2);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[m][r] += op2[m][j][r];
+          for (int r = 0; r < 4; ++r) v[m][r] += o2[r];
         } else if constexpr (TAIL) {
-          float rv[4] = {op2[m][j][0], op2[m][j][1], op2[m][j][2], op2[m][j][3]};
+          float rv[4];
+          unpack4<T>(op2[m][j], rv);
           affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
           if constexpr (HAS_OP3) {                       // step-invariant half of res_conv (conv_fusion)
+            float o3[4];
+            unpack4<T>(op3[m][j], o3);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[m][r] += op3[m][j][r];
+            for (int r = 0; r < 4; ++r) v[m][r] += o3[r];
           }
         }
         store4<T>(out + o, v[m]);
