@@ -32,6 +32,29 @@ from . import rng, schedule
 _REPLACE_OUT = ("mnist", "mvtec", "oct", "imagenet")
 _RESYNC = int(os.environ.get("LD_SUB_RESYNC", "32"))     # steps between phase alignments of the sub-batch streams
 _RESYNC_EARLY = int(os.environ.get("LD_SUB_RESYNC_EARLY", "1"))     # ... and before each of the first steps
+# The host enqueues at most this many steps ahead of the GPU (0: no limit).  Unthrottled, the host builds and writes
+# packets without a pause until the hardware queue is full (~38 steps of 2 x 106 nodes) and the GPU runs ~4 % slower for
+# exactly that long: 20 timed steps 1.549 -> 1.491 ms per step with a limit of 1 (1.500 with 2, 1.530 with 8), 400 steps
+# unchanged (there the full queue paces the host anyway); DESIGN finding 64, tools/exp_short_knobs.sh.
+_AHEAD = int(os.environ.get("LD_SUB_AHEAD", "1"))
+
+
+class _Pace:
+    """Keeps the host at most ``_AHEAD`` replayed steps ahead of the streams (events, spin-wait on the oldest)."""
+
+    def __init__(self, streams):
+        self.streams, self.pending = streams, []
+
+    def step_enqueued(self):
+        if _AHEAD <= 0:
+            return
+        evs = [torch.cuda.Event() for _ in self.streams]
+        for e, gs in zip(evs, self.streams):
+            e.record(gs)
+        self.pending.append(evs)
+        if len(self.pending) > _AHEAD:
+            for e in self.pending.pop(0):
+                e.synchronize()
 
 
 def _align_streams(streams):
@@ -173,6 +196,7 @@ class _SubBatches:
         # taken, persists: line the streams up when they start (their encoders were enqueued one after the other) and
         # again every LD_SUB_RESYNC steps (default 32; 0: never).
         h0 = time.perf_counter()
+        pace = _Pace(self.streams)
         lib.ld_range_push(b"steps (graph replay, %d sub-batches)" % self.S)
         for k in range(max(todo)):
             # (and in front of step 1: the host enqueues the streams' first replays one after the other, 0.3 ms apart, so
@@ -182,6 +206,7 @@ class _SubBatches:
             for i, gs in enumerate(self.streams):
                 if k < todo[i]:
                     cabi.check(lib.ld_graph_launch(ex[i], gs.cuda_stream), "graph_launch")
+            pace.step_enqueued()
         lib.ld_range_pop()
         # host seconds spent enqueueing replays (includes back-pressure once the hardware queue is full)
         self.host_launch_s = getattr(self, "host_launch_s", 0.0) + time.perf_counter() - h0
@@ -300,10 +325,12 @@ class _DdimBranches:
                     cabi.check(rc, "graph_end")
                     self.graphs[key] = g
                 ex[i] = self.graphs[key]
+        pace = _Pace(self.streams)
         for k in range(max(todo)):
             for i, gs in enumerate(self.streams):
                 if k < todo[i]:
                     cabi.check(lib.ld_graph_launch(ex[i], gs.cuda_stream), "graph_launch")
+            pace.step_enqueued()
         for sp, gs, xv in zip(self.plans, self.streams, (x_out, x_in)):
             with torch.cuda.stream(gs):
                 xv.copy_(sp.x_in)
