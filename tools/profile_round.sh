@@ -19,6 +19,7 @@ tail -1 $OUT/${TAG}_fp16_bench.log > $OUT/${TAG}_fp16_bench.json
 rm -rf /tmp/prof_ks /tmp/prof_ks1 /tmp/prof_f /tmp/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -o r -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_ks.log 2>&1 < /dev/null
 cp $(find /tmp/prof_ks -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+python3 $R/tools/conv_path_union.py $(find /tmp/prof_ks -name '*kernel_trace.csv' | head -1) > $OUT/${TAG}_conv_path_union.txt 2>&1
 LD_SUB_BATCHES=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks1 -o r -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_s1_ks.log 2>&1 < /dev/null
 cp $(find /tmp/prof_ks1 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_s1_kernel_stats.csv
 LD_SUB_BATCHES=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_pf.log 2>&1 < /dev/null
