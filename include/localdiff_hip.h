@@ -70,6 +70,9 @@ int ld_memset_zero(void* ptr, size_t bytes, void* stream);
 int ld_timing_begin(int max_launches);
 int ld_timing_count(void);
 int ld_timing_end(float* ms, int cap, int* count);
+/* the same, with the launches' positions on the device clock: start_ms[i] / stop_ms[i] = begin / end of launch i relative
+ * to the begin of launch 0 (one clock for every stream: the overlap of launches on different streams can be read off) */
+int ld_timing_end_abs(float* start_ms, float* stop_ms, int cap, int* count);
 int ld_event_create(void** ev_out);
 int ld_event_record(void* ev, void* stream);
 int ld_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on stop */

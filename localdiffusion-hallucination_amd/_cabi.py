@@ -99,6 +99,7 @@ _SIGS = {
     "ld_timing_begin": (C.c_int, [C.c_int]),
     "ld_timing_count": (C.c_int, []),
     "ld_timing_end": (C.c_int, [vp, C.c_int, vp]),
+    "ld_timing_end_abs": (C.c_int, [vp, vp, C.c_int, vp]),
     "ld_randn": (C.c_int, [vp, i64, u64, i64, i64, vp, vp]),
     "ld_randn_at": (C.c_int, [vp, i64, i64, u64, i64, i64, vp, vp]),
     "ld_step_add": (C.c_int, [vp, C.c_int, vp]),

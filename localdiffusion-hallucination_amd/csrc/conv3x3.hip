@@ -33,6 +33,10 @@ int ld_conv3x3_ring_try(const ld_conv3x3_args* p, hipStream_t st);     // tools/
 
 namespace {
 
+#ifdef LD_DEBUG_VARIANTS
+int g_span_shape[1024][5];
+#endif
+
 template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
 int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   constexpr int TR = 4 * NW, HR = TR + 2, HC = 18;
@@ -63,7 +67,7 @@ template <typename T, int MT, int NW, bool DEEP>
 int launch(const Conv3Dev& a, hipStream_t st) {
 #ifdef LD_DEBUG_VARIANTS
   if constexpr (std::is_same<T, bf16>::value && !DEEP) {
-    switch (a.dbg) {
+    switch (a.dbg & 255) {
       case 1: return launch_dbg<T, MT, NW, DEEP, 1>(a, st);
       case 2: return launch_dbg<T, MT, NW, DEEP, 2>(a, st);
       case 3: return launch_dbg<T, MT, NW, DEEP, 3>(a, st);
@@ -73,6 +77,9 @@ int launch(const Conv3Dev& a, hipStream_t st) {
       case 12: return launch_dbg<T, MT, NW, DEEP, 12>(a, st);
       case 15: return launch_dbg<T, MT, NW, DEEP, 15>(a, st);
       case 64: return launch_dbg<T, MT, NW, DEEP, 64>(a, st);
+      case 128:                                        // launch spans: the same RAW / general split as production
+        if (!a.s[0].stats && !(a.nsrc > 1 && a.s[1].stats)) return launch_dbg<T, MT, NW, DEEP, 128, false, true>(a, st);
+        return launch_dbg<T, MT, NW, DEEP, 128>(a, st);
       default: break;
     }
   }
@@ -137,6 +144,17 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
 
 }  // namespace
 
+#ifdef LD_DEBUG_VARIANTS
+// Debug hook (not part of the public ABI): LD_CONV_DEBUG=128 launch spans.  spans[slot] = {start, end} on the 100 MHz
+// real-time clock, shapes[slot] = {B, H, W, Cin, Cout} of the call that owns the slot (1,024 slots, round robin).
+extern "C" int ld_debug_conv_spans(unsigned long long* spans, int* shapes) {
+  LD_HIP(hipDeviceSynchronize());
+  LD_HIP(hipMemcpyFromSymbol(spans, HIP_SYMBOL(g_conv_span), sizeof(unsigned long long) * 2048));
+  for (int i = 0; i < 1024 * 5; ++i) shapes[i] = g_span_shape[i / 5][i % 5];
+  return LD_OK;
+}
+#endif
+
 // Debug hook (not part of the public ABI): cycle stamps of the last LD_CONV_DEBUG=64 launch (24 uint64).
 extern "C" int ld_debug_conv_trace(unsigned long long* host) {
   LD_HIP(hipDeviceSynchronize());
@@ -178,6 +196,15 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   a.wsplit = p->weight_terms == 2 ? 1 : 0;
   static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
   a.dbg = dbg;
+#ifdef LD_DEBUG_VARIANTS
+  if (dbg == 128) {                                    // launch spans: a slot per call, its shape kept for the reader
+    static int calls = 0;
+    const int slot = calls++ & 1023;
+    g_span_shape[slot][0] = p->B; g_span_shape[slot][1] = p->H; g_span_shape[slot][2] = p->W;
+    g_span_shape[slot][3] = p->src[0].C + (p->nsrc > 1 ? p->src[1].C : 0); g_span_shape[slot][4] = p->Cout;
+    a.dbg = 128 | (slot << 8);
+  }
+#endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!ld_stage_recording() && p->weight_terms != 2) {   // (the persistent kernel keeps ONE chunk of weights in registers)
     const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages

@@ -23,6 +23,11 @@ struct Conv3Dev {
 
 // LD_CONV_DEBUG=64: cycle stamps of one workgroup from the middle of the launch (tools/trace_conv.py)
 __device__ unsigned long long g_conv_trace[24];
+// LD_CONV_DEBUG=128 (debug-variants builds): every launch owns a slot (a.dbg >> 8) and leaves its position on the 100 MHz
+// real-time clock there -- [0] when workgroup (0,0,0) started (last replay wins), [1] the latest end of any workgroup (the
+// clock is monotonic, so the last replay wins as well).  One clock for every stream: the overlap of launches of the two
+// sub-batch streams INSIDE replayed graphs can be read off (tools/exp_conv_path_overlap.py).
+__device__ unsigned long long g_conv_span[1024][2];
 #define TR_STAMP(k) do { if ((DBG & 64) && tracing) tr_t[k] = __builtin_readcyclecounter(); } while (0)
 
 // SK ("split-K halves", bf16 small-map launches): a 512-thread workgroup whose two halves each own every other
@@ -62,6 +67,8 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   const bool tracing = (DBG & 64) && threadIdx.x == 0 && bz == gdz / 2 && by == 0 &&
                        bx == (gdx * 5) / 8;
   TR_STAMP(0);
+  if ((DBG & 128) && threadIdx.x == 0 && bx == 0 && by == 0 && bz == 0)
+    g_conv_span[(a.dbg >> 8) & 1023][0] = __builtin_amdgcn_s_memrealtime();
   const int b = bz, m0 = by * MT;
   const int ty0 = (bx / a.tiles_x) * TR, tx0 = (bx % a.tiles_x) * TC;
   const int H = a.H, W = a.W;
@@ -455,6 +462,10 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
         atomicAdd(&a.ostats[(((size_t)b * LD_STAT_STRIPES + stripe) * a.ogroups + g) * 2 + k], acc1);
       }
     }
+  }
+  if ((DBG & 128) && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores have left
+    atomicMax(&g_conv_span[(a.dbg >> 8) & 1023][1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
   if ((DBG & 64) && tracing) {
     tr_t[19] = __builtin_readcyclecounter();

@@ -113,6 +113,20 @@ extern "C" int ld_timing_end(float* ms, int cap, int* count) {
   return LD_OK;
 }
 
+extern "C" int ld_timing_end_abs(float* start_ms, float* stop_ms, int cap, int* count) {
+  LD_REQUIRE(g_tn >= 0, "ld_timing_end_abs: no session");
+  LD_REQUIRE(start_ms && stop_ms, "ld_timing_end_abs: null output");
+  const int n = g_tn;
+  g_tn = -1;
+  if (count) *count = n;
+  for (int i = 0; i < n && i < cap; ++i) {
+    LD_HIP(hipEventSynchronize(g_tev[2 * i + 1]));
+    LD_HIP(hipEventElapsedTime(&start_ms[i], g_tev[0], g_tev[2 * i]));
+    LD_HIP(hipEventElapsedTime(&stop_ms[i], g_tev[0], g_tev[2 * i + 1]));
+  }
+  return LD_OK;
+}
+
 extern "C" int ld_memset_zero(void* ptr, size_t bytes, void* stream) {
   LD_REQUIRE(ptr || bytes == 0, "ld_memset_zero: null");
   if (bytes) LD_HIP(hipMemsetAsync(ptr, 0, bytes, reinterpret_cast<hipStream_t>(stream)));
