@@ -272,7 +272,6 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
     float v[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const int co = (m0 + m) * 16 + kq * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[m][r] = acc[m][j][r] * rinv + bv[m][r];
     }
