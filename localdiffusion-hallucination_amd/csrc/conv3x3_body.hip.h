@@ -347,7 +347,9 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   // stores and the statistics run without per-fragment execution masks and selects.
   auto emit = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
-    float ad[FULL ? 1 : MT][FULL ? 1 : NW][4];
+    // the addend (conv_fusion's pre-statistics constants): raw loads from an always-valid address (rows / columns past the
+    // image are never stored), all requested before the first wait, converted where they are used (finding 63)
+    typename Raw4<T>::type ad[FULL ? 1 : MT][FULL ? 1 : NW];
     if constexpr (!FULL) {
       if (a.addend) {
 #pragma unroll
@@ -355,14 +357,14 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
 #pragma unroll
           for (int j = 0; j < NW; ++j) {
             const int gy = ty0 + wv * NW + j;
+            const bool in = rows_in || (gy < H && gx < W);
             const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
-            ad[m][j][0] = ad[m][j][1] = ad[m][j][2] = ad[m][j][3] = 0.f;
-            if (rows_in || (gy < H && gx < W)) load4<T>(reinterpret_cast<const T*>(addb + off), ad[m][j]);
+            ad[m][j] = load4_raw<T>(reinterpret_cast<const T*>(addb + (in ? off : 0u)));
           }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int j = 0; j < NW; ++j) asm volatile("" ::"v"(ad[m][j][0]), "v"(ad[m][j][1]), "v"(ad[m][j][2]), "v"(ad[m][j][3]));
+          for (int j = 0; j < NW; ++j) pin_raw4(ad[m][j]);
       }
     }
 #pragma unroll
@@ -376,8 +378,10 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
         float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
         if constexpr (!FULL) {
           if (a.addend) {
+            float av[4];
+            unpack4<T>(ad[m][j], av);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += ad[m][j][r];
+            for (int r = 0; r < 4; ++r) v[r] += av[r];
           }
         }
         if (valid) {
