@@ -60,10 +60,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
   wait_vmcnt_range<0, 63>(n);
 }
 
-template <typename T, int NCH, int R, int DBG>
-__global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
+// NWAVE = 8: the 512-thread workgroup of the description (16 x 16-pixel tiles, 21-KiB ring slots).  NWAVE = 4 ("lite",
+// experiment LD_CONV_C32_LITE): 256 threads, 8 x 16-pixel tiles, 12-KiB slots -- a footprint (R = 4: 48 KB of LDS) that
+// lets the persistent workgroups of BOTH sub-batch streams, and other kernels, share a CU.
+template <typename T, int NCH, int R, int DBG, int NWAVE = 8>
+__global__ __launch_bounds__(64 * NWAVE) void conv3x3_c32_kernel(C32Dev a) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
-  constexpr int MT = 2, NW = 2, NWAVE = 8, TR = NW * NWAVE, TC = 16, HR = TR + 2, HC = TC + 2;
+  constexpr int NTHR = 64 * NWAVE;
+  constexpr int MT = 2, NW = 2, TR = NW * NWAVE, TC = 16, HR = TR + 2, HC = TC + 2;
   constexpr int NPIX = HR * HC, NBLK = (NPIX + 15) / 16, BPW = (NBLK + NWAVE - 1) / NWAVE;   // 324 px, 21 blocks, 3
   constexpr int XBUF = NBLK * 1024;                                                         // bytes per ring slot
   constexpr int WCH = 9 * MT * 1024;                                                        // bytes per weight chunk
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) Areg[tap][m] = wg[(tap * MT + m) * 64 + lane];
     } else {
-      for (int u = tid; u < NCH * 9 * MT * 64; u += 512) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[u];
+      for (int u = tid; u < NCH * 9 * MT * 64; u += NTHR) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wg[u];
     }
   }
   float4 bias[MT];
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
       const SrcDev S = s ? a.s[1] : a.s[0];
       if (S.stats) {
         const long npix = S.ups ? (long)(H / 2) * (W / 2) : (long)H * W;
-        build_gn_coef<DT<T>::precise>(S, b, trow, npix, s_coef + off, s_stat, tid, 512);
+        build_gn_coef<DT<T>::precise>(S, b, trow, npix, s_coef + off, s_stat, tid, NTHR);
       }
       off += 2 * S.C;
     }
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(512) void conv3x3_c32_kernel(C32Dev a) {
 
 template <typename T, int NCH, int R, int DBG>
 int launch_c32_dbg(C32Dev& a, size_t lds, dim3 grid, hipStream_t st) {
-  if (lds > 65536) LD_HIP(ld_allow_lds(conv3x3_c32_kernel<T, NCH, R, DBG>, lds));   // cached per device
+  if (lds > 65536) LD_HIP(ld_allow_lds((conv3x3_c32_kernel<T, NCH, R, DBG>), lds));   // cached per device
   LD_LAUNCH((conv3x3_c32_kernel<T, NCH, R, DBG>), grid, dim3(512), lds, st, a);
   LD_LAUNCH_CHECK("conv3x3_c32");
   return LD_OK;
@@ -437,6 +441,22 @@ int launch_c32(const C32Dev& a0, hipStream_t st) {
   return launch_c32_dbg<T, NCH, R, 0>(a, lds, grid, st);
 }
 
+// "lite" geometry (NWAVE = 4): 8 x 16-pixel tiles, 256-thread workgroups, LD_CONV_C32_LITE_WGS of them per launch
+template <typename T, int R>
+int launch_c32_lite(const C32Dev& a0, hipStream_t st) {
+  C32Dev a = a0;
+  a.tiles_x = a.W / 16;
+  a.ntiles = a.tiles_x * (a.H / 8);
+  const size_t lds = (size_t)R * 12 * 1024 + 2 * a.s[0].C * sizeof(float);
+  static const int wgs = getenv("LD_CONV_C32_LITE_WGS") ? atoi(getenv("LD_CONV_C32_LITE_WGS")) : 256;
+  int G = (wgs + a.B - 1) / a.B;
+  if (G > a.ntiles) G = a.ntiles;
+  if (lds > 65536) LD_HIP(ld_allow_lds((conv3x3_c32_kernel<T, 1, R, 0, 4>), lds));
+  LD_LAUNCH((conv3x3_c32_kernel<T, 1, R, 0, 4>), dim3(G, a.B), dim3(256), lds, st, a);
+  LD_LAUNCH_CHECK("conv3x3_c32 (lite)");
+  return LD_OK;
+}
+
 }  // namespace
 
 // Returns 1 if this launch is handled here, 0 if the generic kernel must take it, <0 on error.
@@ -451,8 +471,13 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   if (ctot != ck || p->nsrc != 1) return 0;
   if (p->out_stats && (p->out_groups <= 0 || 32 % p->out_groups != 0)) return 0;
   static const long min_tiles = getenv("LD_CONV_C32_MIN_TILES") ? atol(getenv("LD_CONV_C32_MIN_TILES")) : 2048;
+  // experiment (finding 66): launches of LD_CONV_C32_LITE .. min_tiles - 1 tiles -- the 4-patch launches of the
+  // two-sub-batch regime -- on the 256-thread geometry (0 = off)
+  static const long lite_min = getenv("LD_CONV_C32_LITE") ? atol(getenv("LD_CONV_C32_LITE")) : 0;
+  static const int lite_ring = getenv("LD_CONV_C32_LITE_R") ? atoi(getenv("LD_CONV_C32_LITE_R")) : 4;
   const long tiles = (long)(p->W / 16) * (p->H / 16) * p->B;
-  if (tiles < min_tiles) return 0;                     // too few tiles to amortise a persistent workgroup
+  const bool lite = lite_min > 0 && tiles >= lite_min && tiles < min_tiles && p->dtype != LD_F32;
+  if (tiles < min_tiles && !lite) return 0;            // too few tiles to amortise a persistent workgroup
   for (int s = 0; s < p->nsrc; ++s) {                  // the kernel uses 32-bit element offsets
     const long ld = p->src[s].pix_stride > 0 ? p->src[s].pix_stride : p->src[s].C;
     if ((long)p->B * p->H * p->W * ld >= (1L << 31)) return 0;
@@ -468,7 +493,10 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   a.dbg = dbg;
   static const int ring = getenv("LD_CONV_C32_R") ? atoi(getenv("LD_CONV_C32_R")) : 6;   // experiment: ring depth
   int rc;
-  if (p->dtype == LD_F32) rc = launch_c32<float, 1, 6>(a, st);
+  if (lite) {
+    if (p->dtype == LD_F16) rc = lite_ring == 6 ? launch_c32_lite<f16, 6>(a, st) : launch_c32_lite<f16, 4>(a, st);
+    else rc = lite_ring == 6 ? launch_c32_lite<bf16, 6>(a, st) : (lite_ring == 3 ? launch_c32_lite<bf16, 3>(a, st) : launch_c32_lite<bf16, 4>(a, st));
+  } else if (p->dtype == LD_F32) rc = launch_c32<float, 1, 6>(a, st);
   else if (p->dtype == LD_F16) rc = ring == 4 ? launch_c32<f16, 1, 4>(a, st) : launch_c32<f16, 1, 6>(a, st);
   else if (ring == 4) rc = launch_c32<bf16, 1, 4>(a, st);
 #ifdef LD_DEBUG_VARIANTS
