@@ -633,6 +633,54 @@ def test_conv1x1_grouped_staging_is_bitwise_the_plain_k_loop(tmp_path):
         assert np.array_equal(res["1"][k], res["0"][k]), (k, float(np.abs(res["1"][k] - res["0"][k]).max()))
 
 
+def _c32_probe(path):
+    """Child process of test_persistent_conv_geometries_agree: Cout = 32 single-chunk 3x3 convolutions (plain, with a
+    GroupNorm + SiLU prologue, with output statistics), results to ``path``."""
+    out = {}
+    for dtype in ("bf16", "fp16"):
+        for (B, H, W) in ((2, 32, 48), (3, 64, 64)):
+            x = hh.rand((B, 32, H, W), 700 + H)
+            w, b = hh.rand((32, 32, 3, 3), 701, -0.1, 0.1), hh.rand((32,), 702).to(hh.DEV)
+            wp = hh.pack(w, dtype, 3)
+            gn = (hh.stats_striped(x, 8), hh.rand((32,), 703, 0.5, 1.5).to(hh.DEV), hh.rand((32,), 704).to(hh.DEV), 8)
+            for name, src in (("plain", hh.make_src(hh.nhwc(x, dtype), 32)), ("pro", hh.make_src(hh.nhwc(x, dtype), 32, gn=gn, act=cabi.ACT_SILU))):
+                st = hh.stats_buffer(B, 8)
+                y = hh.conv3x3([src], wp, b, B, H, W, 32, dtype, stats=st, groups=8)
+                out[f"{dtype}_{H}_{name}"] = y.float().cpu().numpy()
+                out[f"{dtype}_{H}_{name}_stats"] = st.sum(1).cpu().numpy()
+    torch.cuda.synchronize()
+    np.savez(path, **out)
+
+
+@pytest.mark.gpu
+def test_persistent_conv_geometries_agree(tmp_path):
+    """The C = 32 convolution has three code paths: the generic kernel (LD_CONV_NO_C32=1), the persistent ring kernel
+    (512 threads, 16 x 16 tiles; LD_CONV_C32_MIN_TILES=1 puts every eligible launch on it) and its 256-thread geometry
+    (LD_CONV_C32_LITE=1, DESIGN finding 66).  Same MFMA order in all three: outputs bit-equal, statistics equal up to
+    the length of their fp32 partial sums (a persistent workgroup keeps its sums in registers over all its tiles)."""
+    import subprocess
+    import sys
+    envs = {"generic": dict(LD_CONV_NO_C32="1"), "ring": dict(LD_CONV_C32_MIN_TILES="1"), "lite": dict(LD_CONV_C32_LITE="1")}
+    res = {}
+    for name, env in envs.items():
+        path = str(tmp_path / f"c32_{name}.npz")
+        code = (f"import sys; sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); "
+                f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); "
+                f"import test_hip_ops as t; t._c32_probe({path!r})")
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[name] = np.load(path)
+    assert len(res["generic"].files) == 2 * 2 * 2 * 2
+    for k in res["generic"].files:
+        for other in ("ring", "lite"):
+            a, b = res["generic"][k], res[other][k]
+            assert np.isfinite(b).all(), (other, k)
+            if k.endswith("_stats"):
+                assert float(np.abs(a - b).max()) <= 2e-6 * float(np.abs(a).max()), (other, k, float(np.abs(a - b).max() / np.abs(a).max()))
+            else:
+                assert np.array_equal(a, b), (other, k, float(np.abs(a - b).max()))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", LOWP)
 def test_two_term_weights_remove_the_weight_rounding(dtype):
