@@ -34,9 +34,10 @@ _RESYNC = int(os.environ.get("LD_SUB_RESYNC", "32"))     # steps between phase a
 _RESYNC_EARLY = int(os.environ.get("LD_SUB_RESYNC_EARLY", "1"))     # ... and before each of the first steps
 # The host enqueues at most this many steps ahead of the GPU (0: no limit).  Unthrottled, the host builds and writes
 # packets without a pause until the hardware queue is full (~38 steps of 2 x 106 nodes) and the GPU runs ~4 % slower for
-# exactly that long: 20 timed steps 1.549 -> 1.491 ms per step with a limit of 1 (1.500 with 2, 1.530 with 8), 400 steps
-# unchanged (there the full queue paces the host anyway); DESIGN finding 64, tools/exp_short_knobs.sh.
-_AHEAD = int(os.environ.get("LD_SUB_AHEAD", "1"))
+# exactly that long: 20 timed steps 1.519 -> 1.483 ms per step with a limit of 2 (1.479 with 1, but with twice the
+# run-to-run spread: one late host wake-up is a GPU bubble; 1.53 with 8), 400 steps unchanged (there the full queue paces
+# the host anyway); DESIGN finding 64, tools/exp_short_knobs.sh, tools/exp_stability.sh.
+_AHEAD = int(os.environ.get("LD_SUB_AHEAD", "2"))
 
 
 class _Pace:
