@@ -483,6 +483,11 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
 template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
 __global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(SK ? 2 : (MT == 2 ? 3 : 1), SK ? 2 : (MT == 2 ? 3 : 2)))) void conv3x3_kernel(Conv3Dev a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // Every scalar argument the setup needs, requested in ONE batch: left to itself hipcc loads the argument block in
+  // four or five dependent batches (s_load ... s_waitcnt lgkmcnt(0), each ~200 cycles) spread over the address arithmetic.
+  asm volatile("" ::"s"(a.H), "s"(a.W), "s"(a.Cout), "s"(a.tiles_x), "s"(a.nsrc), "s"(a.wsplit), "s"(a.s[0].C), "s"(a.s[0].ld),
+               "s"(a.s[0].ups), "s"(a.s[0].data), "s"(a.s[1].C), "s"(a.s[1].ld), "s"(a.s[1].ups), "s"(a.s[1].data), "s"(a.w),
+               "s"(a.bias), "s"(a.out));
   conv3x3_tile<T, MT, NW, DEEP, DBG, SK, RAW>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z, smem);
 }
 
