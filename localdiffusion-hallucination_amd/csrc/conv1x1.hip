@@ -440,7 +440,10 @@ int dispatch(const Conv1Dev& a0, hipStream_t st) {
   bool mt4 = (a.Cout % 64) == 0;
   // small maps: prefer 32-channel tiles while the 64-channel grid (128-pixel tiles) would leave CUs with at most
   // one workgroup -- the K loop is a chain of synchronous chunk loads and a second resident workgroup hides it
-  static const long small_min = getenv("LD_C1_SMALL_MIN") ? atol(getenv("LD_C1_SMALL_MIN")) : 512;
+  // (256 since round 3: at 512 the two 192->128 @64^2 tail launches of a 4-patch sub-batch -- exactly 256 workgroups of
+  //  64-channel tiles -- fell back to 512 workgroups of 32-channel tiles; with 64-channel tiles the step is 0.65 % faster,
+  //  six alternating pairs; 128 and 384 measure like 512)
+  static const long small_min = getenv("LD_C1_SMALL_MIN") ? atol(getenv("LD_C1_SMALL_MIN")) : 256;
   if (mt4 && (long)((HW + 127) / 128) * (a.Cout / 64) * a.B < small_min) mt4 = false;
   const long blocks4 = (long)((HW + 255) / 256) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
   const bool big = blocks4 >= 512;
