@@ -425,8 +425,11 @@ int dispatch(const Conv1Dev& a0, hipStream_t st) {
     const int nch = (a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / ck : 0)) << a.wsplit;
     static const int group_min_ch = getenv("LD_C1_GROUP_MIN_CH") ? atoi(getenv("LD_C1_GROUP_MIN_CH")) : 4;
     a.group = (group_on && (long)HW * a.B <= group_max_px && nch >= group_min_ch) ? KG : 0;
-    // mid-size maps (the 128^2 stage at 4 patches per launch): two or three chunks per tile -- pairs
-    static const long pair_max_px = getenv("LD_C1_PAIR_MAX_PX") ? atol(getenv("LD_C1_PAIR_MAX_PX")) : 65536;
+    // every other launch with at least two chunks: pairs (one round trip per two chunks).  Until round 3 only up to
+    // 65,536 pixels per launch (the 128^2 stage at 4 patches) -- "at 256^2 pairs change nothing" was measured while the
+    // second-operand loads of those launches were still waited for one by one (finding 63); with that gone the 64->32 @256^2
+    // tail launches gain: step 1.4293 -> 1.3978 ms (-2.2 %), cfg5 -2.0 %, 64 patches per GPU and one batch of 8 unchanged.
+    static const long pair_max_px = getenv("LD_C1_PAIR_MAX_PX") ? atol(getenv("LD_C1_PAIR_MAX_PX")) : (1L << 40);
     if (group_on && !a.group && (long)HW * a.B <= pair_max_px && nch >= 2) a.group = 2;
   }
   if (a.epi == LD_EPI_RMS_RES) {
