@@ -7,6 +7,7 @@
 // Pure HBM streaming: 16 B per lane, coefficient tables (2*C floats per operand) built per block
 // from the fp64 statistics.  grid = (pixel blocks, B).
 #include "common.hip.h"
+#include <stdlib.h>
 
 #include "gn_apply_body.hip.h"
 #include "stage.hip.h"
@@ -18,7 +19,8 @@ int run(const GnDev& g, hipStream_t st) {
   const int Ho = g.pool ? g.H / 2 : g.H, Wo = g.pool ? g.W / 2 : g.W;
   const long nfrag = (long)Ho * Wo * (g.a.C / E);
   LD_REQUIRE(nfrag < (1L << 31) / 16, "ld_gn_apply: image too large for 32-bit fragment indices");
-  long blocks = (nfrag + 511) / 512;                     // two fragments per thread and iteration
+  static const long fpb = getenv("LD_GN_FRAGS_PER_BLOCK") ? atol(getenv("LD_GN_FRAGS_PER_BLOCK")) : 512;   // tuning override
+  long blocks = (nfrag + fpb - 1) / fpb;                 // 512: two fragments per thread and iteration
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks, g.B);
