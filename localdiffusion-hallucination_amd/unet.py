@@ -294,6 +294,12 @@ class Unet(nn.Module):
         return p.model_out.clone()
 
 
+# block1's GroupNorm + FiLM + SiLU as a separate pass (instead of block2's prologue) on maps of at most this many pixels
+# with at least this many channels (tuning overrides LD_SEP_ACT_MAX_PX / LD_SEP_ACT_MIN_C; DESIGN finding 5, 68)
+_SEP_ACT_MAX_PX = int(os.environ.get("LD_SEP_ACT_MAX_PX", str(32 * 32)))
+_SEP_ACT_MIN_C = int(os.environ.get("LD_SEP_ACT_MIN_C", "128"))
+
+
 class _Plan:
     """Static buffers + the C-ABI call list of one denoiser evaluation at a fixed shape.
 
@@ -511,7 +517,7 @@ class _Plan:
         film = self.films.get(p)
         n1 = self.src(raw1, cout, gn=(s1, f[p + ".block1.norm.weight"], f[p + ".block1.norm.bias"], G),
                       act=cabi.ACT_SILU, film=film)
-        if h * w <= 32 * 32 and cout >= 128 and not os.environ.get("LD_NO_SEPARATE_ACT"):
+        if h * w <= _SEP_ACT_MAX_PX and cout >= _SEP_ACT_MIN_C and not os.environ.get("LD_NO_SEPARATE_ACT"):
             # small, wide maps: the normalise+FiLM+SiLU prologue would be repeated by every cout-tile workgroup
             # (4x at 256 channels) on the critical path of one-workgroup-per-CU launches; a separate pass over
             # the (L2-resident) tensor measured cheaper (256->256@32^2: 45 -> 25 us + 9 us).  Everything else keeps
@@ -542,7 +548,7 @@ class _Plan:
                           weight=self.P["w"][p + ".block1.proj.weight#x"], bias=zero, addend=p1)
         n1 = self.src(raw1, c, gn=(s1, f[p + ".block1.norm.weight"], f[p + ".block1.norm.bias"], G),
                       act=cabi.ACT_SILU, film=self.films.get(p))
-        if h * w <= 32 * 32 and c >= 128 and not os.environ.get("LD_NO_SEPARATE_ACT"):
+        if h * w <= _SEP_ACT_MAX_PX and c >= _SEP_ACT_MIN_C and not os.environ.get("LD_NO_SEPARATE_ACT"):
             n1 = self.src(self.gn_apply(ops, n1, None, h, w, c), c)
         raw2 = self.conv3(ops, [n1], p + ".block2.proj", c, h, w, stats=s2, groups=G)
         n2 = self.src(raw2, c, gn=(s2, f[p + ".block2.norm.weight"], f[p + ".block2.norm.bias"], G), act=cabi.ACT_SILU)
