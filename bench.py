@@ -243,15 +243,121 @@ def _family_table(acc, plan, nsteps):
     return table, per_op
 
 
+def _price(row, peak_tf):
+    """A family row -> the roofline that bounds it (the larger of its HBM and MFMA fractions) + GB/s, TFLOP/s."""
+    gbs = row["bytes_per_launch"] / max(row["avg_us"], 1e-9) / 1e3
+    tfs = row["flops_per_launch"] / max(row["avg_us"], 1e-9) / 1e6
+    hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / peak_tf
+    if mfma_frac > hbm_frac:        # a kernel is priced against the roofline that bounds it
+        return {"bound": "mfma", "achieved": tfs, "peak": peak_tf, "unit": "TFLOP/s", "frac": mfma_frac}, gbs, tfs
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}, gbs, tfs
+
+
+def _pmc_traffic(name, solo):
+    """HBM bytes per launch of family ``name`` from the newest committed rocprofv3 --pmc passes of the SAME regime
+    (profiles/*_pmc_traffic.json: the default two-sub-batch regime; *_s1_pmc_traffic.json: one batch on one stream).
+    Not live: counters need their own profiler passes (tools/profile_round.sh)."""
+    files = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")
+             and f.endswith("_s1_pmc_traffic.json") == solo]
+    for cand in sorted(files, reverse=True):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", cand))).get(name, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            t = None
+        if t is not None:
+            return t, "profiles/" + cand
+    return None, None
+
+
+def _leg_block(table, per_op, plan, regime, peak_tf, H, solo, conv_sel=None):
+    """One regime's roofline block: the dominant family priced per launch + the table it is recomputed from."""
+    name = next(iter(table))                                 # the family with the most time per step
+    roof, gbs, tfs = _price(table[name], peak_tf)
+    step_ms = sum(r["ms_per_step"] for r in table.values())
+    traffic, src = _pmc_traffic(name, solo)
+    roof.update({"kernel": name, "regime": regime, "launch_batch": int(plan.x_in.shape[0]), "traffic": traffic,
+                 "traffic_source": src, "avg_launch_us": table[name]["avg_us"], "bytes_per_launch": table[name]["bytes_per_launch"],
+                 "flops_per_launch": table[name]["flops_per_launch"], "launches_per_step": table[name]["launches_per_step"],
+                 "algorithmic_GBps": gbs, "algorithmic_TFLOPps": tfs, "share_of_step": table[name]["ms_per_step"] / max(step_ms, 1e-9),
+                 "step_ms_sum_of_kernels": round(step_ms, 4)})
+    if conv_sel is not None:
+        # the north star's "ResBlock conv path": the C=32 3x3 convolutions at full resolution (SURVEY 8a census,
+        # first two lines), priced against the HBM roofline with their algorithmic bytes
+        sel = [(m, us) for _, m, us in per_op if conv_sel(m)]
+        us_total, b_total = sum(us for _, us in sel), sum(m.get("bytes", 0) for m, _ in sel)
+        roof["resblock_conv_path"] = {"launches_per_step": len(sel), "ms_per_step": round(us_total / 1e3, 4), "bytes_per_step": b_total,
+                                      "algorithmic_GBps": b_total / max(us_total, 1e-9) / 1e3,
+                                      "hbm_frac": b_total / max(us_total, 1e-9) / 1e3 / HBM_PEAK_GBS}
+    roof["families"] = table
+    return roof
+
+
+def conv_path_chip_leg(gd, sub, conv_sel, reps=40):
+    """What the CHIP moves for the ResBlock conv path in the timed regime.  ``hbm_frac`` prices ONE sub-batch's
+    launches while the other sub-batch's launches share the chip; here the conv-path launches of BOTH sub-batches
+    (12 each at cfg3, behind the statistics reset they depend on) are captured as one graph per stream and replayed
+    ``reps`` times concurrently, in phase, as the step replays them: (bytes of both sequences) / wall time."""
+    import ctypes as C
+    lib = cabi_mod().lib()
+    graphs, nbytes = [], 0
+    for sp, gs in zip(sub.plans, sub.streams):
+        idx = [i for i in sorted(sp.meta) if conv_sel(sp.meta[i])]
+        nbytes += sum(sp.meta[i].get("bytes", 0) for i in idx)
+        st = gs.cuda_stream
+        with torch.cuda.stream(gs):
+            gs.synchronize()
+            cabi_mod().check(lib.ld_graph_begin(st), "graph_begin")
+            try:
+                cabi_mod().check(lib.ld_step_begin(*sp._begin_args, None, 0, None, None, st), "step_begin")
+                for i in idx:
+                    sp.ops_main[i](st)
+            finally:
+                g = C.c_void_p()
+                rc = lib.ld_graph_end(st, C.byref(g))
+            cabi_mod().check(rc, "graph_end")
+            graphs.append(g)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cur = torch.cuda.current_stream()
+    best = None
+    for _ in range(3):
+        for gs in sub.streams:
+            gs.wait_stream(cur)
+        ev0.record(sub.streams[0])
+        for gs in sub.streams[1:]:
+            gs.wait_event(ev0)
+        for _r in range(reps):
+            for g, gs in zip(graphs, sub.streams):
+                cabi_mod().check(lib.ld_graph_launch(g, gs.cuda_stream), "graph_launch")
+        for gs in sub.streams[1:]:
+            sub.streams[0].wait_stream(gs)
+        ev1.record(sub.streams[0])
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / reps
+        best = ms if best is None else min(best, ms)
+    for g in graphs:
+        lib.ld_graph_destroy(g)
+    return {"chip_hbm_frac": nbytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "chip_ms_per_step": round(best, 4), "chip_bytes_per_step": nbytes,
+            "chip_method": f"the conv-path launches of all {len(graphs)} sub-batches (+ their statistics reset) as one graph per stream, "
+                           f"replayed {reps}x concurrently and in phase (best of 3): bytes of all sequences / wall"}
+
+
+def cabi_mod():
+    from localdiffusion_hallucination_amd import _cabi
+    return _cabi
+
+
 def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5):
     """Per-launch timing (hipExtLaunchKernelGGL start/stop events on the launch stream = rocprofv3's kernel
-    durations) of a few reverse steps, in two regimes:
-      solo    -- the whole local batch as ONE batch on one stream: every launch has the chip to itself.  This is what
-                 `frac` prices (a roofline fraction is a statement about one kernel and the whole machine), and what
-                 `rocprofv3 --kernel-trace --stats` of `LD_SUB_BATCHES=1 python bench.py` reproduces
-                 (profiles/*_s1_kernel_stats.csv);
-      in_situ -- the regime of the timed region: the batch as concurrent sub-batches on two streams; sub-batch 0 is
-                 timed while the other one's kernels share the chip (launches are slower, the step is faster)."""
+    durations) of a few reverse steps.  The block describes the regime the TIMED region runs in:
+      timed -- the batch as concurrent sub-batches on two streams (replayed step graphs); sub-batch 0 is stepped
+               eagerly with events around every launch while the other sub-batch's graphs share the chip.  `frac`,
+               `kernel`, `avg_launch_us`, `families` are this regime's; `traffic` comes from the committed --pmc passes
+               of the same regime; `rocprofv3 --kernel-trace --stats -- python bench.py` reproduces the durations
+               (profiles/*_kernel_stats.csv; the profiler's interception makes the streams overlap somewhat less);
+      solo  -- (under `roofline.solo`) the whole local batch as ONE batch on one stream, every launch alone on the chip:
+               what `LD_SUB_BATCHES=1 rocprofv3 --kernel-trace --stats` reproduces (profiles/*_s1_kernel_stats.csv).
+    When the batch is not split (one sub-batch), the timed regime IS the solo regime and there is no `solo` block."""
     torch.cuda.synchronize()
     jp.run_cond(torch.cuda.current_stream().cuda_stream)      # the solo leg evaluates the parent plan itself
     peak_tf = MFMA_PEAK_TF[dtype]
@@ -270,7 +376,6 @@ def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5):
         torch.cuda.synchronize()
         table, per_op = _family_table(acc, plan, nsteps)
         legs[leg] = (table, per_op, plan)
-    table, per_op, plan = legs["solo"]
     if os.environ.get("LD_BENCH_OPS"):
         with open(os.environ["LD_BENCH_OPS"], "w") as f:
             for leg, (_, ops, _) in legs.items():
@@ -280,63 +385,29 @@ def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5):
                             f"{us:9.1f} us  {m.get('bytes', 0) / max(us, 1e-9) / 1e3:8.1f} GB/s  "
                             f"{m.get('flops', 0) / max(us, 1e-9) / 1e6:8.1f} TF/s\n")
 
-    def price(row):
-        gbs = row["bytes_per_launch"] / max(row["avg_us"], 1e-9) / 1e3
-        tfs = row["flops_per_launch"] / max(row["avg_us"], 1e-9) / 1e6
-        hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / peak_tf
-        if mfma_frac > hbm_frac:        # a kernel is priced against the roofline that bounds it
-            return {"bound": "mfma", "achieved": tfs, "peak": peak_tf, "unit": "TFLOP/s", "frac": mfma_frac}, gbs, tfs
-        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}, gbs, tfs
+    def conv_sel(m):
+        return m.get("family", "").startswith("conv3x3") and m.get("shape", "").endswith(f"@{H}x{H}")
 
-    def conv_path(ops):
-        # the north star's "ResBlock conv path": the C=32 3x3 convolutions at full resolution (SURVEY 8a census,
-        # first two lines), priced against the HBM roofline with their algorithmic bytes
-        sel = [(m, us) for _, m, us in ops if m.get("family", "").startswith("conv3x3") and m.get("shape", "").endswith(f"@{H}x{H}")]
-        us_total, b_total = sum(us for _, us in sel), sum(m.get("bytes", 0) for m, _ in sel)
-        return {"launches_per_step": len(sel), "ms_per_step": round(us_total / 1e3, 4), "bytes_per_step": b_total,
-                "algorithmic_GBps": b_total / max(us_total, 1e-9) / 1e3,
-                "hbm_frac": b_total / max(us_total, 1e-9) / 1e3 / HBM_PEAK_GBS}
-
-    name = next(iter(table))                                 # the family with the most time per step
-    roof, gbs, tfs = price(table[name])
-    step_ms = sum(r["ms_per_step"] for r in table.values())
-    traffic, traffic_src = None, None
-    for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_s1_pmc_traffic.json")), reverse=True):
-        try:                                                 # committed rocprofv3 --pmc passes of the solo regime, not live
-            traffic = json.load(open(os.path.join(ROOT, "profiles", cand))).get(name, {}).get("hbm_bytes_per_launch")
-            traffic_src = "profiles/" + cand
-        except Exception:
-            traffic = None
-        if traffic is not None:
-            break
-    roof.update({"kernel": name, "regime": "solo: one batch of %d on one stream" % int(jp.x_in.shape[0]),
-                 "launch_batch": int(jp.x_in.shape[0]), "traffic": traffic, "traffic_source": traffic_src,
-                 "avg_launch_us": table[name]["avg_us"], "bytes_per_launch": table[name]["bytes_per_launch"],
-                 "flops_per_launch": table[name]["flops_per_launch"], "launches_per_step": table[name]["launches_per_step"],
-                 "algorithmic_GBps": gbs, "algorithmic_TFLOPps": tfs, "share_of_step": table[name]["ms_per_step"] / max(step_ms, 1e-9),
-                 "step_ms_sum_of_kernels": round(step_ms, 4),
-                 # whole path: 0.7036 TB of algorithmic traffic per 256^2 patch over T=1000 -- still divided
-                 # by the figure that INCLUDES the conditioning encoder (34 MB per forward), which the product evaluates
-                 # once per sample instead of once per step
-                 "path_frac": tp_value * ALGO_TB_PER_PATCH * 1e3 / HBM_PEAK_GBS,
-                 "resblock_conv_path": conv_path(per_op), "families": table})
-    roof["timed_regime_kernel"], roof["timed_regime_frac"], roof["timed_regime_bound"] = name, roof["frac"], roof["bound"]
+    B_ = int(jp.x_in.shape[0])
+    t1, ops1, plan1 = legs["solo"]
+    solo = _leg_block(t1, ops1, plan1, f"solo: one batch of {B_} on one stream, every launch alone on the chip", peak_tf, H, True, conv_sel)
     if "in_situ" in legs:
         t2, ops2, plan2 = legs["in_situ"]
-        r2, g2, f2 = price(t2[name]) if name in t2 else ({"frac": None}, 0, 0)
-        # the family that dominates the regime the timed region actually runs in, priced per launch while the other
-        # sub-batch's kernels share the chip (each launch carries launch_batch patches)
-        dom2 = next(iter(t2))
-        rd, _, _ = price(t2[dom2])
-        roof["timed_regime_kernel"] = dom2
-        roof["timed_regime_frac"] = rd["frac"]
-        roof["timed_regime_bound"] = rd["bound"]
-        roof["in_situ"] = {"regime": "%d concurrent sub-batches of %d, sub-batch 0 timed" % (gd.sub_batches, int(plan2.x_in.shape[0])),
-                           "launch_batch": int(plan2.x_in.shape[0]), "frac": r2["frac"],
-                           "avg_launch_us": t2.get(name, {}).get("avg_us"), "resblock_conv_path": conv_path(ops2),
-                           "step_ms_sum_of_kernels": round(sum(r["ms_per_step"] for r in t2.values()), 4), "families": t2}
+        b2 = int(plan2.x_in.shape[0])
+        roof = _leg_block(t2, ops2, plan2, f"timed: {gd.sub_batches} concurrent sub-batches of {b2} (replayed step graphs); "
+                          f"sub-batch 0's launches timed while the other sub-batch shares the chip", peak_tf, H, False, conv_sel)
+        roof["concurrent_streams"] = gd.sub_batches
+        sub = gd._subs.get((id(jp), gd.sub_batches))
+        if sub is not None:
+            roof["resblock_conv_path"].update(conv_path_chip_leg(gd, sub, conv_sel))
+        roof["solo"] = solo
+    else:
+        roof = solo
+        roof["regime"] = f"timed = solo: one batch of {B_} on one stream"
+    # whole path: 0.7036 TB of algorithmic traffic per 256^2 patch over T=1000 -- still divided by the
+    # figure that INCLUDES the conditioning encoder (34 MB per forward), which the product evaluates once per sample
+    roof["path_frac"] = tp_value * ALGO_TB_PER_PATCH * 1e3 / HBM_PEAK_GBS
     return roof
-
 
 
 def bench_cfg5(a, rank, world, dev, dist):
@@ -382,6 +453,29 @@ def bench_cfg5(a, rank, world, dev, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(out_img).all() and float(out_img.min()) >= 0.0 and float(out_img.max()) <= 2.0
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        # per-launch table of the branch phase (47 of the 50 pairs): branch 0 timed launch by launch while branch 1's
+        # replayed graph shares the chip (the timed regime), and alone on the chip (`solo`)
+        from localdiffusion_hallucination_amd.diffusion import _DdimBranches
+        db = next((v for v in gd._subs.values() if isinstance(v, _DdimBranches)), None)
+        if db is not None:
+            peak_tf, blocks = MFMA_PEAK_TF[dtype], {}
+            for leg, alone in (("timed", False), ("solo", True)):
+                acc = {}
+                db.run_timed(5, acc, 0.0, 2.0, alone=alone)
+                table, per_op = _family_table(acc, db.plans[0], 5)
+                regime = ("timed: the OOD and the IND branch of one 1x512x512 image as two concurrent sub-batches (replayed step graphs); "
+                          "branch 0's launches timed while branch 1 shares the chip") if not alone else \
+                         "solo: one branch of one image on one stream, every launch alone on the chip"
+                blocks[leg] = _leg_block(table, per_op, db.plans[0], regime, peak_tf, H, alone)
+                if os.environ.get("LD_BENCH_OPS"):
+                    with open(os.environ["LD_BENCH_OPS"], "a" if leg == "solo" else "w") as f:
+                        f.write(f"# {leg}\n")
+                        for i, m, us in per_op:
+                            f.write(f"{i:4d} {m.get('family', '?'):22s} {m.get('what', '?'):38s} {m.get('shape', ''):20s} {us:9.1f} us\n")
+            roof = blocks["timed"]
+            roof["solo"] = blocks["solo"]
     if rank == 0:
         print(json.dumps({
             "metric": "images/sec (cfg5: 512^2, DDIM 50 of 1000, branch + fusion)", "value": world * samples / elapsed, "unit": "images/s",
@@ -391,7 +485,8 @@ def bench_cfg5(a, rank, world, dev, dist):
             "config": {"workload": "cfg5: one 1x512x512 image per GPU, 4-stage dim-32 conditional UNet, T=1000 / DDIM S=50 (eta 0), "
                                    "OOD + IND branches (circular mask r=64), fusion at times[-4], full attention over 4096 tokens",
                        "images_per_gpu": 1, "sampling_timesteps": S, "parallelism": f"image-sharded x{world}, one all-gather per sample",
-                       "denoiser_evaluations_per_image": 2 * (S - 3) + 3}}))
+                       "denoiser_evaluations_per_image": 2 * (S - 3) + 3},
+            **({"roofline": roof} if roof is not None else {})}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

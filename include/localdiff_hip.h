@@ -80,22 +80,6 @@ int ld_event_destroy(void* ev);
 /* make `stream` wait for `ev` (fork/join of independent branches on two streams, e.g. a ResnetBlock's
  * res_conv beside its 3x3 convs; also captured as graph edges) */
 int ld_stream_wait_event(void* stream, void* ev);
-/* ---- stage programs: a run of consecutive launches executed by ONE persistent launch (csrc/stage.hip) ------------
- * Between ld_stage_begin() and ld_stage_end() the calls this host thread makes to ld_conv3x3 and ld_gn_apply are
- * validated and dispatched as usual but RECORDED instead of launched (16-bit storage; a call whose kernel variant has
- * no tile function in the stage kernel makes ld_stage_end fail with LD_EINVAL and the caller keeps its ordinary
- * launches).  ld_stage_launch runs the recorded phases for every image of the batch (1..8) in one persistent kernel:
- * one image per XCD (a workgroup's group is the XCD it reads from HW_REG_XCC_ID, images are claimed at run time,
- * preferring XCD (xcd_base + image) mod 8), tiles handed out by per-(XCD, phase) counters, XCD-local phase boundaries
- * (s_waitcnt vmcnt(0) -> counter -> sc1 poll -> buffer_inv sc1).  `ctl_zeroed`: ld_stage_ctl_bytes() bytes of device
- * memory that are ZERO when the launch starts (every launch needs them zeroed again).  The results are those of the
- * stand-alone launches (same tile functions, same arithmetic order).  Replaces launch boundaries inside
- * Unet.forward (ddpm.py:420-446); the reference has no counterpart. */
-int ld_stage_begin(void);
-int ld_stage_end(void** program_out /* host */, int* nphase_out /* host */);
-size_t ld_stage_ctl_bytes(void);
-int ld_stage_launch(void* program, void* ctl_zeroed, int xcd_base, int workgroups, int dtype, void* stream);
-int ld_stage_destroy(void* program);
 /* Profiler-visible phase markers: nested roctx ranges (host side) around the phases of a sample -- "encoder",
  * "step", "exchange" -- so that a rocprofv3 --marker-trace of sample() is readable.  The reference's only hook is the
  * wall-clock timer around sample() (test.py:392-415).  No-ops when no roctx library can be loaded (LD_NO_ROCTX=1:

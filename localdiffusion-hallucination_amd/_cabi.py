@@ -60,11 +60,6 @@ _SIGS = {
     "ld_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "ld_event_destroy": (C.c_int, [vp]),
     "ld_stream_wait_event": (C.c_int, [vp, vp]),
-    "ld_stage_begin": (C.c_int, []),
-    "ld_stage_end": (C.c_int, [C.POINTER(vp), C.POINTER(C.c_int)]),
-    "ld_stage_ctl_bytes": (C.c_size_t, []),
-    "ld_stage_launch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
-    "ld_stage_destroy": (C.c_int, [vp]),
     "ld_counter": (C.c_longlong, [C.c_int]),
     "ld_range_push": (C.c_int, [C.c_char_p]),
     "ld_range_pop": (C.c_int, []),

@@ -230,13 +230,15 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
   }
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
-  if (qi < n) {
+  {
+    // the head's two 16-channel halves leave as ONE 16-byte store per lane (pair_frag16: the exchange runs on every
+    // lane, only the store is predicated)
     const float inv = 1.0f / l;
-    T* op = out + ((size_t)b * n + qi) * hidden + h * D + kg * 4;
+    char* op = reinterpret_cast<char*>(out + ((size_t)b * n + (qi < n ? qi : 0)) * hidden + h * D);
     float r0[4] = {o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv};
     float r1[4] = {o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
-    store4<T>(op, r0);
-    store4<T>(op + 16, r1);
+    const uint4 w16 = pair_frag16<T>(r0, r1);
+    if (qi < n) *reinterpret_cast<uint4*>(op + pair_frag16_off(kg)) = w16;
   }
 }
 }  // namespace

@@ -55,6 +55,7 @@ bool ld_timing_next(hipEvent_t* start, hipEvent_t* stop);
 hipError_t ld_allow_lds_ptr(const void* kernel, size_t bytes);
 template <typename K>
 static inline hipError_t ld_allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 65536) return hipSuccess;           // within the default dynamic-LDS limit: no attribute, no lookup
   return ld_allow_lds_ptr(reinterpret_cast<const void*>(kernel), bytes);
 }
 
@@ -155,6 +156,32 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* v
 template <> __device__ __forceinline__ void store4<f16>(f16* p, const float* v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]));
 }
+// ---------------------------------------------------------------- wide epilogue stores (16-bit storage)
+// An accumulator fragment is 4 consecutive channels of one pixel = 8 bytes in 16-bit storage, and the 4 kq lanes of a
+// pixel sit 16 lanes apart: per m-tile a wave instruction stores 64 x 8 B in 32-byte runs.  For two ADJACENT m-tiles
+// (32 consecutive channels = 64 B per pixel) one v_permlane16_swap per dword regroups the fragments so that every
+// lane holds 8 consecutive channels: ONE 16-byte store instead of two 8-byte ones -- half the store instructions for
+// the same bytes, and with 32 output channels a wave instruction writes 1 KiB contiguous (cdna_hip_programming.md
+// T21 in its 16-lane-row form; the store tails were issue-bound: 10 of the 22.5 us of a 32->32 @256^2 launch).
+//   swap(vdst = p0, src = p1) exchanges rows 1 / 3 of p0 with rows 0 / 2 of p1 (row = 16 lanes = one kq):
+//   kq 0: (own p0 [ch 0-3 of m],        p0 of kq 1 [ch 4-7 of m])        -> m-tile m,     bytes  0..15
+//   kq 1: (p1 of kq 0 [ch 0-3 of m+1],  own p1 [ch 4-7 of m+1])          -> m-tile m + 1, bytes  0..15
+//   kq 2: (own p0 [ch 8-11 of m],       p0 of kq 3 [ch 12-15 of m])      -> m-tile m,     bytes 16..31
+//   kq 3: (p1 of kq 2 [ch 8-11 of m+1], own p1 [ch 12-15 of m+1])        -> m-tile m + 1, bytes 16..31
+// Every lane of the wave must execute the exchange (callers predicate only the store; the lanes of one pixel share
+// their predicate).  The values and their roundings are those of two store4 calls: results are bit-identical.
+template <typename T>
+__device__ __forceinline__ uint4 pair_frag16(const float* v0, const float* v1) {
+  static_assert(sizeof(T) == 2, "pair_frag16: 16-bit storage only (an fp32 fragment is 16 bytes already)");
+  const unsigned a0 = pack2<T>(v0[0], v0[1]), a1 = pack2<T>(v0[2], v0[3]);
+  const unsigned b0 = pack2<T>(v1[0], v1[1]), b1 = pack2<T>(v1[2], v1[3]);
+  const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+  return make_uint4(r0[0], r1[0], r0[1], r1[1]);
+}
+// byte offset of the lane's 16-byte piece from channel 0 of m-tile m of its pixel
+__device__ __forceinline__ unsigned pair_frag16_off(int kq) { return (kq & 1) * 32u + (kq >> 1) * 16u; }
+
 template <typename T> __device__ __forceinline__ void load4(const T* p, float* v);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float* v) {
   float4 r = *reinterpret_cast<const float4*>(p);

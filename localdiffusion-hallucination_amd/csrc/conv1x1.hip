@@ -323,31 +323,42 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) cmax[m][r] = fmaxf(cmax[m][r], v[m][r]);
     }
-    if (valid) {
+    // (the second operands come from clamped, always-valid addresses: evaluated for every lane so that the 16-byte
+    //  pairing below runs with the whole wave active; only the store is predicated)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int co = (m0 + m) * 16 + kq * 4;
-        const size_t o = ((size_t)b * HW + p) * a.Cout + co;
-        if constexpr (EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES) {
-          float o2[4];
-          unpack4<T>(op2[m][j], o2);
+    for (int m = 0; m < MT; ++m) {
+      const int co = (m0 + m) * 16 + kq * 4;
+      if constexpr (EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES) {
+        float o2[4];
+        unpack4<T>(op2[m][j], o2);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[m][r] += o2[r];
-        } else if constexpr (TAIL) {
-          float rv[4];
-          unpack4<T>(op2[m][j], rv);
-          affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
+        for (int r = 0; r < 4; ++r) v[m][r] += o2[r];
+      } else if constexpr (TAIL) {
+        float rv[4];
+        unpack4<T>(op2[m][j], rv);
+        affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
-          if constexpr (HAS_OP3) {                       // step-invariant half of res_conv (conv_fusion)
-            float o3[4];
-            unpack4<T>(op3[m][j], o3);
+        for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
+        if constexpr (HAS_OP3) {                       // step-invariant half of res_conv (conv_fusion)
+          float o3[4];
+          unpack4<T>(op3[m][j], o3);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[m][r] += o3[r];
-          }
+          for (int r = 0; r < 4; ++r) v[m][r] += o3[r];
         }
-        store4<T>(out + o, v[m]);
       }
+    }
+    T* opix = out + ((size_t)b * HW + (valid ? p : 0)) * a.Cout + m0 * 16;
+    if constexpr (sizeof(T) == 2) {
+      // the fragments of two adjacent m-tiles leave as ONE 16-byte store per lane (pair_frag16, common.hip.h)
+      static_assert(MT % 2 == 0, "m-tiles are stored in pairs");
+#pragma unroll
+      for (int m = 0; m < MT; m += 2) {
+        const uint4 w16 = pair_frag16<T>(v[m], v[m + 1]);
+        if (valid) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(opix + m * 16) + pair_frag16_off(kq)) = w16;
+      }
+    } else if (valid) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) store4<T>(opix + m * 16 + kq * 4, v[m]);
     }
   }
   if (k_part) {

@@ -29,7 +29,6 @@ int ld_conv3x3_ring_try(const ld_conv3x3_args* p, hipStream_t st);     // tools/
 #endif
 
 #include "conv3x3_body.hip.h"
-#include "stage.hip.h"
 
 namespace {
 
@@ -47,13 +46,6 @@ int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   d.tiles_x = (a.W + 15) / 16;
   const int tiles_y = (a.H + TR - 1) / TR;
   dim3 grid(d.tiles_x * tiles_y, a.Cout / (16 * MT), a.B);
-  if (ld_stage_recording()) {                          // stage program (stage.hip): record the variant instead of launching it
-    static_assert(sizeof(Conv3Dev) <= LD_STAGE_ARG_BYTES, "stage argument block too small");
-    if constexpr (sizeof(T) == 2 && MT == 2 && NW == 2 && !DEEP && DBG == 0 && !SK)   // (the 64-channel tiles would take the stage kernel to 256 registers)
-      return ld_stage_record(LD_STAGE_CONV3, RAW ? 1 : 0, &d, sizeof(d), grid.x, grid.y, grid.z, lds);
-    else
-      return ld_stage_unsupported("this conv3x3 variant");
-  }
   if (lds > 65536) LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>, lds));   // cached per device
   LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>), grid, dim3(SK ? 512 : 256), lds, st, d);
   LD_LAUNCH_CHECK("conv3x3");
@@ -206,17 +198,17 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   }
 #endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!ld_stage_recording() && p->weight_terms != 2) {   // (the persistent kernel keeps ONE chunk of weights in registers)
+  if (p->weight_terms != 2) {   // (the persistent kernel keeps ONE chunk of weights in registers)
     const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }
 #ifdef LD_DEBUG_VARIANTS
-  if (!ld_stage_recording()) {               // experiment: both operands by LDS-DMA, one barrier per chunk
+  {                                          // experiment: both operands by LDS-DMA, one barrier per chunk
     const int rc = ld_conv3x3_ring_try(p, st);
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }
   static const int ksplit = getenv("LD_CONV_KSPLIT") ? atoi(getenv("LD_CONV_KSPLIT")) : 0;
-  if (ksplit && !ld_stage_recording() && p->weight_terms != 2) {                                       // shelved experiment: weights in registers, K split over waves
+  if (ksplit && p->weight_terms != 2) {                                       // shelved experiment: weights in registers, K split over waves
     const int rc = ld_conv3x3_ksplit_try(p, st);
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }

@@ -1,5 +1,5 @@
 // Device side of the 3x3 convolution (conv3x3.hip has the description, the launch heuristics and the C entry point):
-// the argument block, the tile function and its __global__ wrapper.  Included by conv3x3.hip and by stage.hip.
+// the argument block, the tile function and its __global__ wrapper.  Included by conv3x3.hip (and by the archived stage-program experiment, tools/experiments/stage_programs.hip).
 #pragma once
 #include "common.hip.h"
 
@@ -40,7 +40,7 @@ __device__ unsigned long long g_conv_span[1024][2];
 // the general kernel tests `stats != nullptr` and the activation kind per fragment at run time; with one wave per SIMD
 // those scalar tests, branches and register copies sit on the chunk loop's critical path (DESIGN finding 42).
 // The kernel body as a device function of the (virtual) workgroup index: conv3x3_kernel calls it with its own index,
-// the persistent stage kernel (stage.hip) with the tiles it takes from its work counter.
+// the archived stage-program experiment (tools/experiments/stage_programs.hip) with the tiles it takes from its work counter.
 template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
 __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, const int by, const int bz, const int gdx, const int gdz,
                                              char* smem) {
@@ -367,27 +367,43 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
           for (int j = 0; j < NW; ++j) pin_raw4(ad[m][j]);
       }
     }
+    // 16-bit storage: the fragments of two adjacent m-tiles leave as ONE 16-byte store per lane (pair_frag16)
+    constexpr int MS = sizeof(T) == 2 ? 2 : 1;
+    static_assert(MT % 2 == 0, "m-tiles are stored in pairs");
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const float4 bv = bias[m];
+    for (int m = 0; m < MT; m += MS) {
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
         const int gy = ty0 + wv * NW + j;
         const bool valid = FULL || ((rows_in || (gy < H && gx < W)) && half == 0);   // (SK: half 0 holds the joined sums)
-        const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
-        float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
-        if constexpr (!FULL) {
-          if (a.addend) {
-            float av[4];
-            unpack4<T>(ad[m][j], av);
+        float v[MS][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += av[r];
+        for (int mm = 0; mm < MS; ++mm) {
+          const float4 bv = bias[m + mm];
+          v[mm][0] = acc[m + mm][j][0] + bv.x; v[mm][1] = acc[m + mm][j][1] + bv.y;
+          v[mm][2] = acc[m + mm][j][2] + bv.z; v[mm][3] = acc[m + mm][j][3] + bv.w;
+          if constexpr (!FULL) {
+            if (a.addend) {
+              float av[4];
+              unpack4<T>(ad[m + mm][j], av);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[mm][r] += av[r];
+            }
           }
         }
+        if constexpr (MS == 2) {
+          const uint4 w16 = pair_frag16<T>(v[0], v[1]);      // all lanes: the exchange is unconditional
+          const unsigned off = lane_off - kq * 4 * (unsigned)sizeof(T) + j * row_off + m * 16 * (unsigned)sizeof(T) + pair_frag16_off(kq);
+          if (valid && !(DBG & 8)) *reinterpret_cast<uint4*>(outb + off) = w16;
+        } else {
+          const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
+          if (valid && !(DBG & 8)) store4<T>(reinterpret_cast<T*>(outb + off), v[0]);
+        }
         if (valid) {
-          if (!(DBG & 8)) store4<T>(reinterpret_cast<T*>(outb + off), v);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
+          for (int mm = 0; mm < MS; ++mm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ssum[m + mm][r] += v[mm][r]; ssq[m + mm][r] += v[mm][r] * v[mm][r]; }
         }
       }
     }

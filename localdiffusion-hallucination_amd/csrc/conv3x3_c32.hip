@@ -71,7 +71,9 @@ __global__ __launch_bounds__(64 * NWAVE) void conv3x3_c32_kernel(C32Dev a) {
   constexpr int NPIX = HR * HC, NBLK = (NPIX + 15) / 16, BPW = (NBLK + NWAVE - 1) / NWAVE;   // 324 px, 21 blocks, 3
   constexpr int XBUF = NBLK * 1024;                                                         // bytes per ring slot
   constexpr int WCH = 9 * MT * 1024;                                                        // bytes per weight chunk
-  constexpr int NST = MT * NW;                                                              // store instructions per wave per tile
+  constexpr int MS = sizeof(T) == 2 ? 2 : 1;                                                // m-tiles per store (pair_frag16: 16-byte stores)
+  static_assert(MT % MS == 0, "m-tiles are stored in pairs");
+  constexpr int NST = MT / MS * NW;                                                         // store instructions per wave per tile
   constexpr bool P = DT<T>::precise;
 
   // Single-chunk launches (32 -> 32) keep the wave's 18 weight fragments in REGISTERS for the whole launch: every wave
@@ -306,16 +308,26 @@ __global__ __launch_bounds__(64 * NWAVE) void conv3x3_c32_kernel(C32Dev a) {
       if (cur.ch == NCH - 1 && !(DBG & 8)) {
         const int gx = cur.tx0 + px;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int co = m * 16 + kq * 4;
-          const float4 bv = bias[m];
+        for (int m = 0; m < MT; m += MS) {
 #pragma unroll
           for (int j = 0; j < NW; ++j) {
             const int gy = cur.ty0 + wv * NW + j;
-            float v[4] = {acc[m][j][0] + bv.x, acc[m][j][1] + bv.y, acc[m][j][2] + bv.z, acc[m][j][3] + bv.w};
-            store4<T>(out + (size_t)(((b * H + gy) * W + gx) * 32 + co), v);
+            float v[MS][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { ssum[m][r] += v[r]; ssq[m][r] += v[r] * v[r]; }
+            for (int mm = 0; mm < MS; ++mm) {
+              const float4 bv = bias[m + mm];
+              v[mm][0] = acc[m + mm][j][0] + bv.x; v[mm][1] = acc[m + mm][j][1] + bv.y;
+              v[mm][2] = acc[m + mm][j][2] + bv.z; v[mm][3] = acc[m + mm][j][3] + bv.w;
+            }
+            T* pix = out + (size_t)(((b * H + gy) * W + gx) * 32 + m * 16);
+            if constexpr (MS == 2)      // ONE 16-byte store per lane for the pair of m-tiles: a wave writes 1 KiB contiguous
+              *reinterpret_cast<uint4*>(reinterpret_cast<char*>(pix) + pair_frag16_off(kq)) = pair_frag16<T>(v[0], v[1]);
+            else
+              store4<T>(pix + kq * 4, v[0]);
+#pragma unroll
+            for (int mm = 0; mm < MS; ++mm)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { ssum[m + mm][r] += v[mm][r]; ssq[m + mm][r] += v[mm][r] * v[mm][r]; }
           }
         }
       }

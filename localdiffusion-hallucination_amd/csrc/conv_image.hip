@@ -204,13 +204,17 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(const float* __rest
         }
       }
       const int gy = y0 + row;
-      if (gy < H && gx < W) {
-        T* op = out + (((size_t)b * H + gy) * W + gx) * CO;
+      {
+        // the two m-tiles leave as ONE 16-byte store per lane (pair_frag16; only the store is predicated)
+        const bool in = gy < H && gx < W;
+        char* op = reinterpret_cast<char*>(out + (((size_t)b * H + (in ? gy : 0)) * W + (in ? gx : 0)) * CO);
+        float r4[2][4];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          float r4[4] = {acc[m][0] + bv[m].x, acc[m][1] + bv[m].y, acc[m][2] + bv[m].z, acc[m][3] + bv[m].w};
-          store4<T>(op + m * 16 + kq * 4, r4);
+          r4[m][0] = acc[m][0] + bv[m].x; r4[m][1] = acc[m][1] + bv[m].y; r4[m][2] = acc[m][2] + bv[m].z; r4[m][3] = acc[m][3] + bv[m].w;
         }
+        const uint4 w16 = pair_frag16<T>(r4[0], r4[1]);
+        if (in) *reinterpret_cast<uint4*>(op + pair_frag16_off(kq)) = w16;
       }
     }
   }

@@ -10,7 +10,6 @@
 #include <stdlib.h>
 
 #include "gn_apply_body.hip.h"
-#include "stage.hip.h"
 
 namespace {
 template <typename T>
@@ -25,11 +24,6 @@ int run(const GnDev& g, hipStream_t st) {
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks, g.B);
   const size_t lds = 4 * g.a.C * sizeof(float) + 64 * sizeof(double);
-  if (ld_stage_recording()) {                          // stage program (stage.hip): record instead of launching
-    static_assert(sizeof(GnDev) <= LD_STAGE_ARG_BYTES, "stage argument block too small");
-    if (sizeof(T) != 2 || g.pool) return ld_stage_unsupported("this gn_apply variant");
-    return ld_stage_record(LD_STAGE_GN, g.has_b ? 1 : 0, &g, sizeof(g), grid.x, 1, grid.y, lds);
-  }
   if (g.has_b) {
     if (g.pool) LD_LAUNCH((gn_apply_kernel<T, true, true>), grid, dim3(256), lds, st, g);
     else LD_LAUNCH((gn_apply_kernel<T, true, false>), grid, dim3(256), lds, st, g);

@@ -1,4 +1,4 @@
-// Device side of gn_apply (gn_apply.hip has the description and the C entry point).  Included by gn_apply.hip and stage.hip.
+// Device side of gn_apply (gn_apply.hip has the description and the C entry point).  Included by gn_apply.hip (and by the archived tools/experiments/stage_programs.hip).
 #pragma once
 #include "common.hip.h"
 
@@ -45,7 +45,7 @@ __device__ __forceinline__ void eval_pixel(const GnDev& g, const float* ca, cons
   finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, ra, rb, v);
 }
 
-// The kernel body as a device function of the (virtual) workgroup index (gn_apply_kernel: its own index; stage.hip: the
+// The kernel body as a device function of the (virtual) workgroup index (gn_apply_kernel: its own index; tools/experiments/stage_programs.hip: the
 // blocks a persistent workgroup takes from its work counter).  bx / gdx: block and number of blocks of image `b`.
 template <typename T, bool HAS_B, bool POOL>
 __device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, const int gdx, const int b, float* s_coef) {

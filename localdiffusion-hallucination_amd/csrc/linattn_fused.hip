@@ -543,17 +543,26 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
     ss += __shfl_xor(ss, 16);
     ss += __shfl_xor(ss, 32);
     const float inv = rms_rinv<false>(ss);
-    if (valid) {
+    {
+      // two adjacent m-tiles leave as ONE 16-byte store per lane (pair_frag16: the exchange runs on every lane, only
+      // the store is predicated; the residual comes from LDS, which holds zeros for pixels past the image)
+      static_assert(MT2 % 2 == 0, "m-tiles are stored in pairs");
+      char* opix = reinterpret_cast<char*>(reinterpret_cast<T*>(a.out) + ((size_t)b * n + (valid ? p : 0)) * C);
 #pragma unroll
-      for (int m2 = 0; m2 < MT2; ++m2) {
-        const int co = m2 * 16 + kq * 4;
-        const float4 gv = gvr[m2];
-        // the residual x is already in the staging tile: channels co..co+3 = chunk m2/2, fragment 2*(m2&1) + kq/2
-        float xr[4];
-        load4<T>(reinterpret_cast<const T*>(s_x + ((m2 >> 1) * 4 + (m2 & 1) * 2 + (kq >> 1)) * PLANE + qq * 16 + (kq & 1) * 8), xr);
-        float r4[4] = {y[m2][0] * inv * gv.x + xr[0], y[m2][1] * inv * gv.y + xr[1],
-                       y[m2][2] * inv * gv.z + xr[2], y[m2][3] * inv * gv.w + xr[3]};
-        store4<T>(reinterpret_cast<T*>(a.out) + ((size_t)b * n + p) * C + co, r4);
+      for (int m2 = 0; m2 < MT2; m2 += 2) {
+        float r4[2][4];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          const int mq = m2 + mm;
+          const float4 gv = gvr[mq];
+          // the residual x is already in the staging tile: channels co..co+3 = chunk mq/2, fragment 2*(mq&1) + kq/2
+          float xr[4];
+          load4<T>(reinterpret_cast<const T*>(s_x + ((mq >> 1) * 4 + (mq & 1) * 2 + (kq >> 1)) * PLANE + qq * 16 + (kq & 1) * 8), xr);
+          r4[mm][0] = y[mq][0] * inv * gv.x + xr[0]; r4[mm][1] = y[mq][1] * inv * gv.y + xr[1];
+          r4[mm][2] = y[mq][2] * inv * gv.z + xr[2]; r4[mm][3] = y[mq][3] * inv * gv.w + xr[3];
+        }
+        const uint4 w16 = pair_frag16<T>(r4[0], r4[1]);
+        if (valid) *reinterpret_cast<uint4*>(opix + m2 * 16 * sizeof(T) + pair_frag16_off(kq)) = w16;
       }
     }
   }

@@ -141,8 +141,9 @@ extern "C" int ld_stream_wait_event(void* stream, void* ev) {
 
 // ---- profiler-visible phase markers (roctx ranges) -----------------------------------------------------------
 // The reference's only hook is a wall-clock timer around sample() (test.py:392-415).  These ranges show up in
-// `rocprofv3 --marker-trace` (rocprofiler-sdk's roctx) or any tool that interposes libroctx64; without such a library
-// in the process they cost one predictable branch.
+// `rocprofv3 --marker-trace` (rocprofiler-sdk's roctx) or any tool that interposes libroctx64.  Only a roctx library
+// the profiler has ALREADY mapped is used (RTLD_NOLOAD): an unprofiled process loads nothing and a range costs one
+// predictable branch.  LD_ROCTX=1 loads the library on demand (a tool that attaches later).
 namespace {
 typedef int (*RangePushFn)(const char*);
 typedef int (*RangePopFn)(void);
@@ -156,7 +157,8 @@ Roctx* roctx() {
   std::call_once(once, [] {
     if (getenv("LD_NO_ROCTX")) return;
     const char* names[3] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so"};
-    for (int pass = 0; pass < 2 && !r.push; ++pass)                     // pass 0: whatever the profiler already mapped
+    const int passes = getenv("LD_ROCTX") ? 2 : 1;
+    for (int pass = 0; pass < passes && !r.push; ++pass)                // pass 0: whatever the profiler already mapped
       for (const char* n : names) {
         void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
         if (!h) continue;
@@ -196,12 +198,21 @@ hipError_t ld_allow_lds_ptr(const void* kernel, size_t bytes) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
+  // per-thread fast path: the last grants this thread saw (launching threads do not contend on the mutex once a
+  // kernel's limit has been raised on their device)
+  thread_local std::map<std::pair<const void*, int>, size_t> seen;
+  const auto key = std::make_pair(kernel, dev);
+  const auto it = seen.find(key);
+  if (it != seen.end() && bytes <= it->second) return hipSuccess;
   static std::mutex mu;
   static std::map<std::pair<const void*, int>, size_t> granted;
   std::lock_guard<std::mutex> lock(mu);
   size_t& have = granted[std::make_pair(kernel, dev)];
-  if (bytes <= have) return hipSuccess;
-  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) have = bytes;
-  return e;
+  if (bytes > have) {
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    have = bytes;
+  }
+  seen[key] = have;
+  return hipSuccess;
 }

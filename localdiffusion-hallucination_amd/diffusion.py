@@ -106,13 +106,17 @@ class _SubBatches:
         ddpm.py:852-858) instead of its slice of one draw.  ``masked``: sub-batches whose prediction is replaced
         by the range minimum outside a mask (``set_mask``), i.e. ld_mask_out folded into their final step."""
         self.gd, self.jp, self.S = gd, jp, S
+        if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in os.environ and not getattr(_SubBatches, "_warned", False):
+            _SubBatches._warned = True
+            import warnings
+            warnings.warn("graph-replay sampling without localdiffusion_hallucination_amd.configure_runtime(): the HIP "
+                          "runtime's captured AQL packets make replayed steps 1-5 % slower (call it before the first "
+                          "GPU call of the process; INTEGRATION.md)", RuntimeWarning, stacklevel=3)
         B, _, H, W = jp.x_in.shape
         self.b = B // S
         # plans are cached per shape: instances 1..S of this batch size belong to the sub-batch runners
         self.plans = [gd.model.plan(self.b, H, W, table_T=gd.num_timesteps_ori, instance=instance_base + i + 1)
                       for i in range(S)]
-        for i, sp in enumerate(self.plans):        # stage programs: the sub-batches settle on disjoint halves of the XCDs
-            sp.xcd_base = (4 * i) % 8
         self.streams = gd._sub_streams(S)
         self.shared_noise = shared_noise
         self.masks = {i: torch.ones(self.b, H * W, dtype=torch.float32, device=jp.x_in.device) for i in masked}
@@ -187,7 +191,7 @@ class _SubBatches:
                 sp.x_in.copy_(jp.x_in[i * b:(i + 1) * b])
                 if recond:                          # the parent's conditioning changed: encode this slice of it
                     sp.cond_in.copy_(jp.cond_in[i * b:(i + 1) * b])
-                    sp.run_cond(st)
+                    sp.run_cond_replayed(gs)        # one graph launch per sample (the first sample: eager + capture)
                 sp.set_step(t_start + 1)
                 todo[i] -= self._ensure_graph(i, gs, lo, hi, base)
                 ex[i] = self.graphs[(i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)]
@@ -270,8 +274,6 @@ class _DdimBranches:
         self.gd, self.B, self.mask_x, self.shared = gd, B, mask_x and shared, shared
         dev = gd.device
         self.plans = [gd.model.plan(B, H, W, table_T=gd.num_timesteps_ori, instance=200 + i) for i in range(2)]
-        for i, sp in enumerate(self.plans):
-            sp.xcd_base = 4 * i
         self.streams = gd._sub_streams(2)
         self.idx = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
         self.times = torch.tensor(times, dtype=torch.int32, device=dev)
@@ -296,6 +298,28 @@ class _DdimBranches:
         cabi.check(lib.ld_ddim_step_at(sp.x_in.data_ptr(), sp.model_out.data_ptr(), zp, sp.x_in.data_ptr(), self.table.data_ptr(),
                                        self.idx[i].data_ptr(), lo, hi, cabi.OBJ[gd.objective], n, st), "ddim_step_at")
 
+    def run_timed(self, n_steps, acc, lo, hi, alone=False):
+        """bench.py's per-kernel leg for the strided sampler: branch 0's denoiser evaluations run eagerly with HIP events
+        around every launch (``acc``, see _Plan.run_main_timed) while branch 1 replays its captured step beside it
+        (``alone``: nothing beside it).  Call after ``run`` has captured the graphs; the states are scratch afterwards."""
+        lib = cabi.lib()
+        cur = torch.cuda.current_stream()
+        g1 = next((g for k, g in self.graphs.items() if k[0] == 1), None)
+        for gs in self.streams:
+            gs.wait_stream(cur)
+        if g1 is not None and not alone:
+            self.idx[1].fill_(0)
+            for _ in range(n_steps + 2):
+                cabi.check(lib.ld_graph_launch(g1, self.streams[1].cuda_stream), "graph_launch")
+        sp, gs = self.plans[0], self.streams[0]
+        with torch.cuda.stream(gs):
+            for k in range(n_steps):
+                sp.set_step(int(self.times[min(k, len(self.times) - 1)]))
+                sp.run_main_timed(gs.cuda_stream, acc)
+        for gs in self.streams:
+            cur.wait_stream(gs)
+        torch.cuda.synchronize()
+
     def run(self, x_out, x_in, cond_out, cond_in, mask, first_pair, n_steps, lo, hi):
         """Pairs first_pair .. first_pair + n_steps - 1 for both branches; x_out / x_in are updated in place."""
         import ctypes as C
@@ -310,7 +334,7 @@ class _DdimBranches:
             with torch.cuda.stream(gs):
                 sp.x_in.copy_(xv)
                 sp.cond_in.copy_(cv)
-                sp.run_cond(st)
+                sp.run_cond_replayed(gs)                     # one graph launch per sample (the first sample: eager + capture)
                 self.idx[i].fill_(first_pair - 1)            # the step's first launch advances the pair counter
                 key = (i, float(lo), float(hi), gd_key(self.gd), self.shared)
                 if key not in self.graphs:
@@ -467,6 +491,23 @@ class GaussianDiffusion(nn.Module):
         a freshly constructed one again."""
         self._mask_x_carried, self._mask_x_cfg_seen = None, None
         self.classifier_flag = 0
+
+    def advance_call_state(self, mask):
+        """Leave behind what a ``sample()`` call with this (GLOBAL) mask leaves behind in the state that outlives a call --
+        the call counter and the carried ``mask_x`` (re-armed under ood_AD / ood_confidence, ddpm.py:1106-1108; cleared by
+        the all-ones fallback, :1114, and by the fusion step, :780-781 / :1023-1024) -- without sampling.  dist.py calls it
+        on a rank whose shard of a sharded call is empty, so that every rank of the NEXT call runs the same reverse
+        process (the classifier gate's data-dependent rejection, :907-908, is per rank by nature)."""
+        c = self.config
+        self.cnt += 1
+        if bool(c.get("ood_AD", False)) or bool(c.get("ood_confidence", False)):
+            self._mask_x_set(True)
+        branch_cfg = bool(c["branch_out"]) or self.branch_out
+        fuse_cfg = bool(c["start_intermediate"]) or self.start_intermediate
+        if branch_cfg and self._all_ones(mask):
+            self._mask_x_set(False)
+        elif branch_cfg and fuse_cfg and mask is not None:
+            self._mask_x_set(False)
 
     def _all_ones(self, mask):
         """ddpm.py:1110-1112 (one device sync per call, as there)."""

@@ -75,9 +75,12 @@ class LdComm:
     @classmethod
     def bootstrap(cls, world=None, rank=None, id_file=None, run_id=None, timeout_s=120.0):
         """Collective: every rank calls it.  With a torch process group the id travels by broadcast; otherwise rank 0
-        writes ``id_file`` and the others poll for it.  ``run_id`` (any string all ranks of THIS run agree on, e.g.
-        MASTER_PORT or a job id) becomes part of the file name, so a file left behind by an earlier run is never read;
-        without one the launcher must hand every run a fresh ``id_file``.  Polling gives up after ``timeout_s``."""
+        writes ``id_file`` and the others poll for it.  ``run_id`` (any string all ranks of THIS run agree on and no
+        other run shares: a job id, ``TORCHELASTIC_RUN_ID``) becomes part of the file name; without one the name falls
+        back to ``MASTER_PORT``, which torchrun reuses from run to run -- so rank 0 removes the file again as soon as the
+        communicator is up (``ncclCommInitRank`` is collective: when it returns on rank 0 every rank has read the id),
+        and a file can only be left behind by a run that died inside the rendezvous.  After such a crash pass a fresh
+        ``run_id`` or ``id_file``: a stale id makes ``ncclCommInitRank`` hang, and ``timeout_s`` only bounds the polling."""
         import os
         import time
         if dist.is_available() and dist.is_initialized():
@@ -92,7 +95,7 @@ class LdComm:
         if world == 1:
             return cls(1, 0, cls.make_unique_id())
         if run_id is None:
-            run_id = os.environ.get("MASTER_PORT") or os.environ.get("TORCHELASTIC_RUN_ID")
+            run_id = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT")
         if run_id is not None:
             id_file = f"{id_file}.{run_id}"
         if rank == 0:
@@ -104,7 +107,13 @@ class LdComm:
             if time.monotonic() - t0 > timeout_s:
                 raise TimeoutError(f"LdComm.bootstrap: rank {rank} saw no {id_file} within {timeout_s} s")
             time.sleep(0.01)
-        return cls(world, rank, open(id_file, "rb").read())
+        comm = cls(world, rank, open(id_file, "rb").read())
+        if rank == 0:
+            try:
+                os.unlink(id_file)
+            except OSError:
+                pass
+        return comm
 
     def all_gather(self, send, recv):
         """recv[r*len(send) ...] = rank r's ``send`` (contiguous device tensors), enqueued on the current stream."""
@@ -186,6 +195,16 @@ def _sample_shard(diffusion, lo, hi, per_sample_elems, call):
         diffusion.noise_offset = keep
 
 
+def _idle_rank_advances(diffusion, masks):
+    """A rank without a shard does not call ``sample()``, but the state ``sample()`` carries from one call to the next
+    (the reference's mutated ``config['mask_x']``, golden G14) must move on it as on the working ranks: otherwise the next
+    sharded call -- with a batch large enough to give this rank work -- would mix first-call and second-call reverse
+    processes in one gathered batch."""
+    adv = getattr(diffusion, "advance_call_state", None)
+    if adv is not None:
+        adv(masks)
+
+
 def sample_patches_sharded(diffusion, conds, min_max_val, n_images, k_masks, masks, gather_dtype=None):
     """Independent local patches: run ``diffusion.sample`` on this rank's contiguous shard
     of the [n_images*k_masks] patch list with no traffic inside the T-loop, ONE all-gather, recomposition by the
@@ -201,6 +220,7 @@ def sample_patches_sharded(diffusion, conds, min_max_val, n_images, k_masks, mas
             conds[lo:hi], None, batch_size=hi - lo, mask=None, min_max_val=min_max_val))
     else:                                                    # more ranks than patches: replicas idle
         x = conds.new_zeros((0, C, H, H), dtype=torch.float32)
+        _idle_rank_advances(diffusion, None)
     allx = gather_patches(x.to(torch.float32), P, dtype=gather_dtype)
     return recompose(allx.reshape(n_images, k_masks, *allx.shape[1:]), masks)
 
@@ -230,6 +250,8 @@ def sample_images_sharded(diffusion, cond_img, gt, masks, min_max_val, **sample_
             out = _sample_shard(diffusion, lo, hi, C * H * H, lambda: diffusion.sample(
                 cond_img[lo:hi], None if gt is None else gt[lo:hi], batch_size=hi - lo,
                 mask=None if masks is None else masks[lo:hi], min_max_val=min_max_val, **sample_kw))
+        else:
+            _idle_rank_advances(diffusion, masks)
         layout = diffusion.result_layout(masks)
     finally:
         diffusion._all_ones_forced = keep

@@ -90,9 +90,6 @@ class Unet(nn.Module):
         self._packed = None
         self._packed_key = None
         self._plans = {}
-        # stage programs (csrc/stage.hip): runs of small-map launches as one persistent launch; maps of at most this many
-        # pixels per image (0 = off)
-        self.stage_max_px = int(os.environ.get("LD_STAGE_MAX_PX", "0"))
         # two-term convolution weights (W = hi + lo in 16-bit storage, twice the matrix work) for the layers of the
         # first N resolution levels (0 = off; 2 = the full- and half-resolution layers, which carry 90 % of what
         # rounding the weights costs a sampling chain: DESIGN section 2).  See set_weight_split_levels().
@@ -274,7 +271,7 @@ class Unet(nn.Module):
         f = self.downsample_factor
         assert H % f == 0 and W % f == 0, \
             f"your input dimensions {(H, W)} need to be divisible by {f}, given the unet"   # ddpm.py:405
-        key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels, self.stage_max_px)
+        key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels)
         if key not in self._plans:
             self._plans[key] = _Plan(self, B, H, W, table_T)
         return self._plans[key]
@@ -323,9 +320,6 @@ class _Plan:
         self.named = {}                            # oracle tap name -> NHWC buffer (parity tests)
         self.meta = {}                             # index in ops_main -> {what, family, bytes, flops}
         self.ops_time, self.ops_cond, self.ops_main = [], [], []
-        self.stage_px = {}                         # index in ops_main -> pixels per image, for the ops a stage program can hold
-        self.stages = []                           # (program handle, control block) of the stage programs of this plan
-        self.xcd_base = 0                          # stage programs: image i prefers XCD (xcd_base + i) mod 8
         self.nslot = 0
         self.stats = torch.zeros(160, B, cabi.STAT_STRIPES, 16, 2, dtype=torch.float64, device=self.dev)
         self.cond_slots = 16                       # slots [0,16) belong to the conditioning encoder
@@ -355,7 +349,6 @@ class _Plan:
             self.fusion_const = (p1, p2, torch.zeros(c, dtype=torch.float32, device=self.dev))
         self._slot_cursor = self.cond_slots
         self._build_main()
-        self._build_stages()
         self._slots_used = self._slot_cursor       # statistics slots [cond_slots, _slots_used) are zeroed per evaluation
         s_, km_ = self.stats[self.cond_slots:self._slots_used], self.kmax_arena[:self._kmax_cursor]
         self._begin_args = (s_.data_ptr(), s_.numel() * 8, km_.data_ptr() if km_.numel() else None, km_.numel() * 4)
@@ -438,8 +431,6 @@ class _Plan:
         self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname,
                    dict(family=fam, bytes=(in_el + npx * cout + 9 * cin * cout) * self.esize + 4 * cout,
                         flops=2 * 9 * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"))
-        if ops is self.ops_main:
-            self.stage_px[len(ops) - 1] = h * w
         return out
 
     def conv1(self, ops, srcs, weight, cout, h, w, bias=None, epi=cabi.EPI_PLAIN, unshuffle=0, rms_in=0,
@@ -479,8 +470,6 @@ class _Plan:
         nel = self.B * h * w * c
         self._call(ops, self.lib.ld_gn_apply, g, "gn_apply",
                    dict(family="gn_apply", bytes=(nel * (2 if b_src is not None else 1) + nel // (4 if pool else 1)) * self.esize, flops=0))
-        if ops is self.ops_main and not pool:
-            self.stage_px[len(ops) - 1] = h * w
         return out
 
     # ------------------------------------------------------------------ time embedding / FiLM
@@ -759,65 +748,10 @@ class _Plan:
             self.dt, st), "final_conv"), "final_conv",
             nbytes=B * H * W * (self.esize * cfg.dim + 4 * cfg.out_dim), flops=2 * cfg.dim * cfg.out_dim * B * H * W)
 
-    # ------------------------------------------------------------------ stage programs (csrc/stage.hip)
-    def _build_stages(self):
-        """Replace every run of >= 2 consecutive small-map launches the stage kernel has tile functions for (3x3
-        convolutions with 32-channel tiles, gn_apply) by ONE persistent launch: one image per XCD, XCD-local phase
-        boundaries instead of kernel boundaries.  ``Unet.stage_max_px`` (LD_STAGE_MAX_PX; 0 = off) bounds the map size;
-        at most 8 images per launch.  The control block of a stage lives in statistics slots, which the step's first
-        launch (ld_step_begin) zeroes anyway."""
-        max_px = int(getattr(self.net, "stage_max_px", 0))
-        if max_px <= 0 or self.dt == cabi.LD_F32 or self.B > 8:
-            return
-        ops, lib = self.ops_main, self.lib
-        runs, i = [], 0
-        while i < len(ops):
-            j = i
-            while j < len(ops) and self.stage_px.get(j, 1 << 30) <= max_px:
-                j += 1
-            if j - i >= 2:
-                runs.append((i, j))
-            i = max(j, i + 1)
-        new_ops, new_meta, cur = [], {}, 0
-        slot_bytes = self.stats[0].numel() * 8
-        ctl_bytes = int(lib.ld_stage_ctl_bytes())
-        for (i0, i1) in runs + [(len(ops), len(ops))]:
-            for k in range(cur, i0):
-                new_meta[len(new_ops)] = self.meta.get(k, {})
-                new_ops.append(ops[k])
-            if i0 == len(ops):
-                break
-            cabi.check(lib.ld_stage_begin(), "stage_begin")
-            prog, nph = C.c_void_p(), C.c_int()
-            try:
-                for k in range(i0, i1):
-                    ops[k](None)                   # recorded, not launched
-            finally:
-                rc = lib.ld_stage_end(C.byref(prog), C.byref(nph))
-            if rc != 0 or not prog.value:          # a variant without a tile function: keep the ordinary launches
-                for k in range(i0, i1):
-                    new_meta[len(new_ops)] = self.meta.get(k, {})
-                    new_ops.append(ops[k])
-            else:
-                nslots = (ctl_bytes + slot_bytes - 1) // slot_bytes
-                ctl = self.slot()
-                for _ in range(nslots - 1):
-                    self.slot()
-                self.stages.append((prog, ctl))
-                ms = [self.meta.get(k, {}) for k in range(i0, i1)]
-                new_meta[len(new_ops)] = dict(what=f"stage of {i1 - i0} launches", family="stage",
-                                              bytes=sum(m.get("bytes", 0) for m in ms), flops=sum(m.get("flops", 0) for m in ms),
-                                              shape=f"{ms[0].get('shape', '')}..", fused=[m.get("family", "?") for m in ms])
-                new_ops.append(lambda st, prog=prog, ctl=ctl: cabi.check(
-                    lib.ld_stage_launch(prog, ctl.data_ptr(), self.xcd_base, 512, self.dt, st), "stage"))
-            cur = i1
-        self.ops_main[:] = new_ops
-        self.meta = new_meta
-
     def __del__(self):
         try:
-            for prog, _ in self.stages:
-                self.lib.ld_stage_destroy(prog)
+            if getattr(self, "_cond_graph", None) is not None:
+                self.lib.ld_graph_destroy(self._cond_graph)
         except Exception:
             pass
 
@@ -834,6 +768,36 @@ class _Plan:
             cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
             for op in self.ops_cond:
                 op(st)
+        finally:
+            self.lib.ld_range_pop()
+
+    def run_cond_replayed(self, stream):
+        """``run_cond`` as ONE replayed HIP graph on ``stream`` (a torch stream that is current): the encoder of a sample
+        is ~45 dependent launches (0.4 ms of host-paced issue per sub-batch at the head of every sample, VERDICT r3 item
+        5); its buffers and arguments are static, so after the first evaluation -- eager, because lazy
+        hipFuncSetAttribute calls must not happen inside a capture -- the launch sequence is captured once and every
+        later sample replays it with one graph launch."""
+        st = stream.cuda_stream
+        g = getattr(self, "_cond_graph", None)
+        if g is None:
+            self.run_cond(st)
+            stream.synchronize()
+            s = self.stats[:self.cond_slots]
+            cabi.check(self.lib.ld_graph_begin(st), "graph_begin")
+            try:
+                cabi.check(self.lib.ld_memset_zero(s.data_ptr(), s.numel() * 8, st), "memset")
+                for op in self.ops_cond:
+                    op(st)                     # recorded, not run
+            finally:
+                g = C.c_void_p()
+                rc = self.lib.ld_graph_end(st, C.byref(g))
+            cabi.check(rc, "graph_end")
+            self._cond_graph = g
+            return
+        self.cond_version = getattr(self, "cond_version", 0) + 1
+        self.lib.ld_range_push(b"encoder (graph replay)")
+        try:
+            cabi.check(self.lib.ld_graph_launch(g, st), "graph_launch")
         finally:
             self.lib.ld_range_pop()
 

@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+import localdiffusion_hallucination_amd as _ldh  # noqa: E402
+
+_ldh.configure_runtime()       # before any GPU call of the test process: the runtime settings bench.py measures with
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

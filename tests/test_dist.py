@@ -87,6 +87,12 @@ class _StubDiffusion:
     def __init__(self, fuse=True):
         self.noise_offset, self.fuse = 0, fuse
         self.calls = []
+        self.carried = True          # stands for the mask_x flag the reference carries from one sample() call to the next
+
+    def advance_call_state(self, mask):
+        """GaussianDiffusion.advance_call_state: what a sample() call leaves behind, without sampling (idle ranks)."""
+        if self.fuse:
+            self.carried = False
 
     _all_ones_forced = None
 
@@ -109,6 +115,10 @@ class _StubDiffusion:
         x = cond * 2.0 + z + (0.0 if mask is None else mask)
         if self._all_ones(mask):
             x = x * 0.5 - 3.0
+        if self.carried:             # first-call semantics differ from second-call semantics (golden G14)
+            x = x + 7.0
+        if self.fuse:
+            self.carried = False     # the fusion step clears the carried flag (ddpm.py:780-781)
         return x if self.fuse else torch.stack([x, -x], 0)
 
 
@@ -159,6 +169,65 @@ def test_sharded_sampling_equals_the_unsharded_call_world2_gloo(n_items):
         p.join(120)
         assert p.exitcode == 0
     assert dict(q.get(timeout=10) for _ in range(world)) == {0: True, 1: True}
+
+
+def _two_call_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(2)
+        cond = torch.randn(2, 3, 4, 4)
+        masks = (torch.rand(2, 1, 4, 4) > 0.5).float()
+        whole = _StubDiffusion(True)
+        ref1 = whole.sample(cond[:1], None, batch_size=1, mask=masks[:1])
+        ref2 = whole.sample(cond, None, batch_size=2, mask=masks)
+        gd = _StubDiffusion(True)
+        got1 = ldist.sample_images_sharded(gd, cond[:1], None, masks[:1], (0.0, 2.0))   # world > n: rank 1 is idle
+        got2 = ldist.sample_images_sharded(gd, cond, None, masks, (0.0, 2.0))           # now every rank has work
+        q.put((rank, bool(torch.equal(got1, ref1) and torch.equal(got2, ref2) and gd.carried is False)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_idle_rank_carries_the_call_state_world2_gloo():
+    """the state sample() carries from call to call (mask_x, golden G14) must advance on a rank whose shard
+    was empty too -- a 1-image call at world 2 followed by a 2-image call must equal the same two calls unsharded
+    (without the fix rank 1 samples its image of the second call with first-call semantics)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_call_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=10) for _ in range(world)) == {0: True, 1: True}
+
+
+def test_advance_call_state_mirrors_the_sampler_flags():
+    """GaussianDiffusion.advance_call_state on the host (no GPU needed: it only touches the carried flags): the
+    transitions of ddpm.py:1106-1117 / :780-781 for {mask_x: True, ood_AD: False} and under ood_AD."""
+    import localdiffusion_hallucination_amd as ldh
+    net = ldh.Unet(dim=32, init_dim=32, dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist")
+    base = dict(branch_out=True, start_intermediate=True, start_timestep=2, data="mnist", mask_x=True, ood_AD=False,
+                ood_confidence=False, classifier=False, use_gt=False)
+    band = torch.zeros(1, 1, 28, 28)
+    band[..., :7] = 1.0
+    gd = ldh.GaussianDiffusion(dict(base), net, image_size=28, timesteps=10, objective="pred_x0")
+    assert gd._mask_x_get() is True
+    gd.advance_call_state(band)                   # a fused call clears it ...
+    assert gd._mask_x_get() is False and gd.cnt == 0
+    gd.advance_call_state(band)
+    assert gd._mask_x_get() is False              # ... and nothing re-arms it without ood_AD
+    gd2 = ldh.GaussianDiffusion(dict(base, ood_AD=True), net, image_size=28, timesteps=10, objective="pred_x0")
+    gd2.advance_call_state(torch.ones(1, 1, 28, 28))          # all-ones fallback clears it (:1114) ...
+    assert gd2._mask_x_carried is False
+    assert gd2._flags(band)[2] is True            # ... and ood_AD re-arms the next call (:1106-1108)
+    gd3 = ldh.GaussianDiffusion(dict(base, start_intermediate=False), net, image_size=28, timesteps=10, objective="pred_x0")
+    gd3.advance_call_state(band)                  # branches never fused: nothing clears it
+    assert gd3._mask_x_get() is True
 
 
 def test_recompose_has_no_cpu_fallback():

@@ -130,6 +130,13 @@ def test_consecutive_calls_carry_mask_x_like_the_reference(golden, tag, kw, S, s
     gd = make(dict(mode="mri"), conf, 32, 50, S)
     for i, m in enumerate(seq):
         check(f"G14 {tag} call {i + 1}", run(gd, cond, masks[m], 2), g[f"{tag}_call{i + 1}"])
+    # an idle rank of a sharded call (dist.py) moves the carried state with advance_call_state() instead of sampling:
+    # its LAST call must then equal the reference's last call of the sequence as well
+    twin = make(dict(mode="mri"), conf, 32, 50, S)
+    for m in seq[:-1]:
+        twin.advance_call_state(masks[m].cuda())
+    check(f"G14 {tag} call {len(seq)} after advance_call_state x{len(seq) - 1}", run(twin, cond, masks[seq[-1]], 2),
+          g[f"{tag}_call{len(seq)}"])
     if tag.endswith("_maskx"):
         gd.reset_call_state()
         check(f"G14 {tag} after reset_call_state", run(gd, cond, masks["band"], 2), g[f"{tag}_call1"])

@@ -170,31 +170,3 @@ def test_large_k_projections_fall_back_to_the_exact_softmax_shift(dtype, limit):
     rel = float((y - y_ref).abs().max()) / float(y_ref.abs().max())
     print(f"k rows x6, {dtype}: bounds {sorted(round(b, 1) for b in bounds.values())}, out rel err {rel:.3e}")
     assert torch.isfinite(y).all() and rel < (8e-3 if dtype == "fp16" else 5e-2)
-
-
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("tag,kw,B,H", [("mvtec256", dict(channels=3, out_dim=3, mode="mvtec"), 4, 256), ("mri128", dict(mode="mri"), 3, 128),
-                                        ("mri256x8", dict(mode="mri"), 8, 256)])
-def test_stage_programs_equal_the_stand_alone_launches(dtype, tag, kw, B, H):
-    """csrc/stage.hip: the runs of small-map launches (3x3 convolutions, gn_apply at <= 32^2) as ONE persistent launch
-    each -- one image per XCD, XCD-local phase boundaries -- against the same plan with ordinary launches.  The tile
-    functions and their arithmetic order are the same, so the outputs must agree to the last bit (the GroupNorm
-    statistics are fp64 sums of the same partials; their order cannot reach a 16-bit result), for every image of the
-    batch, repeatedly (a stale read across a phase boundary would show up as a difference)."""
-    x = torch.from_numpy(rng.randn((B, kw.get("channels", 1), H, H), 1, 100)).cuda()
-    cond = torch.from_numpy(rng.uniform((B, kw.get("channels", 1) if "mvtec" in kw["mode"] else 1, H, H), 1, 101, 0.0, 2.0)).cuda()
-    tv = torch.full((B,), 321, dtype=torch.long).cuda()
-    plain, _ = build(kw, dtype)
-    staged, _ = build(kw, dtype)
-    staged.stage_max_px = 32 * 32
-    y0 = plain(x, cond, tv)
-    p = staged.plan(B, H, H)
-    # (with 8 images the 256-channel convolutions of the 32^2 stage take 64-channel tiles, which have no tile function
-    # in the stage kernel: those runs keep their ordinary launches and only the 128-channel blocks are staged)
-    assert len(p.stages) >= (1 if B == 8 else 3), "no stage program was built"
-    fused = sum(len(m.get("fused", ())) for m in p.meta.values())
-    print(f"{tag} {dtype}: {len(p.stages)} stage programs replace {fused} launches; {len(p.ops_main)} launches per evaluation left")
-    for rep in range(6):
-        y1 = staged(x, cond, tv)
-        assert torch.isfinite(y1).all()
-        assert torch.equal(y0, y1), (rep, float((y0 - y1).abs().max()))
