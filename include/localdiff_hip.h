@@ -80,6 +80,19 @@ int ld_event_destroy(void* ev);
 /* make `stream` wait for `ev` (fork/join of independent branches on two streams, e.g. a ResnetBlock's
  * res_conv beside its 3x3 convs; also captured as graph edges) */
 int ld_stream_wait_event(void* stream, void* ev);
+/* ---- tuning: the launch-routing thresholds of the library, ONE table per process ------------------------------------
+ * Every threshold a dispatcher consults (which tile variant, grouped K staging, the persistent C=32 convolution, ...)
+ * is an entry of this table: defaults compiled in, an environment override LD_<NAME IN CAPITALS> read ONCE when the
+ * table is first used, and explicit control through ld_tuning_set (what localdiffusion_hallucination_amd.tuning.Tuning
+ * applies).  Names (defaults): c1_group (1), c1_group_max_px (32768), c1_group_min_ch (4), c1_pair_max_px (2^40),
+ * c1_small_min (256), conv_raw (1), conv_mt4_min_wgs (256), conv_big_min (512), conv_sk (0), conv_sk_max_wgs (256),
+ * conv_c32 (1), conv_c32_min_tiles (2048), gn_frags_per_block (512), fold_split_min (32).  Values change routing, never
+ * results beyond the summation order of a tile variant.  Unknown name: LD_EINVAL.  Not thread-safe against concurrent
+ * launches (set it before launching).  The reference has no counterpart (its tuning is cuDNN's). */
+int ld_tuning_set(const char* name, long long value);
+int ld_tuning_get(const char* name, long long* value_out);
+int ld_tuning_count(void);
+const char* ld_tuning_name(int index);              /* NULL past the end */
 /* Profiler-visible phase markers: nested roctx ranges (host side) around the phases of a sample -- "encoder",
  * "step", "exchange" -- so that a rocprofv3 --marker-trace of sample() is readable.  The reference's only hook is the
  * wall-clock timer around sample() (test.py:392-415).  No-ops when no roctx library can be loaded (LD_NO_ROCTX=1:

@@ -8,8 +8,6 @@ Importing the package does not load the HIP library: pure-host helpers (``rng``,
 ``schedule``) work anywhere.  ``Unet`` / ``GaussianDiffusion`` load it on first use and raise
 ``RuntimeError`` if it is missing -- there is no CPU fallback on the product path.
 """
-import os as _os
-
 
 def configure_runtime(graph_packet_capture=False):
     """Opt-in process-level HIP runtime settings for the graph-replay sampling regime.  Call it BEFORE the first GPU
@@ -19,17 +17,18 @@ def configure_runtime(graph_packet_capture=False):
     ROCm 7.2's captured AQL packets a replayed kernel node carries ~0.4 us more on the GPU side -- cfg3's step 1.585 ->
     1.570 ms with it off, a 64^2 x 4-patch step 0.818 -> 0.773 ms, no workload slower (DESIGN finding 47); the host
     then needs ~300 us instead of 36 us per replay, still below the step.  Returns the settings it applied."""
+    from .tuning import runtime_env_default
     applied = {}
-    if not graph_packet_capture and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in _os.environ:
-        _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    if not graph_packet_capture and runtime_env_default("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0"):
         applied["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
     return applied
 
 
-from . import rng, schedule, weights  # noqa: F401,E402
+from . import rng, schedule, tuning, weights  # noqa: F401,E402
+from .tuning import Tuning  # noqa: F401,E402
 from .weights import UnetConfig  # noqa: F401,E402
 
-__all__ = ["rng", "schedule", "weights", "UnetConfig", "Unet", "GaussianDiffusion", "configure_runtime"]
+__all__ = ["rng", "schedule", "weights", "tuning", "Tuning", "UnetConfig", "Unet", "GaussianDiffusion", "configure_runtime"]
 
 
 def __getattr__(name):

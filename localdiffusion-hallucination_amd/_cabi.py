@@ -7,8 +7,11 @@ resolved, so a broken build can never silently run something else.
 import ctypes as C
 import os
 
+from .tuning import lib_override_path
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("LD_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "liblocaldiff_hip.so")   # override: A/B builds
+
+LIB_PATH = lib_override_path() or os.path.join(_HERE, "csrc", "liblocaldiff_hip.so")   # override: A/B builds
 
 LD_F32, LD_BF16, LD_F16 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
@@ -61,6 +64,10 @@ _SIGS = {
     "ld_event_destroy": (C.c_int, [vp]),
     "ld_stream_wait_event": (C.c_int, [vp, vp]),
     "ld_counter": (C.c_longlong, [C.c_int]),
+    "ld_tuning_set": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "ld_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
+    "ld_tuning_count": (C.c_int, []),
+    "ld_tuning_name": (C.c_char_p, [C.c_int]),
     "ld_range_push": (C.c_int, [C.c_char_p]),
     "ld_range_pop": (C.c_int, []),
     "ld_conv3x3": (C.c_int, [C.POINTER(Conv3x3Args), vp]),

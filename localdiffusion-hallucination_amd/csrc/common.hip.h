@@ -59,6 +59,15 @@ static inline hipError_t ld_allow_lds(K kernel, size_t bytes) {
   return ld_allow_lds_ptr(reinterpret_cast<const void*>(kernel), bytes);
 }
 
+// ---------------------------------------------------------------- tuning table (runtime.hip; include/localdiff_hip.h)
+struct LdTuning {
+  long long c1_group, c1_group_max_px, c1_group_min_ch, c1_pair_max_px, c1_small_min;
+  long long conv_raw, conv_mt4_min_wgs, conv_big_min, conv_sk, conv_sk_max_wgs;
+  long long conv_c32, conv_c32_min_tiles;
+  long long gn_frags_per_block, fold_split_min;
+};
+const LdTuning& ld_tuning();
+
 // ---------------------------------------------------------------- dtype traits
 // One "fragment" is 16 bytes per lane for every storage type: 8 bf16 / 8 fp16 or 4 fp32 consecutive
 // channels.  A K-chunk is 4 fragments = 64 bytes of channels per pixel (32 bf16 or fp16 / 16 fp32).
@@ -178,6 +187,15 @@ __device__ __forceinline__ uint4 pair_frag16(const float* v0, const float* v1) {
   const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
   const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
   return make_uint4(r0[0], r1[0], r0[1], r1[1]);
+}
+// The same regrouping for LOADS of an operand in accumulator-fragment layout (residual / GroupNorm-tail input of the
+// 1x1 epilogues): ONE 16-byte load at pair_frag16_off(kq) instead of two 8-byte ones; the exchange is an involution, so
+// applying it to the loaded piece returns this lane's fragments of m-tile m (f0) and m + 1 (f1).  Whole wave active.
+__device__ __forceinline__ void unpair_frag16(const uint4& w, uint2& f0, uint2& f1) {
+  const auto r0 = __builtin_amdgcn_permlane16_swap(w.x, w.z, false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(w.y, w.w, false, false);
+  f0 = make_uint2(r0[0], r1[0]);
+  f1 = make_uint2(r0[1], r1[1]);
 }
 // byte offset of the lane's 16-byte piece from channel 0 of m-tile m of its pixel
 __device__ __forceinline__ unsigned pair_frag16_off(int kq) { return (kq & 1) * 32u + (kq >> 1) * 16u; }

@@ -88,17 +88,40 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   // Raw and from a clamped address (pixels past the image are never stored): as `if (p < HW) load4(...)` every one of
   // the MT * NW loads was waited for inside its own branch -- 8-16 dependent round trips (3-6 us) in front of the K loop
   // of every launch with a second operand (tools/scan_serial_loads.py).
+  // 16-bit storage: the fragments of two adjacent m-tiles arrive as ONE 16-byte load per lane (W2 = the raw piece; it is
+  // regrouped into the lane's two fragments by unpair_frag16 where it is used, with the whole wave active)
   typedef typename Raw4<T>::type R4;
-  R4 op2[HAS_OP2 ? MT : 1][HAS_OP2 ? NW : 1];
-  if constexpr (HAS_OP2) {
-    const T* src2 = reinterpret_cast<const T*>(TAIL ? a.tail.data : a.res);
+  constexpr bool W2 = sizeof(T) == 2;
+  constexpr int MP = W2 ? MT / 2 : MT;                                // second-operand pieces per pixel row
+  typedef typename std::conditional<W2, uint4, R4>::type RP;
+  RP op2[HAS_OP2 ? MP : 1][HAS_OP2 ? NW : 1];
+  auto load_op = [&](const T* src, RP (&dst)[MP][NW]) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int p = min(p0 + (wv * NW + j) * 16 + px, HW - 1);
+      const T* pix = src + ((size_t)b * HW + p) * a.Cout + m0 * 16;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) op2[m][j] = load4_raw<T>(src2 + ((size_t)b * HW + p) * a.Cout + (m0 + m) * 16 + kq * 4);
+      for (int m = 0; m < MP; ++m) {
+        if constexpr (W2) dst[m][j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(pix + m * 32) + pair_frag16_off(kq));
+        else dst[m][j] = load4_raw<T>(pix + m * 16 + kq * 4);
+      }
     }
-  }
+  };
+  auto pin_op = [&](const RP& r) {
+    if constexpr (W2) asm volatile("" ::"v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w));
+    else pin_raw4(r);
+  };
+  // fragment of m-tile m of pixel row j (call with the whole wave active)
+  auto frag_op = [&](const RP (&src)[MP][NW], int m, int j, float* v) {
+    if constexpr (W2) {
+      uint2 f0, f1;
+      unpair_frag16(src[m >> 1][j], f0, f1);
+      unpack4<T>((m & 1) ? f1 : f0, v);
+    } else {
+      unpack4<T>(src[m][j], v);
+    }
+  };
+  if constexpr (HAS_OP2) load_op(reinterpret_cast<const T*>(TAIL ? a.tail.data : a.res), op2);
   const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)b * a.w_bstride);
 
   // global address of this thread's fragment of chunk `ch` for tile pixel slot `it` (nullptr: past the image)
@@ -231,16 +254,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
     }
   }
   constexpr bool HAS_OP3 = EPI == EPI_GN_TAIL_RES;      // (its own instantiation: 4*MT*NW registers only conv_fusion needs)
-  R4 op3[HAS_OP3 ? MT : 1][HAS_OP3 ? NW : 1];
-  if constexpr (HAS_OP3) {
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int p = min(p0 + (wv * NW + j) * 16 + px, HW - 1);
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-        op3[m][j] = load4_raw<T>(reinterpret_cast<const T*>(a.res) + ((size_t)b * HW + p) * a.Cout + (m0 + m) * 16 + kq * 4);
-    }
-  }
+  RP op3[HAS_OP3 ? MP : 1][HAS_OP3 ? NW : 1];
+  if constexpr (HAS_OP3) load_op(reinterpret_cast<const T*>(a.res), op3);
 
   T* out = reinterpret_cast<T*>(a.out);
   const bool q_part = (m0 * 16) < a.hidden;
@@ -254,13 +269,16 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   for (int m = 0; m < MT; ++m) {                       // every epilogue operand has landed before the first store
     asm volatile("" ::"v"(bv[m][0]), "v"(bv[m][1]), "v"(bv[m][2]), "v"(bv[m][3]));
     if constexpr (EPI == LD_EPI_RMS_RES) asm volatile("" ::"v"(g2v[m][0]), "v"(g2v[m][1]), "v"(g2v[m][2]), "v"(g2v[m][3]));
+  }
+#pragma unroll
+  for (int m = 0; m < MP; ++m) {
     if constexpr (HAS_OP2) {
 #pragma unroll
-      for (int j = 0; j < NW; ++j) pin_raw4(op2[m][j]);
+      for (int j = 0; j < NW; ++j) pin_op(op2[m][j]);
     }
     if constexpr (HAS_OP3) {
 #pragma unroll
-      for (int j = 0; j < NW; ++j) pin_raw4(op3[m][j]);
+      for (int j = 0; j < NW; ++j) pin_op(op3[m][j]);
     }
   }
 #pragma unroll
@@ -330,18 +348,18 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
       const int co = (m0 + m) * 16 + kq * 4;
       if constexpr (EPI == LD_EPI_RMS_RES || EPI == LD_EPI_RES) {
         float o2[4];
-        unpack4<T>(op2[m][j], o2);
+        frag_op(op2, m, j, o2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[m][r] += o2[r];
       } else if constexpr (TAIL) {
         float rv[4];
-        unpack4<T>(op2[m][j], rv);
+        frag_op(op2, m, j, rv);
         affine_act_n<DT<T>::precise, 4>(rv, s_tcoef + co, s_tcoef + a.Cout + co, a.tail.act);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[m][r] += rv[r];
         if constexpr (HAS_OP3) {                       // step-invariant half of res_conv (conv_fusion)
           float o3[4];
-          unpack4<T>(op3[m][j], o3);
+          frag_op(op3, m, j, o3);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[m][r] += o3[r];
         }
@@ -428,19 +446,21 @@ int dispatch(const Conv1Dev& a0, hipStream_t st) {
   const int HW = a.H * a.W;
   {
     // grouped staging where the launch is a chain of dependent round trips over a small map: at most
-    // LD_C1_GROUP_MAX_PX pixels in the whole launch (default 64^2 x 8) and at least 4 K-chunks; LD_C1_GROUP=0: off
-    static const long group_max_px = getenv("LD_C1_GROUP_MAX_PX") ? atol(getenv("LD_C1_GROUP_MAX_PX")) : 32768;
-    static const int group_on = getenv("LD_C1_GROUP") ? atoi(getenv("LD_C1_GROUP")) : 1;
+    // c1_group_max_px pixels in the whole launch (default 64^2 x 8) and at least 4 K-chunks; c1_group = 0: off
+    // (entries of the tuning table, include/localdiff_hip.h)
+    const LdTuning& tn = ld_tuning();
+    const long group_max_px = tn.c1_group_max_px;
+    const int group_on = (int)tn.c1_group;
     const int ck = DT<T>::CK;
     const int nc0 = a.s[0].C / ck;
     const int nch = (a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / ck : 0)) << a.wsplit;
-    static const int group_min_ch = getenv("LD_C1_GROUP_MIN_CH") ? atoi(getenv("LD_C1_GROUP_MIN_CH")) : 4;
+    const int group_min_ch = (int)tn.c1_group_min_ch;
     a.group = (group_on && (long)HW * a.B <= group_max_px && nch >= group_min_ch) ? KG : 0;
     // every other launch with at least two chunks: pairs (one round trip per two chunks).  Until round 3 only up to
     // 65,536 pixels per launch (the 128^2 stage at 4 patches) -- "at 256^2 pairs change nothing" was measured while the
     // second-operand loads of those launches were still waited for one by one (finding 63); with that gone the 64->32 @256^2
     // tail launches gain: step 1.4293 -> 1.3978 ms (-2.2 %), cfg5 -2.0 %, 64 patches per GPU and one batch of 8 unchanged.
-    static const long pair_max_px = getenv("LD_C1_PAIR_MAX_PX") ? atol(getenv("LD_C1_PAIR_MAX_PX")) : (1L << 40);
+    const long pair_max_px = tn.c1_pair_max_px;
     if (group_on && !a.group && (long)HW * a.B <= pair_max_px && nch >= 2) a.group = 2;
   }
   if (a.epi == LD_EPI_RMS_RES) {
@@ -457,7 +477,7 @@ int dispatch(const Conv1Dev& a0, hipStream_t st) {
   // (256 since round 3: at 512 the two 192->128 @64^2 tail launches of a 4-patch sub-batch -- exactly 256 workgroups of
   //  64-channel tiles -- fell back to 512 workgroups of 32-channel tiles; with 64-channel tiles the step is 0.65 % faster,
   //  six alternating pairs; 128 and 384 measure like 512)
-  static const long small_min = getenv("LD_C1_SMALL_MIN") ? atol(getenv("LD_C1_SMALL_MIN")) : 256;
+  const long small_min = ld_tuning().c1_small_min;
   if (mt4 && (long)((HW + 127) / 128) * (a.Cout / 64) * a.B < small_min) mt4 = false;
   const long blocks4 = (long)((HW + 255) / 256) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
   const bool big = blocks4 >= 512;

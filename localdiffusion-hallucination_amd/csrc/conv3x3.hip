@@ -77,27 +77,31 @@ int launch(const Conv3Dev& a, hipStream_t st) {
   }
 #endif
   if constexpr (!DEEP) {
-    static const bool no_raw = getenv("LD_CONV_NO_RAW") != nullptr;      // tuning override: always the general kernel
     const bool raw = !a.s[0].stats && !(a.nsrc > 1 && a.s[1].stats);
-    if (raw && !no_raw) return launch_dbg<T, MT, NW, DEEP, 0, false, true>(a, st);
+    if (raw && ld_tuning().conv_raw) return launch_dbg<T, MT, NW, DEEP, 0, false, true>(a, st);
   }
   return launch_dbg<T, MT, NW, DEEP, 0>(a, st);
 }
 
 template <typename T>
 int dispatch(const Conv3Dev& a, hipStream_t st) {
-  static const int force_mt = getenv("LD_CONV_MT") ? atoi(getenv("LD_CONV_MT")) : 0;   // tuning overrides
+#ifdef LD_DEBUG_VARIANTS          // experiment-only: force a tile variant
+  static const int force_mt = getenv("LD_CONV_MT") ? atoi(getenv("LD_CONV_MT")) : 0;
   static const int force_nw = getenv("LD_CONV_NW") ? atoi(getenv("LD_CONV_NW")) : 0;
+#else
+  constexpr int force_mt = 0, force_nw = 0;
+#endif
+  const LdTuning& tn = ld_tuning();
   bool mt4 = (a.Cout % 64) == 0;
   // a launch that would not even give every CU one 64-channel-tile workgroup uses 32-channel tiles instead
   // (128->128 @32^2, B=8: 128 workgroups -> 256; rocprofv3: 10.3 -> 8.3 us)
-  static const long mt4_min = getenv("LD_CONV_MT4_MIN_WGS") ? atol(getenv("LD_CONV_MT4_MIN_WGS")) : 256;
+  const long mt4_min = tn.conv_mt4_min_wgs;
   if (mt4 && (long)((a.W + 15) / 16) * ((a.H + 7) / 8) * (a.Cout / 64) * a.B < mt4_min) mt4 = false;
   // enough workgroups to fill 256 CUs a couple of times over with the big tile?
   const long blocks16 = (long)((a.W + 15) / 16) * ((a.H + 15) / 16) * (a.Cout / (mt4 ? 64 : 32)) * a.B;
   // 64-channel tiles keep 2 pixel rows per wave: with the prefetch registers the 4-row variant
   // drops to one wave per SIMD and measured slower (64->64@128^2: 23.3 vs 19.7 us)
-  static const long big_min = getenv("LD_CONV_BIG_MIN") ? atol(getenv("LD_CONV_BIG_MIN")) : 512;   // tuning override
+  const long big_min = tn.conv_big_min;
   bool big = blocks16 >= big_min && a.H >= 16 && !mt4;
   if (force_mt == 2) mt4 = false;
   if (force_mt == 4 && (a.Cout % 64) == 0) mt4 = true;
@@ -120,8 +124,8 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
   // 25.5 -> 22.5, 512->256 46.0 -> 37.6; four-chunk launches and grids beyond one workgroup per CU lose.  Over a
   // step: +0.6 % for one batch of 8 on one stream, -1 % with two concurrent sub-batches (the second stream already
   // fills the gaps this variant closes), hence off by default.
-  static const int force_sk = getenv("LD_CONV_SK") ? atoi(getenv("LD_CONV_SK")) : 0;
-  static const long sk_max_wgs = getenv("LD_CONV_SK_MAX_WGS") ? atol(getenv("LD_CONV_SK_MAX_WGS")) : 256;
+  const int force_sk = (int)tn.conv_sk;
+  const long sk_max_wgs = tn.conv_sk_max_wgs;
   bool sk = force_sk >= 1 && sizeof(T) == 2 && !big && !deep && ((nch >= 8 && wg <= sk_max_wgs) || force_sk == 2);
   if constexpr (sizeof(T) == 2) {
     if (sk) return mt4 ? launch_dbg<T, 4, 2, false, 0, true>(a, st) : launch_dbg<T, 2, 2, false, 0, true>(a, st);
@@ -186,9 +190,10 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   LD_REQUIRE(p->weight_terms >= 0 && p->weight_terms <= 2 && !(p->weight_terms == 2 && !ld_dtype_16(p->dtype)),
              "ld_conv3x3: weight_terms %d (2 needs 16-bit storage)", p->weight_terms);
   a.wsplit = p->weight_terms == 2 ? 1 : 0;
+  a.dbg = 0;
+#ifdef LD_DEBUG_VARIANTS          // ablation / trace variants exist only in a library built with --debug-variants
   static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
   a.dbg = dbg;
-#ifdef LD_DEBUG_VARIANTS
   if (dbg == 128) {                                    // launch spans: a slot per call, its shape kept for the reader
     static int calls = 0;
     const int slot = calls++ & 1023;

@@ -429,7 +429,11 @@ int launch_c32(const C32Dev& a0, hipStream_t st) {
   a.ntiles = a.tiles_x * (a.H / 16);
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
   const size_t lds = (NCH == 1 ? 0 : (size_t)NCH * 9 * 2 * 1024) + (size_t)R * 21 * 1024 + 2 * ctot * sizeof(float);
+#ifdef LD_DEBUG_VARIANTS          // experiment-only (finding 53): a grid for part of the chip
   static const int cus = getenv("LD_CONV_C32_CUS") ? atoi(getenv("LD_CONV_C32_CUS")) : 256;
+#else
+  constexpr int cus = 256;
+#endif
   int G = (cus + a.B - 1) / a.B;                       // one workgroup per CU over the whole launch
   if (G > a.ntiles) G = a.ntiles;
   const dim3 grid(G, a.B);
@@ -453,7 +457,9 @@ int launch_c32(const C32Dev& a0, hipStream_t st) {
   return launch_c32_dbg<T, NCH, R, 0>(a, lds, grid, st);
 }
 
-// "lite" geometry (NWAVE = 4): 8 x 16-pixel tiles, 256-thread workgroups, LD_CONV_C32_LITE_WGS of them per launch
+#ifdef LD_DEBUG_VARIANTS
+// "lite" geometry (NWAVE = 4; experiment, finding 66: slower in the sampler): 8 x 16-pixel tiles, 256-thread
+// workgroups, LD_CONV_C32_LITE_WGS of them per launch
 template <typename T, int R>
 int launch_c32_lite(const C32Dev& a0, hipStream_t st) {
   C32Dev a = a0;
@@ -468,13 +474,14 @@ int launch_c32_lite(const C32Dev& a0, hipStream_t st) {
   LD_LAUNCH_CHECK("conv3x3_c32 (lite)");
   return LD_OK;
 }
+#endif
 
 }  // namespace
 
 // Returns 1 if this launch is handled here, 0 if the generic kernel must take it, <0 on error.
 int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
-  static const int disabled = getenv("LD_CONV_NO_C32") ? atoi(getenv("LD_CONV_NO_C32")) : 0;
-  if (disabled || p->addend || p->Cout != 32 || p->H < 32 || p->W < 32 || p->H % 16 != 0 || p->W % 16 != 0) return 0;
+  const LdTuning& tn = ld_tuning();
+  if (!tn.conv_c32 || p->addend || p->Cout != 32 || p->H < 32 || p->W < 32 || p->H % 16 != 0 || p->W % 16 != 0) return 0;
   const int ck = p->dtype == LD_F32 ? 16 : 32;
   int ctot = 0;
   for (int s = 0; s < p->nsrc; ++s) ctot += p->src[s].C;
@@ -482,13 +489,17 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   // register-staged kernel but LOSES 1-6 us on the two-chunk 64->32 ones (the kernel template still carries NCH).
   if (ctot != ck || p->nsrc != 1) return 0;
   if (p->out_stats && (p->out_groups <= 0 || 32 % p->out_groups != 0)) return 0;
-  static const long min_tiles = getenv("LD_CONV_C32_MIN_TILES") ? atol(getenv("LD_CONV_C32_MIN_TILES")) : 2048;
+  const long min_tiles = tn.conv_c32_min_tiles;
+  const long tiles = (long)(p->W / 16) * (p->H / 16) * p->B;
+#ifdef LD_DEBUG_VARIANTS
   // experiment (finding 66): launches of LD_CONV_C32_LITE .. min_tiles - 1 tiles -- the 4-patch launches of the
   // two-sub-batch regime -- on the 256-thread geometry (0 = off)
   static const long lite_min = getenv("LD_CONV_C32_LITE") ? atol(getenv("LD_CONV_C32_LITE")) : 0;
   static const int lite_ring = getenv("LD_CONV_C32_LITE_R") ? atoi(getenv("LD_CONV_C32_LITE_R")) : 4;
-  const long tiles = (long)(p->W / 16) * (p->H / 16) * p->B;
   const bool lite = lite_min > 0 && tiles >= lite_min && tiles < min_tiles && p->dtype != LD_F32;
+#else
+  constexpr bool lite = false;
+#endif
   if (tiles < min_tiles && !lite) return 0;            // too few tiles to amortise a persistent workgroup
   for (int s = 0; s < p->nsrc; ++s) {                  // the kernel uses 32-bit element offsets
     const long ld = p->src[s].pix_stride > 0 ? p->src[s].pix_stride : p->src[s].C;
@@ -501,20 +512,23 @@ int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st) {
   a.w = p->weight; a.bias = p->bias; a.out = p->out; a.ostats = p->out_stats;
   a.ogroups = p->out_groups > 0 ? p->out_groups : 1;
   a.B = p->B; a.H = p->H; a.W = p->W; a.t_ptr = p->t_ptr; a.tiles_x = a.ntiles = 0;
+  a.dbg = 0;
+  int rc;
+#ifdef LD_DEBUG_VARIANTS          // ablation switches, ring depths 2-4 and the lite geometry: --debug-variants builds only
   static const int dbg = getenv("LD_CONV_DEBUG") ? atoi(getenv("LD_CONV_DEBUG")) : 0;
   a.dbg = dbg;
-  static const int ring = getenv("LD_CONV_C32_R") ? atoi(getenv("LD_CONV_C32_R")) : 6;   // experiment: ring depth
-  int rc;
+  static const int ring = getenv("LD_CONV_C32_R") ? atoi(getenv("LD_CONV_C32_R")) : 6;
   if (lite) {
     if (p->dtype == LD_F16) rc = lite_ring == 6 ? launch_c32_lite<f16, 6>(a, st) : launch_c32_lite<f16, 4>(a, st);
     else rc = lite_ring == 6 ? launch_c32_lite<bf16, 6>(a, st) : (lite_ring == 3 ? launch_c32_lite<bf16, 3>(a, st) : launch_c32_lite<bf16, 4>(a, st));
-  } else if (p->dtype == LD_F32) rc = launch_c32<float, 1, 6>(a, st);
-  else if (p->dtype == LD_F16) rc = ring == 4 ? launch_c32<f16, 1, 4>(a, st) : launch_c32<f16, 1, 6>(a, st);
-  else if (ring == 4) rc = launch_c32<bf16, 1, 4>(a, st);
-#ifdef LD_DEBUG_VARIANTS
-  else if (ring == 2) rc = launch_c32<bf16, 1, 2>(a, st);
-  else if (ring == 3) rc = launch_c32<bf16, 1, 3>(a, st);
+  } else if (p->dtype == LD_BF16 && ring == 4) rc = launch_c32<bf16, 1, 4>(a, st);
+  else if (p->dtype == LD_F16 && ring == 4) rc = launch_c32<f16, 1, 4>(a, st);
+  else if (p->dtype == LD_BF16 && ring == 2) rc = launch_c32<bf16, 1, 2>(a, st);
+  else if (p->dtype == LD_BF16 && ring == 3) rc = launch_c32<bf16, 1, 3>(a, st);
+  else
 #endif
+  if (p->dtype == LD_F32) rc = launch_c32<float, 1, 6>(a, st);
+  else if (p->dtype == LD_F16) rc = launch_c32<f16, 1, 6>(a, st);
   else rc = launch_c32<bf16, 1, 6>(a, st);
   if (rc == LD_OK) ld_count(LD_COUNTER_CONV3X3_C32);
   return rc == LD_OK ? 1 : rc;

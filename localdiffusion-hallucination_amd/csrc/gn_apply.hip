@@ -18,7 +18,7 @@ int run(const GnDev& g, hipStream_t st) {
   const int Ho = g.pool ? g.H / 2 : g.H, Wo = g.pool ? g.W / 2 : g.W;
   const long nfrag = (long)Ho * Wo * (g.a.C / E);
   LD_REQUIRE(nfrag < (1L << 31) / 16, "ld_gn_apply: image too large for 32-bit fragment indices");
-  static const long fpb = getenv("LD_GN_FRAGS_PER_BLOCK") ? atol(getenv("LD_GN_FRAGS_PER_BLOCK")) : 512;   // tuning override
+  const long fpb = ld_tuning().gn_frags_per_block > 0 ? ld_tuning().gn_frags_per_block : 512;   // tuning table
   long blocks = (nfrag + fpb - 1) / fpb;                 // 512: two fragments per thread and iteration
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;

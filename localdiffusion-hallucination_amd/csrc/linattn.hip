@@ -373,8 +373,8 @@ extern "C" int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const floa
   LD_REQUIRE(!(perm && !ld_dtype_16(dtype)), "ld_linattn_ctxfold: perm=1 is the 16-bit chained-operand order");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   LD_DISPATCH(dtype, [&] {
-    // many partials: four chunk groups per workgroup (LD_FOLD_SPLIT_MIN, default 32 partials; 0 = never)
-    static const int split_min = getenv("LD_FOLD_SPLIT_MIN") ? atoi(getenv("LD_FOLD_SPLIT_MIN")) : 32;
+    // many partials: four chunk groups per workgroup (tuning table: fold_split_min, default 32 partials; 0 = never)
+    const int split_min = (int)ld_tuning().fold_split_min;
     if (split_min > 0 && nchunks >= split_min)
       LD_LAUNCH((ctxfold_kernel<T, 2>), dim3(heads, B, 16), dim3(256), 0, st, ctx_part, nchunks, w_out, (T*)w_packed, C, heads, perm);
     else

@@ -1,6 +1,7 @@
 // Runtime plumbing of the C-ABI: error string, device info, HIP-graph capture, events.
 #include "common.hip.h"
 #include <dlfcn.h>
+#include <string.h>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -182,6 +183,60 @@ extern "C" int ld_range_pop(void) {
   if (r->pop) r->pop();
   return LD_OK;
 }
+
+// ---- tuning table ---------------------------------------------------------------------------------------------------
+namespace {
+LdTuning g_tuning = {/*c1_group*/ 1, /*c1_group_max_px*/ 32768, /*c1_group_min_ch*/ 4, /*c1_pair_max_px*/ 1LL << 40, /*c1_small_min*/ 256,
+                     /*conv_raw*/ 1, /*conv_mt4_min_wgs*/ 256, /*conv_big_min*/ 512, /*conv_sk*/ 0, /*conv_sk_max_wgs*/ 256,
+                     /*conv_c32*/ 1, /*conv_c32_min_tiles*/ 2048, /*gn_frags_per_block*/ 512, /*fold_split_min*/ 32};
+struct TuningEntry { const char* name; long long LdTuning::*field; };
+const TuningEntry g_tuning_entries[] = {
+    {"c1_group", &LdTuning::c1_group}, {"c1_group_max_px", &LdTuning::c1_group_max_px}, {"c1_group_min_ch", &LdTuning::c1_group_min_ch},
+    {"c1_pair_max_px", &LdTuning::c1_pair_max_px}, {"c1_small_min", &LdTuning::c1_small_min}, {"conv_raw", &LdTuning::conv_raw},
+    {"conv_mt4_min_wgs", &LdTuning::conv_mt4_min_wgs}, {"conv_big_min", &LdTuning::conv_big_min}, {"conv_sk", &LdTuning::conv_sk},
+    {"conv_sk_max_wgs", &LdTuning::conv_sk_max_wgs}, {"conv_c32", &LdTuning::conv_c32}, {"conv_c32_min_tiles", &LdTuning::conv_c32_min_tiles},
+    {"gn_frags_per_block", &LdTuning::gn_frags_per_block}, {"fold_split_min", &LdTuning::fold_split_min}};
+constexpr int g_tuning_n = sizeof(g_tuning_entries) / sizeof(g_tuning_entries[0]);
+void tuning_env_once() {
+  // the ONE place the library reads tuning from the environment: LD_<NAME IN CAPITALS>, once per process
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const TuningEntry& e : g_tuning_entries) {
+      char var[64] = "LD_";
+      size_t k = 3;
+      for (const char* c = e.name; *c && k + 1 < sizeof(var); ++c) var[k++] = (*c >= 'a' && *c <= 'z') ? (char)(*c - 32) : *c;
+      var[k] = 0;
+      if (const char* v = getenv(var)) g_tuning.*(e.field) = atoll(v);
+    }
+  });
+}
+}  // namespace
+const LdTuning& ld_tuning() {
+  tuning_env_once();
+  return g_tuning;
+}
+extern "C" int ld_tuning_set(const char* name, long long value) {
+  LD_REQUIRE(name, "ld_tuning_set: null name");
+  tuning_env_once();
+  for (const TuningEntry& e : g_tuning_entries)
+    if (strcmp(e.name, name) == 0) {
+      g_tuning.*(e.field) = value;
+      return LD_OK;
+    }
+  return ld_fail(LD_EINVAL, "ld_tuning_set: unknown entry '%s'", name);
+}
+extern "C" int ld_tuning_get(const char* name, long long* value_out) {
+  LD_REQUIRE(name && value_out, "ld_tuning_get: null argument");
+  tuning_env_once();
+  for (const TuningEntry& e : g_tuning_entries)
+    if (strcmp(e.name, name) == 0) {
+      *value_out = g_tuning.*(e.field);
+      return LD_OK;
+    }
+  return ld_fail(LD_EINVAL, "ld_tuning_get: unknown entry '%s'", name);
+}
+extern "C" int ld_tuning_count(void) { return g_tuning_n; }
+extern "C" const char* ld_tuning_name(int index) { return index >= 0 && index < g_tuning_n ? g_tuning_entries[index].name : nullptr; }
 
 // ---- host-side launch counters: which kernel a dispatcher routed a call to ------------------------------------
 namespace {

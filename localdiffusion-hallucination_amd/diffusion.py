@@ -20,7 +20,6 @@ Noise: ``noise_source='device'`` draws z_t with the counter-based generator on t
 (``ld_randn``); ``'host'`` uploads the same stream from ``rng.py`` (bit-identical to the golden
 fixtures); a callable ``f(shape, k) -> tensor`` may be supplied instead.
 """
-import os
 import time
 
 import torch
@@ -28,32 +27,29 @@ from torch import nn
 
 from . import _cabi as cabi
 from . import rng, schedule
+from .tuning import Tuning, runtime_configured
 
 _REPLACE_OUT = ("mnist", "mvtec", "oct", "imagenet")
-_RESYNC = int(os.environ.get("LD_SUB_RESYNC", "32"))     # steps between phase alignments of the sub-batch streams
-_RESYNC_EARLY = int(os.environ.get("LD_SUB_RESYNC_EARLY", "1"))     # ... and before each of the first steps
-# The host enqueues at most this many steps ahead of the GPU (0: no limit).  Unthrottled, the host builds and writes
-# packets without a pause until the hardware queue is full (~38 steps of 2 x 106 nodes) and the GPU runs ~4 % slower for
-# exactly that long: 20 timed steps 1.519 -> 1.483 ms per step with a limit of 2 (1.479 with 1, but with twice the
-# run-to-run spread: one late host wake-up is a GPU bubble; 1.53 with 8), 400 steps unchanged (there the full queue paces
-# the host anyway); DESIGN finding 64, tools/exp_short_knobs.sh, tools/exp_stability.sh.
-_AHEAD = int(os.environ.get("LD_SUB_AHEAD", "2"))
 
 
 class _Pace:
-    """Keeps the host at most ``_AHEAD`` replayed steps ahead of the streams (events, spin-wait on the oldest)."""
+    """Keeps the host at most ``ahead`` (Tuning.sub_ahead) replayed steps ahead of the streams (events, spin-wait on the
+    oldest; 0: no limit).  Unthrottled, the host builds and writes packets without a pause until the hardware queue is
+    full (~38 steps of 2 x 106 nodes) and the GPU runs ~4 % slower for exactly that long: 20 timed steps 1.519 -> 1.483 ms
+    per step with a limit of 2 (1.479 with 1, but with twice the run-to-run spread: one late host wake-up is a GPU
+    bubble; 1.53 with 8), 400 steps unchanged (there the full queue paces the host anyway); docs/findings.md 64."""
 
-    def __init__(self, streams):
-        self.streams, self.pending = streams, []
+    def __init__(self, streams, ahead):
+        self.streams, self.pending, self.ahead = streams, [], int(ahead)
 
     def step_enqueued(self):
-        if _AHEAD <= 0:
+        if self.ahead <= 0:
             return
         evs = [torch.cuda.Event() for _ in self.streams]
         for e, gs in zip(evs, self.streams):
             e.record(gs)
         self.pending.append(evs)
-        if len(self.pending) > _AHEAD:
+        if len(self.pending) > self.ahead:
             for e in self.pending.pop(0):
                 e.synchronize()
 
@@ -106,7 +102,7 @@ class _SubBatches:
         ddpm.py:852-858) instead of its slice of one draw.  ``masked``: sub-batches whose prediction is replaced
         by the range minimum outside a mask (``set_mask``), i.e. ld_mask_out folded into their final step."""
         self.gd, self.jp, self.S = gd, jp, S
-        if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in os.environ and not getattr(_SubBatches, "_warned", False):
+        if not runtime_configured() and not getattr(_SubBatches, "_warned", False):
             _SubBatches._warned = True
             import warnings
             warnings.warn("graph-replay sampling without localdiffusion_hallucination_amd.configure_runtime(): the HIP "
@@ -201,12 +197,13 @@ class _SubBatches:
         # taken, persists: line the streams up when they start (their encoders were enqueued one after the other) and
         # again every LD_SUB_RESYNC steps (default 32; 0: never).
         h0 = time.perf_counter()
-        pace = _Pace(self.streams)
+        tn = self.gd.tuning
+        pace = _Pace(self.streams, tn.sub_ahead)
         lib.ld_range_push(b"steps (graph replay, %d sub-batches)" % self.S)
         for k in range(max(todo)):
             # (and in front of step 1: the host enqueues the streams' first replays one after the other, 0.3 ms apart, so
             # the alignment in front of step 0 finds empty queues and aligns nothing)
-            if self.S > 1 and _RESYNC > 0 and (k % _RESYNC == 0 or k <= _RESYNC_EARLY) and k < min(todo):
+            if self.S > 1 and tn.sub_resync > 0 and (k % tn.sub_resync == 0 or k <= tn.sub_resync_early) and k < min(todo):
                 _align_streams(self.streams)
             for i, gs in enumerate(self.streams):
                 if k < todo[i]:
@@ -350,7 +347,7 @@ class _DdimBranches:
                     cabi.check(rc, "graph_end")
                     self.graphs[key] = g
                 ex[i] = self.graphs[key]
-        pace = _Pace(self.streams)
+        pace = _Pace(self.streams, self.gd.tuning.sub_ahead)
         for k in range(max(todo)):
             for i, gs in enumerate(self.streams):
                 if k < todo[i]:
@@ -415,8 +412,10 @@ class GaussianDiffusion(nn.Module):
         self._mask_x_cfg_seen = None
         self._all_ones_forced = None              # dist.py: the all-ones decision of the GLOBAL batch for a shard's call
         # build-specific knobs (additive; defaults reproduce the reference's behaviour)
+        # every performance knob in one object (tuning.py): the denoiser's, or defaults + LD_* environment overrides
+        self.tuning = getattr(model, "tuning", None) or Tuning.from_env()
         self.noise_source = "device"
-        self.fuse_final_step = os.environ.get("LD_NO_FUSED_FINAL") is None
+        self.fuse_final_step = bool(self.tuning.fused_final_step)
         self.noise_seed = 10                      # torch.manual_seed(10), ddpm.py:934
         # first element of this object's samples inside each draw of the run's noise stream: a rank that owns
         # samples [lo, hi) of a sharded batch sets lo*C*H*W and then draws exactly the values the unsharded batch
@@ -424,8 +423,8 @@ class GaussianDiffusion(nn.Module):
         self.noise_offset = 0
         self.use_graph = False
         # concurrent sub-batches of the joint steps (see _SubBatches); 1 = one batch on the caller's stream
-        self.sub_batches = int(os.environ.get("LD_SUB_BATCHES", "2"))
-        self.min_sub_batch = int(os.environ.get("LD_MIN_SUB_BATCH", "2"))
+        self.sub_batches = int(self.tuning.sub_batches)
+        self.min_sub_batch = int(self.tuning.min_sub_batch)
         self.sub_cu_mask = None                   # experiments: "xcd" / "lo" / "even" CU-masked sub-batch streams (set before sampling)
         self._sched = None
         self._graphs = {}

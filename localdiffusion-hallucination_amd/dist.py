@@ -95,7 +95,8 @@ class LdComm:
         if world == 1:
             return cls(1, 0, cls.make_unique_id())
         if run_id is None:
-            run_id = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT")
+            from .tuning import rendezvous_run_id
+            run_id = rendezvous_run_id()
         if run_id is not None:
             id_file = f"{id_file}.{run_id}"
         if rank == 0:

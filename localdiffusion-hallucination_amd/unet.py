@@ -16,13 +16,13 @@ the plan computes the same function (fp32 mode agrees with the reference to ~1e-
 """
 import ctypes as C
 import math
-import os
 
 import numpy as np
 import torch
 from torch import nn
 
 from . import _cabi as cabi
+from .tuning import Tuning
 from .weights import UnetConfig, unet_param_shapes
 
 _TORCH_DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
@@ -47,7 +47,7 @@ class Unet(nn.Module):
                  learned_sinusoidal_cond=False, random_fourier_features=False,
                  learned_sinusoidal_dim=16, sinusoidal_pos_emb_theta=10000, attn_dim_head=32,
                  attn_heads=4, full_attn=(False, False, False, True), flash_attn=False, mode="mri",
-                 compute_dtype="fp32"):
+                 compute_dtype="fp32", tuning=None):
         super().__init__()
         if self_condition or learned_variance or learned_sinusoidal_cond or random_fourier_features:
             raise NotImplementedError("self_condition / learned_variance / learned sinusoidal embeddings "
@@ -90,10 +90,12 @@ class Unet(nn.Module):
         self._packed = None
         self._packed_key = None
         self._plans = {}
+        # every performance knob in one object (tuning.py); default: compiled-in defaults + LD_* environment overrides
+        self.tuning = tuning if tuning is not None else Tuning.from_env()
         # two-term convolution weights (W = hi + lo in 16-bit storage, twice the matrix work) for the layers of the
         # first N resolution levels (0 = off; 2 = the full- and half-resolution layers, which carry 90 % of what
         # rounding the weights costs a sampling chain: DESIGN section 2).  See set_weight_split_levels().
-        self.weight_split_levels = int(os.environ.get("LD_WEIGHT_SPLIT_LEVELS", "0"))
+        self.weight_split_levels = int(self.tuning.weight_split_levels)
         self._version = 0
 
     # ------------------------------------------------------------------ reference attributes
@@ -155,6 +157,7 @@ class Unet(nn.Module):
         if self._packed is not None and self._packed_key == key:
             return self._packed
         lib = cabi.lib()
+        self.tuning.apply_kernel_table(lib)
         st = torch.cuda.current_stream().cuda_stream
         dt, tdt = cabi.dtype_code(self.compute_dtype), _TORCH_DT[self.compute_dtype]
         sd = {k: v.detach().to(torch.float32).contiguous() for k, v in self.state_dict().items()}
@@ -291,12 +294,6 @@ class Unet(nn.Module):
         return p.model_out.clone()
 
 
-# block1's GroupNorm + FiLM + SiLU as a separate pass (instead of block2's prologue) on maps of at most this many pixels
-# with at least this many channels (tuning overrides LD_SEP_ACT_MAX_PX / LD_SEP_ACT_MIN_C; DESIGN finding 5, 68)
-_SEP_ACT_MAX_PX = int(os.environ.get("LD_SEP_ACT_MAX_PX", str(32 * 32)))
-_SEP_ACT_MIN_C = int(os.environ.get("LD_SEP_ACT_MIN_C", "128"))
-
-
 class _Plan:
     """Static buffers + the C-ABI call list of one denoiser evaluation at a fixed shape.
 
@@ -313,6 +310,7 @@ class _Plan:
         self.tdt = _TORCH_DT[net.compute_dtype]
         self.esize = 4 if self.dt == cabi.LD_F32 else 2
         self.P = net.packed()
+        self.tn = net.tuning
         self.f32 = self.P["f32"]
         cfg = net.cfg
         self.cfg = cfg
@@ -338,8 +336,7 @@ class _Plan:
         self.cond_feat = self._build_cond()
         self.named["cond_model"] = self.cond_feat
         self.fusion_const = None
-        if ("conv_fusion.block1.proj.weight#c" in self.P["w"] and not cfg.cond_early_exit
-                and not os.environ.get("LD_NO_FUSION_FOLD")):
+        if "conv_fusion.block1.proj.weight#c" in self.P["w"] and not cfg.cond_early_exit and self.tn.fusion_fold:
             c = self.cond_feat.shape[-1]
             hh, ww = self.cond_feat.shape[1], self.cond_feat.shape[2]
             p1 = self.conv3(self.ops_cond, [self.src(self.cond_feat, c)], "conv_fusion.block1.proj", c, hh, ww,
@@ -360,6 +357,17 @@ class _Plan:
             torch.cuda.current_stream().synchronize()
 
     # ------------------------------------------------------------------ helpers
+    def _kt(self, name):
+        """An entry of the library's launch-routing table (the plan's family labels follow the dispatcher's rule)."""
+        v = C.c_longlong()
+        cabi.check(self.lib.ld_tuning_get(name.encode(), C.byref(v)), "tuning_get")
+        return int(v.value)
+
+    def _separate_act(self, px, c):
+        """block1's GroupNorm + FiLM + SiLU as a separate pass (instead of block2's prologue): small, wide maps
+        (Tuning.separate_act / sep_act_max_px / sep_act_min_c; DESIGN findings 5, 68)."""
+        return self.tn.separate_act and px <= self.tn.sep_act_max_px and c >= self.tn.sep_act_min_c
+
     def buf(self, h, w, c):
         return torch.empty(self.B, h, w, c, dtype=self.tdt, device=self.dev)
 
@@ -424,8 +432,8 @@ class _Plan:
         fam = f"conv3x3<{dname},{4 if mt4 else 2},{4 if big else 2}>"
         ck = 16 if self.dt == cabi.LD_F32 else 32
         if (cout == 32 and len(srcs) == 1 and cin == ck and addend is None and h >= 32 and w >= 32 and h % 16 == 0
-                and w % 16 == 0 and (w // 16) * (h // 16) * self.B >= int(os.environ.get("LD_CONV_C32_MIN_TILES", "2048"))
-                and not os.environ.get("LD_CONV_NO_C32") and a.weight_terms != 2):
+                and w % 16 == 0 and (w // 16) * (h // 16) * self.B >= self._kt("conv_c32_min_tiles")
+                and self._kt("conv_c32") and a.weight_terms != 2):
             fam = f"conv3x3_c32<{dname}>"              # the persistent LDS-DMA kernel takes it (conv3x3_c32.hip)
         in_el = sum(s.C * (npx // 4 if s.upsample else npx) for s in srcs)
         self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname,
@@ -506,7 +514,7 @@ class _Plan:
         film = self.films.get(p)
         n1 = self.src(raw1, cout, gn=(s1, f[p + ".block1.norm.weight"], f[p + ".block1.norm.bias"], G),
                       act=cabi.ACT_SILU, film=film)
-        if h * w <= _SEP_ACT_MAX_PX and cout >= _SEP_ACT_MIN_C and not os.environ.get("LD_NO_SEPARATE_ACT"):
+        if self._separate_act(h * w, cout):
             # small, wide maps: the normalise+FiLM+SiLU prologue would be repeated by every cout-tile workgroup
             # (4x at 256 channels) on the critical path of one-workgroup-per-CU launches; a separate pass over
             # the (L2-resident) tensor measured cheaper (256->256@32^2: 45 -> 25 us + 9 us).  Everything else keeps
@@ -537,7 +545,7 @@ class _Plan:
                           weight=self.P["w"][p + ".block1.proj.weight#x"], bias=zero, addend=p1)
         n1 = self.src(raw1, c, gn=(s1, f[p + ".block1.norm.weight"], f[p + ".block1.norm.bias"], G),
                       act=cabi.ACT_SILU, film=self.films.get(p))
-        if h * w <= _SEP_ACT_MAX_PX and c >= _SEP_ACT_MIN_C and not os.environ.get("LD_NO_SEPARATE_ACT"):
+        if self._separate_act(h * w, c):
             n1 = self.src(self.gn_apply(ops, n1, None, h, w, c), c)
         raw2 = self.conv3(ops, [n1], p + ".block2.proj", c, h, w, stats=s2, groups=G)
         n2 = self.src(raw2, c, gn=(s2, f[p + ".block2.norm.weight"], f[p + ".block2.norm.bias"], G), act=cabi.ACT_SILU)
@@ -558,8 +566,7 @@ class _Plan:
         # (end of round 2: 512 instead of 1024 at 256^2 -- 128 partials per image, two workgroups per CU at 4 patches:
         # step -1.0 % on the same box, three alternating rounds)
         # ... at up to 8 patches per launch; 64 patches per GPU measured 0.8 % slower with it and keep 1024)
-        rule = os.environ.get("LD_LINATTN_CHUNK_PX", "512,256,128" if B <= 8 else "1024,256,128").split(",")   # n >= 65536, n >= 16384, smaller
-        rule = [int(v) for v in (rule * 3)[:3]]
+        rule = self.tn.chunk_rule(B)                      # n >= 65536, n >= 16384, smaller
         chunk_px = rule[0] if n >= 65536 else (rule[1] if n >= 16384 else rule[2])
         nchunks = max(1, min(128, n // chunk_px)) if heads == 4 else max(1, min(32, n // 256))
         ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, heads, 32, nchunks)), dtype=torch.float32, device=self.dev)

@@ -654,31 +654,36 @@ def _c32_probe(path):
 
 @pytest.mark.gpu
 def test_persistent_conv_geometries_agree(tmp_path):
-    """The C = 32 convolution has three code paths: the generic kernel (LD_CONV_NO_C32=1), the persistent ring kernel
-    (512 threads, 16 x 16 tiles; LD_CONV_C32_MIN_TILES=1 puts every eligible launch on it) and its 256-thread geometry
-    (LD_CONV_C32_LITE=1, DESIGN finding 66).  Same MFMA order in all three: outputs bit-equal, statistics equal up to
-    the length of their fp32 partial sums (a persistent workgroup keeps its sums in registers over all its tiles)."""
-    import subprocess
-    import sys
-    envs = {"generic": dict(LD_CONV_NO_C32="1"), "ring": dict(LD_CONV_C32_MIN_TILES="1"), "lite": dict(LD_CONV_C32_LITE="1")}
+    """The C = 32 convolution has two code paths: the generic kernel (tuning table: conv_c32 = 0) and the persistent ring
+    kernel (512 threads, 16 x 16 tiles; conv_c32_min_tiles = 1 puts every eligible launch on it).  Same MFMA order in
+    both: outputs bit-equal, statistics equal up to the length of their fp32 partial sums (a persistent workgroup keeps
+    its sums in registers over all its tiles).  The routing is switched through ld_tuning_set, the launch counters
+    confirm which kernel ran."""
+    from localdiffusion_hallucination_amd.tuning import kernel_table
+    lib = cabi.lib()
+    keep = kernel_table(lib)
     res = {}
-    for name, env in envs.items():
-        path = str(tmp_path / f"c32_{name}.npz")
-        code = (f"import sys; sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); "
-                f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); "
-                f"import test_hip_ops as t; t._c32_probe({path!r})")
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
-        res[name] = np.load(path)
+    try:
+        for name, sets in (("generic", {"conv_c32": 0}), ("ring", {"conv_c32": 1, "conv_c32_min_tiles": 1})):
+            for k, v in sets.items():
+                cabi.check(lib.ld_tuning_set(k.encode(), v), "tuning_set")
+            c0 = lib.ld_counter(cabi.COUNTER_CONV3X3_C32)
+            path = str(tmp_path / f"c32_{name}.npz")
+            _c32_probe(path)
+            ran = lib.ld_counter(cabi.COUNTER_CONV3X3_C32) - c0
+            assert (ran > 0) == (name == "ring"), (name, ran)
+            res[name] = np.load(path)
+    finally:
+        for k in ("conv_c32", "conv_c32_min_tiles"):
+            lib.ld_tuning_set(k.encode(), keep[k])
     assert len(res["generic"].files) == 2 * 2 * 2 * 2
     for k in res["generic"].files:
-        for other in ("ring", "lite"):
-            a, b = res["generic"][k], res[other][k]
-            assert np.isfinite(b).all(), (other, k)
-            if k.endswith("_stats"):
-                assert float(np.abs(a - b).max()) <= 2e-6 * float(np.abs(a).max()), (other, k, float(np.abs(a - b).max() / np.abs(a).max()))
-            else:
-                assert np.array_equal(a, b), (other, k, float(np.abs(a - b).max()))
+        a, b = res["generic"][k], res["ring"][k]
+        assert np.isfinite(b).all(), k
+        if k.endswith("_stats"):
+            assert float(np.abs(a - b).max()) <= 2e-6 * float(np.abs(a).max()), (k, float(np.abs(a - b).max() / np.abs(a).max()))
+        else:
+            assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
 
 
 @pytest.mark.gpu

@@ -374,16 +374,15 @@ def test_concurrent_sub_batches_match_the_single_batch(dtype, tol):
     check("4x2 " + dtype, run(gd, cond, None, 8), single, tol)
 
 
-def test_host_pacing_does_not_change_the_samples(monkeypatch):
-    """The host stays at most LD_SUB_AHEAD steps ahead of the sub-batch streams (DESIGN finding 64): pacing is host-side
+def test_host_pacing_does_not_change_the_samples():
+    """The host stays at most Tuning.sub_ahead steps ahead of the sub-batch streams (DESIGN finding 64): pacing is host-side
     only -- the same replays in the same order on each stream -- so every setting gives the same samples.  fp32: the only
     run-to-run freedom left is the order of the statistics atomics."""
-    from localdiffusion_hallucination_amd import diffusion as dm
     cond = torch.from_numpy(rng.uniform((8, 1, 32, 32), 8, 1, 0.0, 2.0))
     outs = []
     for ahead in (0, 1, 3):
-        monkeypatch.setattr(dm, "_AHEAD", ahead)
         gd = make(dict(mode="mri"), dict(data="mri"), 32, 12, dtype="fp32")
+        gd.tuning.sub_ahead = ahead
         gd.noise_source = "device"
         gd.sub_batches, gd.min_sub_batch = 2, 4
         outs.append(run(gd, cond, None, 8))
