@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
   uint4 qf = make_uint4(0u, 0u, 0u, 0u);
   if (qi < n) qf = *reinterpret_cast<const uint4*>(base + (size_t)qi * rowstride + h * D + kg * 8);
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-  float m = -1e30f, l = 0.f;
+  float m = -1e30f;
   // staging role: 4 consecutive lanes fetch the 64 contiguous bytes of one key's head slice (one line request per
   // key; with one lane per key every lane touched its own 128-B line for 16 bytes: 8x the L2->L1 traffic)
   const int skey = tid >> 2, schunk = tid & 3;
@@ -170,18 +170,20 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
     }
   };
   request(0);
-  for (int j0 = 0; j0 < n; j0 += TKV) {
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < NST; ++u) {
-      s_k[schunk][u * 64 + skey] = kk[u];
-      *reinterpret_cast<uint4*>(s_v + (u * 64 + skey) * VROW + schunk * 16) = vv[u];
-    }
-    __syncthreads();
-    if (j0 + TKV < n) request(j0 + TKV);
+  // The normaliser l = sum_j P_ij comes out of the matrix pipe: a third A tile of ONES beside the two V^T tiles makes
+  // every row of its product the column sum of P^T (of the P that is actually multiplied: the storage-rounded one, so
+  // the output is an exactly normalised average of V rows).  32 dependent v_add per 128 keys become 4 MFMAs on a pipe
+  // that is a quarter busy.
+  const unsigned one2 = pack2<T>(1.0f, 1.0f);
+  const uint4 ones = make_uint4(one2, one2, one2, one2);
+  f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
+  // One 128-key tile.  FULL: no key of the tile is past n (every tile at the model's sizes): the four instructions per
+  // score that masked such keys (index, compare, mask merge, select: 128 of the ~400 instructions of a tile) exist
+  // only in the ragged variant.
+  auto tile = [&](int j0, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
     f32x4 s[NKT];
     float mx = -1e30f;
-    const bool full = j0 + TKV <= n;                     // no key of this tile is past the end
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const uint4 kf = s_k[kg][kt * 16 + li];
@@ -189,28 +191,25 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
       mma16<T>(s[kt], kf, qf);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (!full && (j0 + kt * 16 + kg * 4 + r) >= n) s[kt][r] = -1e30f;
+        if constexpr (!FULL) {
+          if ((j0 + kt * 16 + kg * 4 + r) >= n) s[kt][r] = -1e30f;
+        }
         mx = fmaxf(mx, s[kt][r]);
       }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = kq4_max(mx);                                    // over the 4 kg lanes of the query (VALU exchanges, common.hip.h)
     const float mn = fmaxf(m, mx);
-    const float alpha = __expf(m - mn);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * 1.4426950408889634f);
     m = mn;
-    l *= alpha;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; lacc[r] *= alpha; }
     unsigned pk[NKT][2];
     const float mn2 = mn * 1.4426950408889634f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       float pv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], 1.4426950408889634f, -mn2));   // masked keys: exp2(-huge) = 0
-        l += pv[r];
-      }
+      for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], 1.4426950408889634f, -mn2));   // masked keys: exp2(-huge) = 0
       pk[kt][0] = pack2<T>(pv[0], pv[1]);
       pk[kt][1] = pack2<T>(pv[2], pv[3]);
     }
@@ -226,14 +225,25 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
         if (dt == 0) mma16<T>(o0, vf, pf);
         else mma16<T>(o1, vf, pf);
       }
+      mma16<T>(lacc, ones, pf);
     }
+  };
+  for (int j0 = 0; j0 < n; j0 += TKV) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      s_k[schunk][u * 64 + skey] = kk[u];
+      *reinterpret_cast<uint4*>(s_v + (u * 64 + skey) * VROW + schunk * 16) = vv[u];
+    }
+    __syncthreads();
+    if (j0 + TKV < n) request(j0 + TKV);
+    if (j0 + TKV <= n) tile(j0, std::true_type{});
+    else tile(j0, std::false_type{});
   }
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
   {
     // the head's two 16-channel halves leave as ONE 16-byte store per lane (pair_frag16: the exchange runs on every
     // lane, only the store is predicated)
-    const float inv = 1.0f / l;
+    const float inv = 1.0f / lacc[0];
     char* op = reinterpret_cast<char*>(out + ((size_t)b * n + (qi < n ? qi : 0)) * hidden + h * D);
     float r0[4] = {o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv};
     float r1[4] = {o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};

@@ -403,6 +403,26 @@ __device__ __forceinline__ float wave16_sum(float v) {
   return v;
 }
 
+// Reductions over the 4 lanes that hold one pixel's K-slices / channel quarters (lane & 15 equal, 16 lanes apart): the
+// fragment layouts keep a pixel's (or a query's) partial sums there.  v_permlane16_swap / v_permlane32_swap of a value
+// with itself leave (row 0 | row 0 | row 2 | row 2) and (row 1 | row 1 | row 3 | row 3), resp. (lower | lower) and
+// (upper | upper), in the two results: two VALU exchanges + two ops, where __shfl_xor(x, 16) / (x, 32) are two dependent
+// trips through the LDS crossbar (ds_bpermute, ~120 cycles each behind an s_waitcnt).  Every lane ends with the
+// reduction; the operand order of each lane's two additions is that of the shuffle form (bit-identical sums).
+// Whole wave active.
+__device__ __forceinline__ float kq4_sum(float x) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float kq4_max(float x) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // fp64 value of another lane of the same 16-lane row (DPP on the two halves: VALU speed, no LDS crossbar)
 template <int CTRL> __device__ __forceinline__ double dpp_mov_d(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);

@@ -229,8 +229,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 #pragma unroll
     for (int it = 0; it < NW; ++it) {
       float r = rs[it];
-      r += __shfl_xor(r, 16);
-      r += __shfl_xor(r, 32);
+      r = kq4_sum(r);
       if (kq == 0) s_rinv[(it * 4 + wv) * 16 + px] = rms_rinv<DT<T>::precise>(r);
     }
     __syncthreads();
@@ -300,8 +299,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
         float mx = v[m][0];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { mx = fmaxf(mx, v[m][r]); mx = fmaxf(mx, v[m + 1][r]); }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = kq4_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -309,8 +307,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
           v[m + 1][r] = DT<T>::precise ? expf(v[m + 1][r] - mx) : __expf(v[m + 1][r] - mx);
           sum += v[m][r] + v[m + 1][r];
         }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = kq4_sum(sum);
         const float sc = DT<T>::precise ? a.q_scale / sum : a.q_scale * __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[m][r] *= sc; v[m + 1][r] *= sc; }
@@ -326,8 +323,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ss = fmaf(v[m][r], v[m][r], ss);
-      ss += __shfl_xor(ss, 16);
-      ss += __shfl_xor(ss, 32);
+      ss = kq4_sum(ss);
       const float inv = rms_rinv<DT<T>::precise>(ss);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {

@@ -99,8 +99,7 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         float r = rs[it];
-        r += __shfl_xor(r, 16);
-        r += __shfl_xor(r, 32);
+        r = kq4_sum(r);
         if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = rms_rinv<false>(r);
       }
       __syncthreads();
@@ -228,6 +227,9 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
   for (int c = 0; c < NCW; ++c)
 #pragma unroll
     for (int m = 0; m < 4; ++m) A[m][c] = a.wkv[(((size_t)h * NCW + c) * 4 + m) * 64 + lane];
+  // (Z_d = sum_n P_nd stays an fp32 sum of the UNROUNDED weights: taking it from the matrix pipe -- a B tile of ones in
+  //  the context product -- was measured in round 4: no step time, and the fp16 context moved from 4e-3 to 6e-3 of its
+  //  range against the oracle)
   float cmax[2][4], mloc[2][4], zs[2][4];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -290,8 +292,7 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         float r = rs[it];
-        r += __shfl_xor(r, 16);
-        r += __shfl_xor(r, 32);
+        r = kq4_sum(r);
         if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = rms_rinv<false>(r);
       }
       __syncthreads();
@@ -475,8 +476,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
 #pragma unroll
   for (int it = 0; it < NW; ++it) {
     float r = rs[it];
-    r += __shfl_xor(r, 16);
-    r += __shfl_xor(r, 32);
+    r = kq4_sum(r);
     if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = rms_rinv<false>(r);
   }
   __syncthreads();
@@ -499,26 +499,22 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
 #pragma unroll
     for (int hh = 0; hh < 4; ++hh) {                    // one head = channel tiles 2hh, 2hh+1
       float v0[4], v1[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { v0[r] = q[2 * hh][r] * rinv2; v1[r] = q[2 * hh + 1][r] * rinv2; }
       float mx;
       if (a.qshift) {
         mx = qs2[hh];                                   // data-independent bound (see ld_linattn_out)
       } else {
         mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fmaxf(v0[r], v1[r]));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fmaxf(q[2 * hh][r], q[2 * hh + 1][r]) * rinv2);   // rinv2 > 0
+        mx = kq4_max(mx);
       }
       float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v0[r] = __builtin_amdgcn_exp2f(v0[r] - mx); v1[r] = __builtin_amdgcn_exp2f(v1[r] - mx);
+      for (int r = 0; r < 4; ++r) {                     // one fma + one v_exp per value (the file is built with -ffp-contract=off)
+        v0[r] = __builtin_amdgcn_exp2f(fmaf(q[2 * hh][r], rinv2, -mx)); v1[r] = __builtin_amdgcn_exp2f(fmaf(q[2 * hh + 1][r], rinv2, -mx));
         sum += v0[r] + v1[r];
       }
-      sum += __shfl_xor(sum, 16);
-      sum += __shfl_xor(sum, 32);
+      sum = kq4_sum(sum);
       const float sc = a.q_scale * __builtin_amdgcn_rcpf(sum);
       B2[hh] = make_uint4(pack2<T>(v0[0] * sc, v0[1] * sc), pack2<T>(v0[2] * sc, v0[3] * sc),
                           pack2<T>(v1[0] * sc, v1[1] * sc), pack2<T>(v1[2] * sc, v1[3] * sc));
@@ -540,8 +536,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) ss = fmaf(y[m2][r], y[m2][r], ss);
     }
-    ss += __shfl_xor(ss, 16);
-    ss += __shfl_xor(ss, 32);
+    ss = kq4_sum(ss);
     const float inv = rms_rinv<false>(ss);
     {
       // two adjacent m-tiles leave as ONE 16-byte store per lane (pair_frag16: the exchange runs on every lane, only

@@ -295,6 +295,7 @@ class _DdimBranches:
         cabi.check(lib.ld_ddim_step_at(sp.x_in.data_ptr(), sp.model_out.data_ptr(), zp, sp.x_in.data_ptr(), self.table.data_ptr(),
                                        self.idx[i].data_ptr(), lo, hi, cabi.OBJ[gd.objective], n, st), "ddim_step_at")
 
+    @torch.inference_mode()
     def run_timed(self, n_steps, acc, lo, hi, alone=False):
         """bench.py's per-kernel leg for the strided sampler: branch 0's denoiser evaluations run eagerly with HIP events
         around every launch (``acc``, see _Plan.run_main_timed) while branch 1 replays its captured step beside it
