@@ -421,6 +421,17 @@ int ld_fuse_ddim_k(const float* x_first, const float* x_rest, const float* x0_fi
 /* q_sample (ddpm.py:1148-1154) for the use_gt start (:937-944) */
 int ld_q_sample(const float* x0, const float* noise, float* out, float sqrt_ab, float sqrt_1mab,
                 int64_t n, void* stream);
+/* ---- training-side forward (forward half): GaussianDiffusion.forward / p_losses, ddpm.py:1147-1214 -----
+ * q_sample with one timestep per sample: out_b = sqrt_ab[t_b] x0_b + sqrt_1mab[t_b] noise_b  (t: int32 [B] on the
+ * device, sqrt_ab / sqrt_1mab: the fp32 schedule buffers [T] on the device). */
+int ld_q_sample_t(const float* x0, const float* noise, float* out, const int* t, const float* sqrt_ab,
+                  const float* sqrt_1mab, int B, int64_t elems_per_sample, void* stream);
+/* per-sample loss (:1186-1201): loss_out[b] = loss_weight[t_b] * mean_{c,h,w} (model_out - target)^2, target = noise
+ * (LD_OBJ_NOISE) | x_start (LD_OBJ_X0) | sqrt_ab[t_b] noise - sqrt_1mab[t_b] x_start (LD_OBJ_V, predict_v :643-647).
+ * fp32 NCHW operands, fp64 accumulation in a fixed order; the batch mean (:1201) is the caller's. */
+int ld_p_losses(const float* model_out, const float* x_start, const float* noise, const int* t, const float* sqrt_ab,
+                const float* sqrt_1mab, const float* loss_weight, float* loss_out, int B, int64_t elems_per_sample,
+                int objective, void* stream);
 /* recomposition of K gathered local patches by their masks (north-star multi-GPU path,
  * SURVEY.md 8e): out[b] = sum_k patches[b,k]*m_k  with m_k = (masks[k] >= 1) */
 int ld_recompose(const float* patches /*[B,K,C,HW]*/, const float* masks /*[K,HW]*/, float* out,

@@ -121,6 +121,8 @@ _SIGS = {
     "ld_fuse_ddim_k": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, C.c_int, C.c_int,
                                  C.c_int, C.c_int, vp]),
     "ld_q_sample": (C.c_int, [vp, vp, vp, f32, f32, i64, vp]),
+    "ld_q_sample_t": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, i64, vp]),
+    "ld_p_losses": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, C.c_int, vp]),
     "ld_recompose": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_comm_unique_id": (C.c_int, [vp]),
     "ld_comm_init": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),

@@ -215,6 +215,42 @@ __global__ void fuse_ddim_k_kernel(const float* x_first, const float* x_rest, co
 __global__ void q_sample_kernel(const float* x0, const float* z, float* out, float sab, float s1mab, long n) {
   GRID_STRIDE(i, n) out[i] = sab * x0[i] + s1mab * z[i];
 }
+// q_sample with a timestep per sample (training-side forward, ddpm.py:1147-1154 with t [B]): grid.y = sample
+__global__ void q_sample_t_kernel(const float* x0, const float* z, float* out, const int* t, const float* sab, const float* s1mab,
+                                  long per) {
+  const int b = blockIdx.y;
+  const float a = sab[t[b]], c = s1mab[t[b]];
+  const long base = (long)b * per;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x)
+    out[base + i] = a * x0[base + i] + c * z[base + i];
+}
+// Per-sample training loss (ddpm.py:1186-1201): loss_b = loss_weight[t_b] * mean_{c,h,w} (model_out - target)^2 with the
+// target of the objective -- noise (pred_noise) | x_start (pred_x0) | sqrt_ab[t_b] noise - sqrt_1mab[t_b] x_start
+// (pred_v, :643-647).  One workgroup per sample; every thread sums its strided elements in fp64 and the workgroup
+// combines them in a fixed order: the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void p_losses_kernel(const float* mo, const float* x0, const float* z, const int* t,
+                                                       const float* sab, const float* s1mab, const float* lw, float* loss,
+                                                       long per, int objective) {
+  __shared__ double s_part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tb = t[b];
+  const float a = sab[tb], c = s1mab[tb];
+  const long base = (long)b * per;
+  double acc = 0.0;
+  for (long i = tid; i < per; i += 256) {
+    const float xs = x0[base + i], nz = z[base + i];
+    const float target = objective == LD_OBJ_NOISE ? nz : (objective == LD_OBJ_X0 ? xs : a * nz - c * xs);
+    const float d = mo[base + i] - target;
+    acc += (double)(d * d);
+  }
+  s_part[tid] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) s_part[tid] += s_part[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) loss[b] = (float)(s_part[0] / (double)per) * lw[tb];
+}
 __global__ void recompose_kernel(const float* patches, const float* masks, float* out, int K, int C, int HW, long n) {
   GRID_STRIDE(i, n) {                       // i over [B, C, HW]
     const long bc = i / HW, p = i - bc * HW, b = bc / C, c = bc - b * C;
@@ -456,6 +492,26 @@ extern "C" int ld_q_sample(const float* x0, const float* noise, float* out, floa
   LD_REQUIRE(x0 && noise && out && n > 0, "ld_q_sample: null pointer");
   LD_LAUNCH(q_sample_kernel, dim3(nblocks(n)), dim3(BS), 0, ST(stream), x0, noise, out, sqrt_ab, sqrt_1mab, (long)n);
   LD_LAUNCH_CHECK("q_sample");
+  return LD_OK;
+}
+extern "C" int ld_q_sample_t(const float* x0, const float* noise, float* out, const int* t, const float* sqrt_ab,
+                             const float* sqrt_1mab, int B, int64_t elems_per_sample, void* stream) {
+  LD_REQUIRE(x0 && noise && out && t && sqrt_ab && sqrt_1mab && B > 0 && elems_per_sample > 0, "ld_q_sample_t: bad args");
+  long bx = (elems_per_sample + BS - 1) / BS;
+  if (bx > 1024) bx = 1024;
+  LD_LAUNCH(q_sample_t_kernel, dim3((unsigned)bx, B), dim3(BS), 0, ST(stream), x0, noise, out, t, sqrt_ab, sqrt_1mab, (long)elems_per_sample);
+  LD_LAUNCH_CHECK("q_sample_t");
+  return LD_OK;
+}
+extern "C" int ld_p_losses(const float* model_out, const float* x_start, const float* noise, const int* t, const float* sqrt_ab,
+                           const float* sqrt_1mab, const float* loss_weight, float* loss_out, int B, int64_t elems_per_sample,
+                           int objective, void* stream) {
+  LD_REQUIRE(model_out && x_start && noise && t && sqrt_ab && sqrt_1mab && loss_weight && loss_out, "ld_p_losses: null pointer");
+  LD_REQUIRE(B > 0 && elems_per_sample > 0, "ld_p_losses: empty batch");
+  LD_REQUIRE(objective == LD_OBJ_X0 || objective == LD_OBJ_NOISE || objective == LD_OBJ_V, "ld_p_losses: objective %d", objective);
+  LD_LAUNCH(p_losses_kernel, dim3(B), dim3(256), 0, ST(stream), model_out, x_start, noise, t, sqrt_ab, sqrt_1mab, loss_weight, loss_out,
+            (long)elems_per_sample, objective);
+  LD_LAUNCH_CHECK("p_losses");
   return LD_OK;
 }
 extern "C" int ld_recompose(const float* patches, const float* masks, float* out, int B, int K, int C, int HW,

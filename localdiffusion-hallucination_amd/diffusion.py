@@ -373,8 +373,8 @@ class GaussianDiffusion(nn.Module):
         assert not (type(self) == GaussianDiffusion and model.channels != model.out_dim)
         assert not model.random_or_learned_sinusoidal_cond
         assert objective in {"pred_noise", "pred_x0", "pred_v"}
-        if auto_normalize:
-            raise NotImplementedError("auto_normalize=True is never used by the reference's callers (test.py:138)")
+        # ddpm.py:619-620: [0,1] images <-> the sampler's [-1,1] range (off for every caller of the reference, test.py:138)
+        self.auto_normalize = bool(auto_normalize)
         self.config = config
         self.branch_out = bool(config["branch_out"])
         self.start_intermediate = bool(config["start_intermediate"])
@@ -563,9 +563,12 @@ class GaussianDiffusion(nn.Module):
                 self._mask_x_set(False)                    # ddpm.py:1114
             shape = (batch_size, self.channels, self.image_size, self.image_size)
             if self.is_ddim_sampling:
-                return self.ddim_sample(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps)
-            return self.p_sample_loop(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps,
-                                      return_all_outputs=return_all_outputs)
+                return self.unnormalize(self.ddim_sample(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps))
+            out = self.p_sample_loop(cond_img, mask, min_max_val, shape, return_all_timesteps=return_all_timesteps,
+                                     return_all_outputs=return_all_outputs)
+            if return_all_outputs:                         # (ret, x_start_lst, confidence_map), ddpm.py:972-974
+                return (self.unnormalize(out[0]),) + tuple(out[1:])
+            return self.unnormalize(out)
         finally:
             if decided_here:
                 self._all_ones_forced = None
@@ -589,6 +592,80 @@ class GaussianDiffusion(nn.Module):
                                     x0.data_ptr(), row.data_ptr(), None, float(min_max_val[0]),
                                     float(min_max_val[1]), cabi.OBJ[self.objective], x.numel(), st), "ddpm_step")
         return x_prev, x0
+
+    # ------------------------------------------------------------------ training-side forward (no gradient)
+    def normalize(self, x):
+        """ddpm.py:105-106, 619."""
+        return x * 2 - 1 if self.auto_normalize else x
+
+    def unnormalize(self, x):
+        """ddpm.py:108-109, 620; applied to what the loops return (:972, :1074).  A list result (DDIM branches that were
+        never fused) raises as the reference's ``(list + 1)`` does."""
+        if not self.auto_normalize:
+            return x
+        if isinstance(x, (list, tuple)):
+            raise TypeError("can only concatenate list (not \"int\") to list")      # what ddpm.py:109 raises on :1069's list
+        return (x + 1) * 0.5
+
+    @torch.inference_mode()
+    def q_sample(self, x_start, t, noise=None):
+        """ddpm.py:1147-1154 with a timestep per sample: ``t`` int64 [B].  ``noise`` None: the next draw of the run's
+        noise stream (``noise_source``)."""
+        x0 = x_start.to(self.device, torch.float32).contiguous()
+        if noise is None:
+            noise = torch.empty_like(x0)
+            self._train_draw = getattr(self, "_train_draw", -1) + 1
+            self._noise(noise, self._train_draw)
+        noise = noise.to(self.device, torch.float32).contiguous()
+        t32 = t.to(self.device, torch.int32).contiguous()
+        out = torch.empty_like(x0)
+        cabi.check(cabi.lib().ld_q_sample_t(x0.data_ptr(), noise.data_ptr(), out.data_ptr(), t32.data_ptr(),
+                                            self.sqrt_alphas_cumprod.data_ptr(), self.sqrt_one_minus_alphas_cumprod.data_ptr(),
+                                            x0.shape[0], x0[0].numel(), self._st()), "q_sample_t")
+        return out
+
+    @torch.inference_mode()
+    def p_losses(self, x_start, cond_img, t, noise=None, offset_noise_strength=None, per_sample=False):
+        """The training loss of one batch WITHOUT a backward pass (ddpm.py:1156-1201): q_sample at the per-sample
+        timesteps ``t``, one denoiser evaluation, the objective's target, the per-sample mean squared error times
+        ``loss_weight[t]``, the batch mean.  ``noise`` None: draws from the run's noise stream in the reference's order
+        (noise, then the [B,C] offset noise when its strength is positive, :1165-1167).  Returns the scalar loss
+        (and the per-sample losses with ``per_sample=True``).  Backward / optimiser are out of scope."""
+        assert not self.self_condition
+        lib, st, dev = cabi.lib(), self._st(), self.device
+        x0 = x_start.to(dev, torch.float32).contiguous()
+        B = x0.shape[0]
+        if noise is None:
+            noise = torch.empty_like(x0)
+            self._train_draw = getattr(self, "_train_draw", -1) + 1
+            self._noise(noise, self._train_draw)
+        noise = noise.to(dev, torch.float32).contiguous()
+        strength = self.offset_noise_strength if offset_noise_strength is None else offset_noise_strength
+        if strength > 0.0:
+            off = torch.empty(B, x0.shape[1], dtype=torch.float32, device=dev)
+            self._train_draw = getattr(self, "_train_draw", -1) + 1
+            self._noise(off, self._train_draw)
+            noise = (noise + strength * off[:, :, None, None]).contiguous()
+        x = self.q_sample(x0, t, noise)
+        model_out = self.model(x, cond_img.to(dev, torch.float32), t.to(dev, torch.long)).contiguous()
+        t32 = t.to(dev, torch.int32).contiguous()
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        cabi.check(lib.ld_p_losses(model_out.data_ptr(), x0.data_ptr(), noise.data_ptr(), t32.data_ptr(),
+                                   self.sqrt_alphas_cumprod.data_ptr(), self.sqrt_one_minus_alphas_cumprod.data_ptr(),
+                                   self.loss_weight.data_ptr(), loss.data_ptr(), B, x0[0].numel(), cabi.OBJ[self.objective], st),
+                   "p_losses")
+        total = loss.mean()
+        return (total, loss) if per_sample else total
+
+    def forward(self, img, cond_img, train, *args, **kwargs):
+        """ddpm.py:1203-1214: draws the timesteps with torch's generator as the reference does (``train=False`` re-seeds
+        it with 42 first; drawn on the host so that the values do not depend on the device), then ``p_losses``."""
+        b, c, h, w = img.shape
+        assert h == self.image_size and w == self.image_size, f"height and width of image must be {self.image_size}"
+        if not train:
+            torch.random.manual_seed(42)
+        t = torch.randint(0, self.num_timesteps, (b,)).long()
+        return self.p_losses(self.normalize(img), cond_img, t, *args, **kwargs)
 
     def _sync_model(self):
         """Captured HIP graphs and sub-batch runners hold raw pointers into the denoiser's plans and packed weights:

@@ -141,6 +141,32 @@ class RefSampler:
     def _tvec(self, b, t):
         return torch.full((b,), t, dtype=torch.long)
 
+    # --- training-side forward (ddpm.py:1147-1214): the loss of one batch, no gradient ---
+    def _ext(self, name, t, x):
+        """extract(buffer, t, x.shape), ddpm.py:455-458: per-sample scalars broadcast over [B,C,H,W]."""
+        return self.buf[name][t].reshape(-1, *([1] * (x.dim() - 1)))
+
+    def q_sample(self, x_start, t, noise):
+        """ddpm.py:1147-1154."""
+        return self._ext("sqrt_alphas_cumprod", t, x_start) * x_start + self._ext("sqrt_one_minus_alphas_cumprod", t, x_start) * noise
+
+    def predict_v(self, x_start, t, noise):
+        """ddpm.py:643-647."""
+        return self._ext("sqrt_alphas_cumprod", t, x_start) * noise - self._ext("sqrt_one_minus_alphas_cumprod", t, x_start) * x_start
+
+    def p_losses(self, x_start, cond, t, noise, offset_noise=None, offset_noise_strength=0.0):
+        """ddpm.py:1156-1201 (self_condition is never enabled by the reference's callers).  ``t`` int64 [B], ``noise`` like
+        x_start, ``offset_noise`` [B,C] (drawn after ``noise`` when the strength is positive, :1165-1167)."""
+        if offset_noise_strength > 0.0:
+            noise = noise + offset_noise_strength * offset_noise[:, :, None, None]
+        x = self.q_sample(x_start, t, noise)
+        out = self.f(x, cond, t)
+        obj = self.o.objective
+        target = noise if obj == "pred_noise" else (x_start if obj == "pred_x0" else self.predict_v(x_start, t, noise))
+        loss = ((out - target) ** 2).reshape(out.shape[0], -1).mean(dim=1)            # F.mse_loss(reduction='none') + reduce 'b ... -> b'
+        loss = loss * self.buf["loss_weight"][t]
+        return loss.mean(), loss
+
     # --- one model evaluation, single branch (ddpm.py:715-761 non-branch arm) ---
     def predict_single(self, x, cond, t, lohi, clip):
         out = self.f(x, cond, self._tvec(x.shape[0], t))

@@ -677,3 +677,46 @@ def test_eval_driver_matches_cfg1_golden(golden, tmp_path):
     assert abs(res["test_loss"] - float(np.mean((g["final"] - g["hr"]) ** 2))) < 1e-4
     for f in ("hr_all.npy", "lr_all.npy", "pred_all.npy", "ad_masks.npy"):
         assert (tmp_path / f).exists()
+
+
+@pytest.mark.parametrize("tag,kw,H,B", [("mnist28", MNIST, 28, 4), ("mri32", dict(mode="mri"), 32, 2)])
+def test_training_forward_losses_match_the_reference(golden, tag, kw, H, B):
+    """SURVEY 8f-4, forward half: GaussianDiffusion.forward(img, cond, train=False) and p_losses (explicit timesteps,
+    offset noise 0.1) on the HIP path -- ld_q_sample_t, one denoiser evaluation with per-sample timesteps, ld_p_losses --
+    against golden G15 from the real reference (ddpm.py:1156-1214), three objectives, fp32 storage; and the loss in
+    16-bit storage within the one-forward bounds."""
+    g = golden("g15_p_losses")
+    x0, cond = torch.from_numpy(g[tag + "_x0"]), torch.from_numpy(g[tag + "_cond"])
+    for obj in ("pred_x0", "pred_noise", "pred_v"):
+        gd = make(kw, dict(data="mnist" if tag.startswith("mnist") else "mri"), H, 100, objective=obj)
+        loss = float(gd(x0.cuda(), cond.cuda(), False))
+        ref = float(g[f"{tag}_{obj}_loss_fwd"])
+        print(f"G15 {tag} {obj}: forward loss {loss:.6e} (reference {ref:.6e})")
+        assert abs(loss - ref) <= 1e-4 * max(1.0, abs(ref)), (obj, loss, ref)
+        gd2 = make(kw, dict(data="mnist" if tag.startswith("mnist") else "mri"), H, 100, objective=obj)
+        tot, per = gd2.p_losses(x0.cuda(), cond.cuda(), torch.from_numpy(g[f"{tag}_{obj}_t_exp"]), offset_noise_strength=0.1, per_sample=True)
+        ref = float(g[f"{tag}_{obj}_loss_exp"])
+        assert abs(float(tot) - ref) <= 1e-4 * max(1.0, abs(ref)), (obj, float(tot), ref)
+        assert np.allclose(per.cpu().numpy(), g[f"{tag}_{obj}_per_exp"], rtol=2e-4, atol=1e-6)
+        for dtype, tol in (("bf16", 5e-2), ("fp16", 8e-3)):
+            gd3 = make(kw, dict(data="mnist" if tag.startswith("mnist") else "mri"), H, 100, objective=obj, dtype=dtype)
+            l16 = float(gd3(x0.cuda(), cond.cuda(), False))
+            assert abs(l16 - float(g[f"{tag}_{obj}_loss_fwd"])) <= tol * max(1.0, abs(float(g[f"{tag}_{obj}_loss_fwd"]))), (obj, dtype, l16)
+
+
+def test_auto_normalize_maps_the_result_to_zero_one():
+    """auto_normalize=True (ddpm.py:105-110, 619-620, 972, 1074, 1213; no caller of the reference turns it on): the loops'
+    result passes through unnormalize = (x + 1) / 2 and forward() normalises its image with 2x - 1 before q_sample."""
+    H, B, T = 28, 2, 6
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 44, 1, 0.0, 2.0))
+    plain = make(MNIST, dict(data="mnist"), H, T)
+    auto = make(MNIST, dict(data="mnist"), H, T)
+    auto.auto_normalize = True
+    a, b = run(plain, cond, None, B), run(auto, cond, None, B)
+    assert np.array_equal(b, (a + 1) * 0.5)
+    x0 = torch.from_numpy(rng.uniform((B, 1, H, H), 44, 2, 0.0, 1.0))
+    t = torch.tensor([1, 4])
+    l_auto = float(auto.p_losses(auto.normalize(x0.cuda()), cond.cuda(), t))
+    auto2 = make(MNIST, dict(data="mnist"), H, T)
+    l_plain = float(auto2.p_losses((x0 * 2 - 1).cuda(), cond.cuda(), t))
+    assert l_auto == l_plain

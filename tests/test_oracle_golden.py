@@ -313,3 +313,26 @@ def test_consecutive_calls_carry_mask_x_like_the_reference(golden, tag, kw, S, s
         with torch.no_grad():
             out = smp.sample(cond, masks[m], (0.0, 2.0), 2, Noise(10)).numpy()
         np.testing.assert_allclose(out, g[f"{tag}_call{i + 1}"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("tag,cfg,H,B", [("mnist28", CFG_MNIST, 28, 4), ("mri32", CFG_MRI, 32, 2)])
+def test_training_forward_losses(golden, tag, cfg, H, B):
+    """G15 (from the real reference): GaussianDiffusion.forward(train=False) and p_losses with explicit timesteps and
+    offset noise, three objectives (ddpm.py:1156-1214).  The oracle's restatement on the fixture's draws."""
+    g = golden("g15_p_losses")
+    sd = {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(cfg, 0).items()}
+    x0, cond = torch.from_numpy(g[tag + "_x0"]), torch.from_numpy(g[tag + "_cond"])
+    for obj in ("pred_x0", "pred_noise", "pred_v"):
+        smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd, cfg), diffusion_ref.SamplerOptions(timesteps=100, objective=obj), 1, H)
+        n0 = torch.from_numpy(rng.randn((B, 1, H, H), 10, 0))
+        off = torch.from_numpy(rng.randn((B, 1), 10, 1))
+        with torch.no_grad():
+            l1, p1 = smp.p_losses(x0, cond, torch.from_numpy(g[f"{tag}_{obj}_t_fwd"]), n0)
+            l2, p2 = smp.p_losses(x0, cond, torch.from_numpy(g[f"{tag}_{obj}_t_exp"]), n0, offset_noise=off, offset_noise_strength=0.1)
+        for got, per, key in ((l1, p1, "fwd"), (l2, p2, "exp")):
+            ref = float(g[f"{tag}_{obj}_loss_{key}"])
+            assert abs(float(got) - ref) <= 2e-5 * max(1.0, abs(ref)), (obj, key, float(got), ref)
+            assert np.allclose(per.numpy(), g[f"{tag}_{obj}_per_{key}"], rtol=2e-5, atol=1e-6)
+    # the timesteps of forward(train=False): torch's generator seeded with 42 (ddpm.py:1210-1211), drawn on the host
+    torch.random.manual_seed(42)
+    assert torch.randint(0, 100, (B,)).tolist() == g[f"{tag}_pred_x0_t_fwd"].tolist()

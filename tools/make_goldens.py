@@ -772,6 +772,52 @@ def g14(ddpm):
     save("g14_consecutive_calls", **out)
 
 
+def g15(ddpm):
+    print("G15 training-side forward: GaussianDiffusion.forward / p_losses (ddpm.py:1156-1214), three objectives")
+    out = {}
+    for tag, cfg, H, B in (("mnist28", CFG_MNIST, 28, 4), ("mri32", CFG_MRI, 32, 2)):
+        sd = sd_torch(cfg)
+        x0 = torch.from_numpy(rng.uniform((B, 1, H, H), 15, 1, 0.0, 2.0))
+        cond = torch.from_numpy(rng.uniform((B, 1, H, H), 15, 2, 0.0, 2.0))
+        out[tag + "_x0"], out[tag + "_cond"] = to_np(x0), to_np(cond)
+        for obj in ("pred_x0", "pred_noise", "pred_v"):
+            T = 100
+            ref_model = build_reference_unet(ddpm, cfg, sd)
+            gd = _ref_diffusion(ddpm, base_config(data="mnist" if cfg is CFG_MNIST else "mri"), ref_model, H, T, "sigmoid", obj, None).eval()
+            # (a) forward(img, cond, train=False): the reference seeds torch's generator with 42 and draws t with torch.randint
+            noise = PortableNoise(10)
+            with reference_run(noise):
+                with torch.inference_mode():
+                    loss_fwd = gd(x0.clone(), cond.clone(), False)
+            torch.random.manual_seed(42)
+            t_fwd = torch.randint(0, T, (B,)).long()
+            # (b) p_losses with explicit timesteps (first / middle / last) and offset noise
+            t_exp = torch.tensor(([0, T // 2, T - 1, 7] * B)[:B])
+            noise = PortableNoise(10)
+            with reference_run(noise):
+                with torch.inference_mode():
+                    loss_exp = gd.p_losses(x0.clone(), cond.clone(), t_exp, offset_noise_strength=0.1)
+            # oracle restatement on the same draws
+            o = opts_from(base_config(), T, None, obj)
+            smp = diffusion_ref.RefSampler(diffusion_ref.make_model_fn(sd, cfg), o, 1, H)
+            pn = PortableNoise(10)
+            with torch.no_grad():
+                o_fwd, per_fwd = smp.p_losses(x0, cond, t_fwd, pn.randn_like(x0))
+                pn = PortableNoise(10)
+                n1 = pn.randn_like(x0)
+                off = pn.randn(B, 1)
+                o_exp, per_exp = smp.p_losses(x0, cond, t_exp, n1, offset_noise=off, offset_noise_strength=0.1)
+            d1, d2 = abs(float(loss_fwd) - float(o_fwd)), abs(float(loss_exp) - float(o_exp))
+            print(f"  {tag} {obj}: forward loss {float(loss_fwd):.6e} (t = {t_fwd.tolist()}), p_losses {float(loss_exp):.6e}; "
+                  f"oracle-vs-reference {d1:.3e} / {d2:.3e}")
+            assert d1 <= 1e-6 * max(1.0, abs(float(loss_fwd))) and d2 <= 1e-6 * max(1.0, abs(float(loss_exp)))
+            out[f"{tag}_{obj}_t_fwd"], out[f"{tag}_{obj}_loss_fwd"] = t_fwd.numpy(), np.float32(float(loss_fwd))
+            out[f"{tag}_{obj}_per_fwd"] = to_np(per_fwd)
+            out[f"{tag}_{obj}_t_exp"], out[f"{tag}_{obj}_loss_exp"] = t_exp.numpy(), np.float32(float(loss_exp))
+            out[f"{tag}_{obj}_per_exp"] = to_np(per_exp)
+    save("g15_p_losses", **out)
+
+
 def g0_inventory(ddpm):
     print("G0 parameter inventory")
     lines = []
@@ -794,7 +840,7 @@ def main():
     ddpm = import_reference()
     os.makedirs(GOLD, exist_ok=True)
     todo = [("G0", g0_inventory), ("G1", g1), ("G2", g2), ("G3", g3), ("G4", g4), ("G6", g6),
-            ("G7", g7), ("G8", g8), ("G9", g9), ("G10", g10), ("G12", g12), ("G14", g14), ("G5", g5), ("G11", g11), ("G13", g13)]
+            ("G7", g7), ("G8", g8), ("G9", g9), ("G10", g10), ("G12", g12), ("G14", g14), ("G15", g15), ("G5", g5), ("G11", g11), ("G13", g13)]
     only = set(filter(None, a.only.split(",")))
     for name, fn in todo:
         if only and name not in only:
