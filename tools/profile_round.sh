@@ -4,6 +4,7 @@
 #   2. the same with LD_SUB_BATCHES=1 (one batch, one stream: the regime `roofline.frac` prices)  -> <tag>_s1_bench.json
 #   3. rocprofv3 --kernel-trace --stats of both commands (fewer steps)    -> <tag>_kernel_stats.csv, <tag>_s1_kernel_stats.csv
 #   4. separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of the solo regime -> <tag>_s1_pmc_traffic.json / _pmc_summary.txt
+#   5. the same passes in the default regime -> <tag>_pmc_traffic.json / _pmc_summary.txt;  6. cfg5 bench line + kernel trace
 # rocprofv3's interception slows the graph launches of the two-sub-batch regime (its kernels then overlap less than
 # un-profiled); the single-stream eager run is hardly perturbed, which is why the roofline numbers are tied to it.
 TAG=${1:-rXX}
@@ -25,6 +26,18 @@ cp $(find /tmp/prof_ks1 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_s1_kern
 LD_SUB_BATCHES=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_pf.log 2>&1 < /dev/null
 LD_SUB_BATCHES=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_pw.log 2>&1 < /dev/null
 python3 $R/tools/pmc_summarize.py /tmp/prof_f /tmp/prof_w $OUT/${TAG}_s1_pmc_traffic.json $OUT/${TAG}_s1_bench.json > $OUT/${TAG}_s1_pmc_summary.txt 2>&1
+# 5. the same two --pmc passes in the DEFAULT regime (two concurrent sub-batches of 4: what `roofline.frac` prices and
+#    `roofline.traffic` quotes; per launch of 4 patches)               -> <tag>_pmc_traffic.json / _pmc_summary.txt
+rm -rf /tmp/prof_f2 /tmp/prof_w2
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f2 -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_pf2.log 2>&1 < /dev/null
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w2 -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_pw2.log 2>&1 < /dev/null
+python3 $R/tools/pmc_summarize.py /tmp/prof_f2 /tmp/prof_w2 $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_bench.json > $OUT/${TAG}_pmc_summary.txt 2>&1
+# 6. cfg5 (512^2, DDIM 50, branch + fusion, fp16): bench line with its roofline block + kernel trace
+python3 $R/bench.py --workload cfg5 --no-cpu-baseline > $OUT/${TAG}_cfg5_bench.log 2>&1 < /dev/null
+tail -1 $OUT/${TAG}_cfg5_bench.log > $OUT/${TAG}_cfg5_bench.json
+rm -rf /tmp/prof_k5
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k5 -o r -- python3 $R/bench.py --workload cfg5 --steps 100 --no-cpu-baseline --no-roofline > $OUT/${TAG}_cfg5_ks.log 2>&1 < /dev/null
+cp $(find /tmp/prof_k5 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_cfg5_kernel_stats.csv
 cut -c1-200 $OUT/${TAG}_bench.json
 head -14 $OUT/${TAG}_s1_kernel_stats.csv | cut -c1-150
 tail -15 $OUT/${TAG}_s1_pmc_summary.txt
