@@ -123,18 +123,14 @@ class _SubBatches:
         for m in self.masks.values():
             m.copy_(mask.reshape(m.shape))
 
-    def _step(self, i, st, lo, hi, base, part=None):
-        """One reverse step of sub-batch i.  ``part``: "head" / "tail" = the launches in front of / from conv_fusion on
-        (see _Plan.run_main): the two halves a sample's FIRST step is replayed as, around the wait for its encoder."""
+    def _step(self, i, st, lo, hi, base):
         gd, sp = self.gd, self.plans[i]
         lib = cabi.lib()
         xa, wf, bf = sp.final
         B_, C_, H_, W_ = sp.model_out.shape
         # the step counter moves at the HEAD of the step (inside ld_step_begin): callers park it one above the step
         # they want to run next
-        sp.run_main(st, skip_final=True, step_delta=-1, part=part)
-        if part == "head":
-            return
+        sp.run_main(st, skip_final=True, step_delta=-1)
         cabi.check(lib.ld_final_step_at(xa.data_ptr(), wf.data_ptr(), bf.data_ptr(), sp.model_out.data_ptr(),
                                         sp.x_in.data_ptr(), None, gd._sched_table().data_ptr(), sp.t_dev.data_ptr(),
                                         lo, hi, cabi.OBJ[gd.objective], gd.noise_seed, base, -1,
@@ -156,16 +152,14 @@ class _SubBatches:
             self._step(i, st, lo, hi, base)
             ran = 1
         gs.synchronize()
-        parts = (None, "head", "tail") if self.gd.tuning.overlap_encoder else (None,)
-        for part in parts:
-            cabi.check(lib.ld_graph_begin(st), "graph_begin")
-            try:
-                self._step(i, st, lo, hi, base, part=part)   # recorded, not run: the step counter stays put
-            finally:
-                g = C.c_void_p()
-                rc = lib.ld_graph_end(st, C.byref(g))
-            cabi.check(rc, "graph_end")
-            self.graphs[key if part is None else key + (part,)] = g
+        cabi.check(lib.ld_graph_begin(st), "graph_begin")
+        try:
+            self._step(i, st, lo, hi, base)          # recorded, not run: the step counter stays put
+        finally:
+            g = C.c_void_p()
+            rc = lib.ld_graph_end(st, C.byref(g))
+        cabi.check(rc, "graph_end")
+        self.graphs[key] = g
         return ran
 
     def _trim(self, lo, hi, base):
@@ -186,38 +180,17 @@ class _SubBatches:
         recond = self.cond_seen != getattr(jp, "cond_version", 0)
         self.cond_seen = getattr(jp, "cond_version", 0)
         todo, ex = [n_steps] * self.S, [None] * self.S
-        # A sample's encoder beside its first step (Tuning.overlap_encoder): the conditioning features are first read at
-        # conv_fusion, half a step in, so the first step is replayed as two graphs -- the launches in front of
-        # conv_fusion, then, behind an event the encoder stream records, the rest -- while the encoders of all sub-batches
-        # run on ONE extra stream (0.3 ms per sample that sat in front of step 0: finding 73).  Same kernels in the same
-        # per-stream order: bit-identical samples.  Needs the graphs of an earlier call (the first call captures them).
-        enc_done = [None] * self.S
-        es = None
         for i, (sp, gs) in enumerate(zip(self.plans, self.streams)):
             gs.wait_stream(cur)
             st = gs.cuda_stream
-            key = (i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)
             with torch.cuda.stream(gs):
                 sp.x_in.copy_(jp.x_in[i * b:(i + 1) * b])
                 if recond:                          # the parent's conditioning changed: encode this slice of it
                     sp.cond_in.copy_(jp.cond_in[i * b:(i + 1) * b])
-                    overlap = (self.gd.tuning.overlap_encoder and getattr(sp, "_cond_graph", None) is not None
-                               and key + ("head",) in self.graphs and n_steps >= 1)
-                    if overlap:
-                        if es is None:
-                            es = self.gd._encoder_stream()
-                        ready = torch.cuda.Event()
-                        ready.record(gs)            # this sub-batch's conditioning image is in place, its previous steps are done
-                        es.wait_event(ready)
-                        with torch.cuda.stream(es):
-                            sp.run_cond_replayed(es)
-                            enc_done[i] = torch.cuda.Event()
-                            enc_done[i].record(es)
-                    else:
-                        sp.run_cond_replayed(gs)    # one graph launch per sample (the first sample: eager + capture)
+                    sp.run_cond_replayed(gs)        # one graph launch per sample (the first sample: eager + capture)
                 sp.set_step(t_start + 1)
                 todo[i] -= self._ensure_graph(i, gs, lo, hi, base)
-                ex[i] = self.graphs[key]
+                ex[i] = self.graphs[(i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)]
         # interleave the launches so that neither hardware queue runs ahead of the other.  The sub-batches run fastest IN
         # PHASE (the same launch of every sub-batch on the chip at the same time: shared weight blocks in L2, launches
         # that end together; 1.56 ms per step against 1.62-1.67 half a step apart, DESIGN finding 44) and a phase, once
@@ -234,16 +207,8 @@ class _SubBatches:
                 _align_streams(self.streams)
             for i, gs in enumerate(self.streams):
                 if k < todo[i]:
-                    if k == 0 and enc_done[i] is not None:          # first step of a sample: head | wait for the encoder | tail
-                        key = (i, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)
-                        cabi.check(lib.ld_graph_launch(self.graphs[key + ("head",)], gs.cuda_stream), "graph_launch")
-                        gs.wait_event(enc_done[i])
-                        cabi.check(lib.ld_graph_launch(self.graphs[key + ("tail",)], gs.cuda_stream), "graph_launch")
-                    else:
-                        cabi.check(lib.ld_graph_launch(ex[i], gs.cuda_stream), "graph_launch")
+                    cabi.check(lib.ld_graph_launch(ex[i], gs.cuda_stream), "graph_launch")
             pace.step_enqueued()
-        if es is not None:
-            cur.wait_stream(es)
         lib.ld_range_pop()
         # host seconds spent enqueueing replays (includes back-pressure once the hardware queue is full)
         self.host_launch_s = getattr(self, "host_launch_s", 0.0) + time.perf_counter() - h0
@@ -734,12 +699,6 @@ class GaussianDiffusion(nn.Module):
         while len(self._side_streams) < S:
             self._side_streams.append(_masked_stream(len(self._side_streams), self.sub_cu_mask) or torch.cuda.Stream())
         return self._side_streams[:S]
-
-    def _encoder_stream(self):
-        """The one extra stream the sub-batch runners' encoders share when they run beside a sample's first step."""
-        if getattr(self, "_enc_stream", None) is None:
-            self._enc_stream = torch.cuda.Stream()
-        return self._enc_stream
 
     def timed_plan(self, jp):
         """The plan whose launches ``run_joint_steps(..., timers=acc)`` times: sub-batch 0 when the joint steps

@@ -24,7 +24,6 @@ class Tuning:
     sub_resync_early: int = 1            # ... and in front of each of the first steps
     sub_ahead: int = 2                   # the host enqueues at most this many replayed steps ahead of the GPU (0 = no limit)
     fused_final_step: bool = True        # final_conv + posterior update + noise draw as one launch
-    overlap_encoder: bool = True         # a sample's conditioning encoder runs beside its first step's down path (its features enter at conv_fusion)
     # ---- plan builder (unet.py)
     weight_split_levels: int = 0         # two-term (hi + lo) weights on the first N resolution levels (accuracy mode)
     separate_act: bool = True            # block1's GroupNorm + FiLM + SiLU as its own pass on small, wide maps
@@ -42,7 +41,7 @@ class Tuning:
         "LD_SUB_AHEAD": ("sub_ahead", int), "LD_WEIGHT_SPLIT_LEVELS": ("weight_split_levels", int),
         "LD_SEP_ACT_MAX_PX": ("sep_act_max_px", int), "LD_SEP_ACT_MIN_C": ("sep_act_min_c", int),
         "LD_NO_FUSED_FINAL": ("fused_final_step", lambda v: False), "LD_NO_SEPARATE_ACT": ("separate_act", lambda v: False),
-        "LD_NO_FUSION_FOLD": ("fusion_fold", lambda v: False), "LD_NO_OVERLAP_ENCODER": ("overlap_encoder", lambda v: False),
+        "LD_NO_FUSION_FOLD": ("fusion_fold", lambda v: False),
         "LD_LINATTN_CHUNK_PX": ("linattn_chunk_px", lambda v: tuple(int(x) for x in (v.split(",") * 3)[:3])),
     }
 

@@ -725,9 +725,6 @@ class _Plan:
         x = self.attention(ops, "mid_attn", x, c, h, w, True)
         x = self.resnet_block(ops, "mid_block2", lambda x=x, c=c: [self.src(x, c)], c, c, h, w, res_tensor=x)
         feat = self.cond_feat
-        # everything before this index is independent of the conditioning encoder's output (its features enter at
-        # conv_fusion, ddpm.py:434-436): a sample's first step can run that far beside the encoder (run_main(part=...))
-        self.first_cond_op = len(ops)
         if self.fusion_const is not None:
             x = self.fusion_block_folded(ops, x, c, h, w)
         else:
@@ -811,25 +808,19 @@ class _Plan:
         finally:
             self.lib.ld_range_pop()
 
-    def run_main(self, st, skip_final=False, step_delta=0, idx_ptr=None, t_table=None, part=None):
+    def run_main(self, st, skip_final=False, step_delta=0, idx_ptr=None, t_table=None):
         """One denoiser evaluation.  ``skip_final``: stop before final_conv (the caller runs ld_final_step).
         ``step_delta``: added to the device step counter by the evaluation's first launch (ld_step_begin zeroes the
         statistics slots this plan uses, the k-max arena if the unfused linear attention is on the plan, and moves
-        the counter -- one launch where two memsets and ld_step_add were three).  ``part``: "head" = ld_step_begin and
-        the launches in front of conv_fusion (independent of the conditioning features), "tail" = the rest; None = all."""
+        the counter -- one launch where two memsets and ld_step_add were three)."""
         self.lib.ld_range_push(b"step")            # roctx: host-side issue of one denoiser evaluation (or its capture)
         try:
-            if part != "tail":
-                if idx_ptr is not None:            # strided sampling: t_dev = t_table[++idx] (ld_step_begin)
-                    cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr, 0, idx_ptr, t_table, st), "step_begin")
-                else:
-                    cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr if step_delta else None, int(step_delta),
-                                                      None, None, st), "step_begin")
+            if idx_ptr is not None:                # strided sampling: t_dev = t_table[++idx] (ld_step_begin)
+                cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr, 0, idx_ptr, t_table, st), "step_begin")
+            else:
+                cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr if step_delta else None, int(step_delta),
+                                                  None, None, st), "step_begin")
             ops = self.ops_main[:-1] if skip_final else self.ops_main
-            if part == "head":
-                ops = self.ops_main[:self.first_cond_op]
-            elif part == "tail":
-                ops = ops[self.first_cond_op:]
             for op in ops:
                 op(st)
         finally:
