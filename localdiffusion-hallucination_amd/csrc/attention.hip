@@ -124,8 +124,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 // LDS: K as [kgrp][key][16 B] planes (conflict-free b128 reads), V as 96-byte rows (64 B data +
 // 32 B pad: the 8 rows a half-wave's transposed read touches land on 8 disjoint bank octets).
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-constexpr int TKV = 128;                // keys per tile: one barrier pair, one max/sum shuffle pair per 128 keys
-constexpr int VROW = 96;
+constexpr int VROW = 96;                 // (TKV = keys per tile, a template parameter: one barrier pair, one row maximum and one rescale per tile)
 
 __device__ __forceinline__ uint2 tr_read(const char* p) {
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -133,7 +132,7 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T>
+template <typename T, int TKV>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                              int n, int heads) {
   constexpr int NKT = TKV / 16, NST = TKV / 64;          // 16-key MFMA tiles per tile; staging rows per thread
@@ -263,7 +262,9 @@ extern "C" int ld_attention(const void* qkv, void* out, int B, int n, int heads,
     LD_LAUNCH(attention_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, (float*)out, n, heads);
   else if (ld_dtype_16(dtype))
     LD_DISPATCH16(dtype, [&] {
-      LD_LAUNCH(attention_mfma_kernel<T>, grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n, heads);
+      // long sequences (cfg5: n = 4,096): 256-key tiles halve the barriers, row reductions and rescales per key
+      if (n >= 2048) LD_LAUNCH((attention_mfma_kernel<T, 256>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n, heads);
+      else LD_LAUNCH((attention_mfma_kernel<T, 128>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n, heads);
       return 0;
     }());
   else

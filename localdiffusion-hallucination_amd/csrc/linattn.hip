@@ -285,21 +285,23 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctx
 // walks ALL chunk partials (nchunks / 16 dependent load batches: 8 at the 128 partials of a 256^2 block).  DR = 2:
 // the 256 threads are 4 chunk groups x (2 x 32 elements); a thread sums every fourth partial (2 batches at 128
 // partials), the groups meet in LDS -- four times the workgroups, a quarter of the dependent round trips.
-template <typename T, int DR>
+// MC = the most chunk partials the instantiation combines (128: every launch of cfg3 / cfg4; 512: one large image per
+// launch, where 128 chunks would leave kvctx with fewer workgroups than CUs -- cfg5's 512^2 maps at B = 1).
+template <typename T, int DR, int MC = MAXCH>
 __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ ctx_part, int nchunks,
                                                       const float* __restrict__ w_out, T* __restrict__ w_packed,
                                                       int C, int heads, int perm) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int CG = 8 / DR, EL = DR * 32;                 // chunk groups, elements of the slice
-  __shared__ float s_w[DR][MAXCH + 1], s_z[DR], s_ctx[DR * 33], s_part[CG][EL];
+  __shared__ float s_w[DR][MC + 1], s_z[DR], s_ctx[DR * 33], s_part[CG][EL];
   const int h = blockIdx.x, b = blockIdx.y, part = blockIdx.z, tid = threadIdx.x;
   const float* src = ctx_part + ((size_t)b * heads + h) * nchunks * CTX_STRIDE;
   if (tid < EL) {   // per k-channel d (32 threads each): global max of the chunk maxima, rescale weights, Z
     const int dl = tid >> 5, sub = tid & 31, d = part * DR + dl;
-    float mc[MAXCH / 32], zc[MAXCH / 32];
+    float mc[MC / 32], zc[MC / 32];
     float M = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < MAXCH / 32; ++k) {
+    for (int k = 0; k < MC / 32; ++k) {
       const int c = k * 32 + sub;
       const bool ok = c < nchunks;
       mc[k] = ok ? src[(size_t)c * CTX_STRIDE + 1056 + d] : -INFINITY;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
     for (int o = 1; o < 32; o <<= 1) M = fmaxf(M, __shfl_xor(M, o));
     float z = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXCH / 32; ++k) {
+    for (int k = 0; k < MC / 32; ++k) {
       const int c = k * 32 + sub;
       const float wgt = c < nchunks ? expf(mc[k] - M) : 0.f;
       s_w[dl][c] = wgt;
@@ -366,8 +368,8 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
 
 extern "C" int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const float* w_out, void* w_packed, int B, int C,
                                   int heads, int dim_head, int perm, int dtype, void* stream) {
-  LD_REQUIRE(ctx_part && w_out && w_packed && B > 0 && heads > 0 && nchunks > 0 && nchunks <= MAXCH,
-             "ld_linattn_ctxfold: bad args (nchunks 1..128)");
+  LD_REQUIRE(ctx_part && w_out && w_packed && B > 0 && heads > 0 && nchunks > 0 && nchunks <= 4 * MAXCH,
+             "ld_linattn_ctxfold: bad args (nchunks 1..512)");
   LD_REQUIRE(dim_head == 32 && C % 16 == 0, "ld_linattn_ctxfold: dim_head 32, C %% 16 == 0");
   LD_REQUIRE(ld_dtype_ok(dtype), "ld_linattn_ctxfold: bad dtype %d", dtype);
   LD_REQUIRE(!(perm && !ld_dtype_16(dtype)), "ld_linattn_ctxfold: perm=1 is the 16-bit chained-operand order");
@@ -375,7 +377,9 @@ extern "C" int ld_linattn_ctxfold(const float* ctx_part, int nchunks, const floa
   LD_DISPATCH(dtype, [&] {
     // many partials: four chunk groups per workgroup (tuning table: fold_split_min, default 32 partials; 0 = never)
     const int split_min = (int)ld_tuning().fold_split_min;
-    if (split_min > 0 && nchunks >= split_min)
+    if (nchunks > MAXCH)      // one k-channel per workgroup, eight chunk groups: 2-4 dependent batches of 16 loads at 256-512 partials
+      LD_LAUNCH((ctxfold_kernel<T, 1, 4 * MAXCH>), dim3(heads, B, 32), dim3(256), 0, st, ctx_part, nchunks, w_out, (T*)w_packed, C, heads, perm);
+    else if (split_min > 0 && nchunks >= split_min)
       LD_LAUNCH((ctxfold_kernel<T, 2>), dim3(heads, B, 16), dim3(256), 0, st, ctx_part, nchunks, w_out, (T*)w_packed, C, heads, perm);
     else
       LD_LAUNCH((ctxfold_kernel<T, 8>), dim3(heads, B, 4), dim3(256), 0, st, ctx_part, nchunks, w_out, (T*)w_packed, C, heads, perm);

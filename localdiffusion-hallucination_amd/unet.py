@@ -569,6 +569,12 @@ class _Plan:
         rule = self.tn.chunk_rule(B)                      # n >= 65536, n >= 16384, smaller
         chunk_px = rule[0] if n >= 65536 else (rule[1] if n >= 16384 else rule[2])
         nchunks = max(1, min(128, n // chunk_px)) if heads == 4 else max(1, min(32, n // 256))
+        # one or two large images per launch (cfg5: 512^2 maps at B = 1): 128 chunks of 2,048 pixels are 128 workgroups on
+        # 256 CUs.  Chunks shrink (down to one 256-pixel tile) until the launch has two workgroups per CU; ctxfold
+        # combines up to 512 partials.  cfg3 / cfg4 (B >= 4 at 256^2) are untouched: 512 workgroups already.
+        if heads == 4 and self.tn.linattn_chunk_px is None:
+            while B * nchunks < 512 and nchunks < 512 and n // (2 * nchunks) >= 256:
+                nchunks *= 2
         ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, heads, 32, nchunks)), dtype=torch.float32, device=self.dev)
         wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)
         wout = f[p + ".to_out.0.weight"].reshape(c, hid).contiguous()
