@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(args, env_extra=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(env_extra or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
 
 
 def test_more_gpus_than_devices_is_an_error():
@@ -63,8 +63,15 @@ def test_two_ranks_on_one_gpu_over_gloo_print_one_line():
     """The N > 1 control flow of bench.py end to end on a 1-GPU box: two rank processes share the GPU, gloo carries the
     collectives (RCCL refuses two ranks on one device), rank 0 prints ONE JSON line with n_gpus == 2."""
     import json
-    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-other-dtype"],
-             {"LD_BENCH_SHARE_GPU": "1"})
+    args = ["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-other-dtype"]
+    # the launcher's own timeout (it kills its ranks by PID and prints the first failing rank's stderr tail) sits below
+    # the test's; two processes bringing up HIP + gloo on one shared, freshly booted GPU box were once seen to take
+    # minutes (round 4: one 300 s timeout in ~10 runs, never reproduced): one retry, with the first attempt's tail shown
+    env = {"LD_BENCH_SHARE_GPU": "1", "LD_BENCH_RANK_TIMEOUT": "400"}
+    r = _run(args, env)
+    if r.returncode != 0 and "timeout" in r.stderr:
+        print("first attempt timed out:\n" + r.stderr[-3000:])
+        r = _run(args, env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]       # (gloo itself prints a "[Gloo] Rank 0 is connected" line)
     assert len(lines) == 1
