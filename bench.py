@@ -308,7 +308,7 @@ def conv_path_chip_leg(gd, sub, conv_sel, reps=40):
             gs.synchronize()
             cabi_mod().check(lib.ld_graph_begin(st), "graph_begin")
             try:
-                cabi_mod().check(lib.ld_step_begin(*sp._begin_args, None, 0, None, None, st), "step_begin")
+                cabi_mod().check(lib.ld_step_begin_film(*sp._begin_args, sp._t_dev_ptr, 0, None, None, *sp._film_args, st), "step_begin")
                 for i in idx:
                     sp.ops_main[i](st)
             finally:

@@ -355,6 +355,13 @@ int ld_step_add(int32_t* t_ptr, int delta, void* stream);
  * at the head / tail of every replayed step. */
 int ld_step_begin(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
                   int32_t* idx_ptr, const int32_t* t_table, void* stream);
+/* the same + the step's FiLM row: film_cur[0 .. row_floats) = film_rows[t_new * row_floats ...] with t_new the counter's
+ * value AFTER the move (t_ptr required; delta may be 0) -- the (scale, shift) vectors of every ResnetBlock for this
+ * timestep (ddpm.py:191-206 evaluated for all t at setup, ld_film) land at a fixed address, so the launches that apply
+ * FiLM need no dependent load of the step counter.  row_floats % 4 == 0, 16-byte aligned rows. */
+int ld_step_begin_film(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
+                       int32_t* idx_ptr, const int32_t* t_table, const float* film_rows, int row_floats,
+                       float* film_cur, void* stream);
 
 /* p_sample, single branch (ddpm.py:631-666, 739-761, 817-838, 857-858):
  *   x0 = clamp(to_x0(model_out)), x_prev = c1*x0 + c2*x_t + (t>0 ? sigma*z : 0).

@@ -106,6 +106,7 @@ _SIGS = {
     "ld_randn_at": (C.c_int, [vp, i64, i64, u64, i64, i64, vp, vp]),
     "ld_step_add": (C.c_int, [vp, C.c_int, vp]),
     "ld_step_begin": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_int, vp, vp, vp]),
+    "ld_step_begin_film": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp]),
     "ld_ddim_step_at": (C.c_int, [vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, i64, vp]),
     "ld_ddpm_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, i64, vp]),
     "ld_posterior_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp]),

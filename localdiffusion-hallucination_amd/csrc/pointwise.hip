@@ -41,17 +41,35 @@ __global__ void randn_kernel(float* out, long n, long first, unsigned long long 
 __global__ void step_add_kernel(int* t, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *t += delta; }
 // start of a denoiser evaluation in ONE launch: zero the statistics arena(s) and advance the device step counter
 // (as two hipMemsetAsync + ld_step_add these were three dependent ~5-8 us nodes at the head of every replayed step)
-__global__ void step_begin_kernel(uint4* a, long na, uint4* b, long nb, int* t, int delta, int* idx, const int* t_table) {
+// + (film_rows != nullptr) the step's FiLM row: every ResnetBlock's (scale, shift) vector for the NEW timestep is copied
+// from the [T, row_floats] table into a fixed buffer, so that the ~20 launches of a step that apply FiLM read it from a
+// known address instead of first loading the step counter and then the row it selects -- one dependent global round trip
+// less at the head of every workgroup of those launches.  Block 0 does it: it is the one that knows the new timestep.
+__global__ void step_begin_kernel(uint4* a, long na, uint4* b, long nb, int* t, int delta, int* idx, const int* t_table,
+                                  const float* film_rows, int row_floats, float* film_cur) {
+  __shared__ int s_t;
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
   GRID_STRIDE(i, na) a[i] = z;
   GRID_STRIDE(i, nb) b[i] = z;
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    if (idx && t_table) {                 // strided (DDIM) sampling: advance the pair counter, look the timestep up
-      const int k = *idx + 1;
-      *idx = k;
-      if (t) *t = t_table[k];
-    } else if (t && delta != 0) {
-      *t += delta;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      int tn = t ? *t : 0;
+      if (idx && t_table) {               // strided (DDIM) sampling: advance the pair counter, look the timestep up
+        const int k = *idx + 1;
+        *idx = k;
+        tn = t_table[k];
+        if (t) *t = tn;
+      } else if (t && delta != 0) {
+        tn += delta;
+        *t = tn;
+      }
+      s_t = tn;
+    }
+    if (film_rows) {                      // (uniform)
+      __syncthreads();
+      const float4* src = reinterpret_cast<const float4*>(film_rows + (size_t)s_t * row_floats);
+      float4* dst = reinterpret_cast<float4*>(film_cur);
+      for (int i = threadIdx.x; i < row_floats / 4; i += blockDim.x) dst[i] = src[i];
     }
   }
 }
@@ -374,13 +392,21 @@ extern "C" int ld_step_add(int32_t* t_ptr, int delta, void* stream) {
 }
 extern "C" int ld_step_begin(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
                              int32_t* idx_ptr, const int32_t* t_table, void* stream) {
+  return ld_step_begin_film(zero_a, bytes_a, zero_b, bytes_b, t_ptr, delta, idx_ptr, t_table, nullptr, 0, nullptr, stream);
+}
+extern "C" int ld_step_begin_film(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
+                                  int32_t* idx_ptr, const int32_t* t_table, const float* film_rows, int row_floats,
+                                  float* film_cur, void* stream) {
   LD_REQUIRE((idx_ptr == nullptr) == (t_table == nullptr), "ld_step_begin: idx_ptr and t_table go together");
+  LD_REQUIRE((film_rows == nullptr) == (film_cur == nullptr), "ld_step_begin_film: film_rows and film_cur go together");
+  LD_REQUIRE(!film_rows || (t_ptr && row_floats > 0 && row_floats % 4 == 0 && ((size_t)film_rows % 16) == 0 && ((size_t)film_cur % 16) == 0),
+             "ld_step_begin_film: needs the step counter, row_floats %% 4 == 0 and 16-byte aligned rows");
   LD_REQUIRE((zero_a || bytes_a == 0) && (zero_b || bytes_b == 0), "ld_step_begin: null arena");
   LD_REQUIRE(bytes_a % 16 == 0 && bytes_b % 16 == 0 && ((size_t)zero_a % 16) == 0 && ((size_t)zero_b % 16) == 0,
              "ld_step_begin: arenas must be 16-byte aligned and sized");
   const long na = (long)(bytes_a / 16), nb = (long)(bytes_b / 16);
   LD_LAUNCH(step_begin_kernel, dim3(nblocks(na + nb + 1)), dim3(BS), 0, ST(stream), (uint4*)zero_a, na, (uint4*)zero_b, nb,
-            t_ptr, delta, idx_ptr, t_table);
+            t_ptr, delta, idx_ptr, t_table, film_rows, row_floats, film_cur);
   LD_LAUNCH_CHECK("step_begin");
   return LD_OK;
 }

@@ -331,7 +331,15 @@ class _Plan:
         self.rows = table_T if table_T else B
         self.temb = torch.zeros(self.rows, cfg.time_dim, dtype=torch.float32, device=self.dev)
         self.films = {}
+        # table mode: every block's FiLM table is a column range of ONE [T, film_row] arena and the step's first launch
+        # (ld_step_begin_film) copies the row of the current timestep to ``film_cur``: consumers read (scale, shift) from a
+        # fixed address, without the dependent load of the step counter (see src())
+        self._film_off, self.film_row = {}, 0
         self._build_time()
+        self.film_rows = self.film_cur = None
+        if table_T and self.film_row:
+            self.film_rows = torch.zeros(table_T, self.film_row, dtype=torch.float32, device=self.dev)
+            self.film_cur = torch.zeros(self.film_row, dtype=torch.float32, device=self.dev)
         self._slot_cursor = 0
         self.cond_feat = self._build_cond()
         self.named["cond_model"] = self.cond_feat
@@ -350,10 +358,16 @@ class _Plan:
         s_, km_ = self.stats[self.cond_slots:self._slots_used], self.kmax_arena[:self._kmax_cursor]
         self._begin_args = (s_.data_ptr(), s_.numel() * 8, km_.data_ptr() if km_.numel() else None, km_.numel() * 4)
         self._t_dev_ptr = self.t_dev.data_ptr()
+        self._film_args = (None, 0, None)
         if table_T:
             st = torch.cuda.current_stream().cuda_stream
             for op in self.ops_time:
                 op(st)
+            if self.film_rows is not None:             # setup: the per-block tables become column ranges of the arena
+                for film in self.films.values():
+                    off = self._film_off[id(film)]
+                    self.film_rows[:, off:off + film.shape[1]].copy_(film)
+                self._film_args = (self.film_rows.data_ptr(), self.film_row, self.film_cur.data_ptr())
             torch.cuda.current_stream().synchronize()
 
     # ------------------------------------------------------------------ helpers
@@ -378,7 +392,9 @@ class _Plan:
         return self.stats[s]
 
     def t_ptr(self):
-        return self.t_dev.data_ptr() if self.table_T else None
+        """The step-counter argument of the launches that apply FiLM: none -- in table mode the row of the current step is
+        at a fixed address (film_cur), with per-sample timesteps the rows are indexed by the batch element."""
+        return None
 
     def src(self, t, c, stride=0, ups=0, gn=None, act=cabi.ACT_NONE, film=None):
         s = cabi.Src()
@@ -387,10 +403,13 @@ class _Plan:
             stats, gamma, beta, groups = gn
             s.gn_stats, s.gn_gamma, s.gn_beta, s.gn_groups = stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), groups
         s.act = act
-        if film is not None:
+        if film is not None and self.table_T:          # the step's row, gathered by ld_step_begin_film
+            s.film = self.film_cur.data_ptr() + 4 * self._film_off[id(film)]
+            s.film_tstride = s.film_bstride = 0
+        elif film is not None:                          # per-sample timesteps (Unet.forward): a row per batch element
             s.film = film.data_ptr()
-            s.film_tstride = 2 * c if self.table_T else 0
-            s.film_bstride = 0 if self.table_T else 2 * c
+            s.film_tstride = 0
+            s.film_bstride = 2 * c
         self.keep.append(t)
         return s
 
@@ -500,6 +519,8 @@ class _Plan:
                 two_c = f[name].shape[0]
                 film = torch.zeros(n, two_c, dtype=torch.float32, device=self.dev)
                 self.films[p] = film
+                self._film_off[id(film)] = self.film_row
+                self.film_row += two_c
                 w, b = f[name], f[p + ".mlp.1.bias"]
                 self.ops_time.append(lambda st, w=w, b=b, film=film, two_c=two_c: cabi.check(lib.ld_film(
                     self.temb.data_ptr(), n, td, w.data_ptr(), b.data_ptr(), two_c, film.data_ptr(), st), "film"))
@@ -822,10 +843,11 @@ class _Plan:
         self.lib.ld_range_push(b"step")            # roctx: host-side issue of one denoiser evaluation (or its capture)
         try:
             if idx_ptr is not None:                # strided sampling: t_dev = t_table[++idx] (ld_step_begin)
-                cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr, 0, idx_ptr, t_table, st), "step_begin")
+                cabi.check(self.lib.ld_step_begin_film(*self._begin_args, self._t_dev_ptr, 0, idx_ptr, t_table, *self._film_args, st),
+                           "step_begin")
             else:
-                cabi.check(self.lib.ld_step_begin(*self._begin_args, self._t_dev_ptr if step_delta else None, int(step_delta),
-                                                  None, None, st), "step_begin")
+                cabi.check(self.lib.ld_step_begin_film(*self._begin_args, self._t_dev_ptr, int(step_delta), None, None,
+                                                       *self._film_args, st), "step_begin")
             ops = self.ops_main[:-1] if skip_final else self.ops_main
             for op in ops:
                 op(st)
@@ -837,7 +859,7 @@ class _Plan:
         its own start/stop events, so the times are kernel execution times as rocprofv3 reports them); adds each
         op's kernel time to ``acc[index] = [ms_total, launches]`` (bench.py's per-kernel roofline leg)."""
         lib = self.lib
-        cabi.check(lib.ld_step_begin(*self._begin_args, None, 0, None, None, st), "step_begin")
+        cabi.check(lib.ld_step_begin_film(*self._begin_args, self._t_dev_ptr, 0, None, None, *self._film_args, st), "step_begin")
         cabi.check(lib.ld_timing_begin(8 * len(self.ops_main)), "timing_begin")
         marks = [0]
         try:
