@@ -340,22 +340,30 @@ __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, 
                                               double* red, int tid, int nthreads) {
   const int C = S.C, G = S.groups, gs = C / G;
   float* gstat = reinterpret_cast<float*>(red);          // after the stripe sum: [G] mean, [G] rstd (floats)
-  // Request order matters (vector loads issue in order): first the 2*stripes statistics words of this thread's
-  // group, then gamma / beta / FiLM of its first channel -- which do not depend on the statistics and whose
-  // address needs the (long since loaded) step index -- and only then the arithmetic: one global round trip
-  // instead of two in front of every consumer launch.
+  // ONE global round trip in front of the arithmetic: gamma / beta / FiLM of this thread's first channel (their addresses
+  // depend on nothing: in table mode the step's FiLM row sits at a fixed address, ld_step_begin_film) and the 2 * stripes
+  // statistics words of its group are all requested before anything waits.  hipcc otherwise places the first
+  // `s2 += st2[0]` INSIDE the block of statistics loads (`s_waitcnt vmcnt(6)` behind the seventh of sixteen requests:
+  // the first load's whole round trip in front of the other nine and of gamma / beta) -- seen with hipcc -S in every
+  // kernel that builds coefficients (~47 launches per step); the scheduling barrier pins the requests together.
+  const float* film = S.film ? S.film + (long)trow * S.film_tstride + (long)b * S.film_bstride : nullptr;
+  float g0 = 0.f, b0 = 0.f, f0 = 0.f, f1 = 0.f;
+  if (tid < C) {
+    // (the FiLM words come from an always-valid address and are selected afterwards: inside an `if (film)` branch hipcc
+    //  waits for them before leaving it, i.e. in front of the statistics requests)
+    const float* fp = film ? film : S.gamma;
+    g0 = S.gamma[tid]; b0 = S.beta[tid];
+    f0 = fp[tid]; f1 = fp[(film ? C : 0) + tid];
+  }
   double st1[LD_STAT_STRIPES], st2[LD_STAT_STRIPES];
   if (tid < G) {
     const double* p = S.stats + (size_t)b * LD_STAT_STRIPES * G * 2 + 2 * tid;
 #pragma unroll
     for (int s = 0; s < LD_STAT_STRIPES; ++s) { st1[s] = p[(size_t)s * G * 2]; st2[s] = p[(size_t)s * G * 2 + 1]; }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  const float* film = S.film ? S.film + (long)trow * S.film_tstride + (long)b * S.film_bstride : nullptr;
-  float g0 = 0.f, b0 = 0.f, f0 = 0.f, f1 = 0.f;
-  if (tid < C) {
-    g0 = S.gamma[tid]; b0 = S.beta[tid];
-    if (film) { f0 = film[tid]; f1 = film[C + tid]; }
-  }
+  // (opaque from here on: hipcc otherwise computes `f0 + 1` right behind its load, in front of the statistics requests)
+  asm volatile("" : "+v"(g0), "+v"(b0), "+v"(f0), "+v"(f1));
   if (tid < G) {
     // sum the stripes in fp64, then ONE double divide/sqrt per group (not per channel)
     double s1 = 0.0, s2 = 0.0;
