@@ -10,6 +10,7 @@
 #include "../../include/localdiff_hip.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // a 16-byte register value that is NOT a struct (uint4 copies are memcpys in the IR)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __bf16 bf16;
 typedef _Float16 f16;

@@ -54,13 +54,30 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, cons
   const int trow = g.t_ptr ? *g.t_ptr : 0;
   const long npix_in = (long)g.H * g.W;
   double* red = reinterpret_cast<double*>(s_coef + 4 * C);
-  build_gn_coef<DT<T>::precise>(g.a, b, trow, npix_in, s_coef, red, tid, 256);
-  if (HAS_B && g.b.stats) build_gn_coef<DT<T>::precise>(g.b, b, trow, npix_in, s_coef + 2 * C, red, tid, 256);
   const int fpp = C / E;                               // fragments per pixel
   const int Ho = POOL ? g.H / 2 : g.H, Wo = POOL ? g.W / 2 : g.W;
   const int npix_out = Ho * Wo;
   T* out = reinterpret_cast<T*>(g.out) + (size_t)b * npix_out * C;
   const size_t in0 = (size_t)b * npix_in * C;
+  // The thread's first pixel pair is requested BEFORE the coefficients are built: the data does not depend on them,
+  // and behind them it was a second dependent round trip in a launch that is two round trips long (nearly every
+  // launch is one pair per thread).  Branch-free (clamped addresses, native vectors): a conditional load costs a wait.
+  u32x4 pa0, pa1, pb0, pb1;
+  {
+    const int fq = fpp <= 256 ? fpp : 256, cq = (tid % fq) * E, ppq = 256 / fq;
+    const int o0 = bx * ppq + tid / fq, o1 = o0 + gdx * ppq;
+    const size_t e0 = in0 + (size_t)(o0 < npix_out ? o0 : npix_out - 1) * C + cq;
+    const size_t e1 = in0 + (size_t)(o1 < npix_out ? o1 : npix_out - 1) * C + cq;
+    pa0 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.a.data) + e0);
+    pa1 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.a.data) + e1);
+    pb0 = pa0; pb1 = pa1;
+    if (HAS_B) {
+      pb0 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.b.data) + e0);
+      pb1 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.b.data) + e1);
+    }
+  }
+  build_gn_coef<DT<T>::precise>(g.a, b, trow, npix_in, s_coef, red, tid, 256);
+  if (HAS_B && g.b.stats) build_gn_coef<DT<T>::precise>(g.b, b, trow, npix_in, s_coef + 2 * C, red, tid, 256);
   auto one = [&](int opix, int c, const float* ca, const float* sa, const float* cb, const float* sb) {
     float v[E];
     if (!POOL) {
@@ -92,11 +109,18 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, cons
     // one(), hipcc kept the second pixel's loads BEHIND the first pixel's store (it cannot prove that `out` does not
     // alias the inputs), and the wait for them then also drains that store -- the vector-memory counter is in order and
     // counts stores (tools/scan_store_waits.py)
+    bool first = true;
     for (; opix + step < npix_out; opix += 2 * step) {
       if constexpr (!POOL) {
         uint4 ra0, rb0, ra1, rb1;
-        load_pixel<T, HAS_B>(g, in0 + (size_t)opix * C + c, ra0, rb0);
-        load_pixel<T, HAS_B>(g, in0 + (size_t)(opix + step) * C + c, ra1, rb1);
+        if (first) {
+          ra0 = make_uint4(pa0[0], pa0[1], pa0[2], pa0[3]); rb0 = make_uint4(pb0[0], pb0[1], pb0[2], pb0[3]);
+          ra1 = make_uint4(pa1[0], pa1[1], pa1[2], pa1[3]); rb1 = make_uint4(pb1[0], pb1[1], pb1[2], pb1[3]);
+        } else {
+          load_pixel<T, HAS_B>(g, in0 + (size_t)opix * C + c, ra0, rb0);
+          load_pixel<T, HAS_B>(g, in0 + (size_t)(opix + step) * C + c, ra1, rb1);
+        }
+        first = false;
         float v0[E], v1[E];
         finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, ra0, rb0, v0);
         finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, ra1, rb1, v1);
@@ -107,7 +131,15 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, cons
         one(opix + step, c, ca, sa, cb, sb);
       }
     }
-    if (opix < npix_out) one(opix, c, ca, sa, cb, sb);
+    if (opix < npix_out) {
+      if (!POOL && first) {                            // a single pixel, already here
+        float v0[E];
+        finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, make_uint4(pa0[0], pa0[1], pa0[2], pa0[3]), make_uint4(pb0[0], pb0[1], pb0[2], pb0[3]), v0);
+        *reinterpret_cast<uint4*>(out + (size_t)opix * C + c) = pack16<T>(v0);
+      } else {
+        one(opix, c, ca, sa, cb, sb);
+      }
+    }
   } else {
     const int nfrag = npix_out * fpp;
     for (int f = bx * 256 + tid; f < nfrag; f += gdx * 256) {

@@ -296,18 +296,39 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
   __shared__ float s_w[DR][MC + 1], s_z[DR], s_ctx[DR * 33], s_part[CG][EL];
   const int h = blockIdx.x, b = blockIdx.y, part = blockIdx.z, tid = threadIdx.x;
   const float* src = ctx_part + ((size_t)b * heads + h) * nchunks * CTX_STRIDE;
-  if (tid < EL) {   // per k-channel d (32 threads each): global max of the chunk maxima, rescale weights, Z
-    const int dl = tid >> 5, sub = tid & 31, d = part * DR + dl;
-    float mc[MC / 32], zc[MC / 32];
+  const int hidden = heads * 32, mt_total = C / 16;
+  // Every request that does not depend on an earlier result leaves before the first wait: the chunk maxima / Z of
+  // phase 1, the first 16 context partials of phase 2 and the first W_out row of phase 3.  Written phase by phase the
+  // launch was four dependent round trips (tools/scan_head_chain.py); now it is one, plus one per further batch of 16.
+  const int r1 = tid % EL, dl1 = r1 >> 5, sub = r1 & 31, d1 = part * DR + dl1;       // phase 1 (threads >= EL: redundant copies)
+  float mc[MC / 32], zc[MC / 32];
+#pragma unroll
+  for (int k = 0; k < MC / 32; ++k) {
+    const int c = k * 32 + sub;
+    const bool ok = c < nchunks;
+    mc[k] = src[(size_t)(ok ? c : 0) * CTX_STRIDE + 1056 + d1];
+    zc[k] = src[(size_t)(ok ? c : 0) * CTX_STRIDE + 1024 + d1];
+    if (!ok) { mc[k] = -INFINITY; zc[k] = 0.f; }
+  }
+  const int cg = tid / EL, rem = tid - cg * EL, dl = rem >> 5;
+  const int i = part * EL + rem;                           // element d*32+e of the head's context
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = cg + k * CG;
+    v[k] = src[(size_t)(c < nchunks ? c : 0) * CTX_STRIDE + i];
+  }
+  const int nout = C * DR;
+  const int idx0 = tid < nout ? tid : nout - 1;
+  const int co0 = idx0 / DR;
+  f32x4 wr[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) wr[q] = *reinterpret_cast<const f32x4*>(w_out + (size_t)co0 * hidden + h * 32 + q * 4);
+  __builtin_amdgcn_sched_barrier(0);
+  {   // per k-channel d (32 lanes each): global max of the chunk maxima, rescale weights, Z
     float M = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < MC / 32; ++k) {
-      const int c = k * 32 + sub;
-      const bool ok = c < nchunks;
-      mc[k] = ok ? src[(size_t)c * CTX_STRIDE + 1056 + d] : -INFINITY;
-      zc[k] = ok ? src[(size_t)c * CTX_STRIDE + 1024 + d] : 0.f;
-      M = fmaxf(M, mc[k]);
-    }
+    for (int k = 0; k < MC / 32; ++k) M = fmaxf(M, mc[k]);
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) M = fmaxf(M, __shfl_xor(M, o));
     float z = 0.f;
@@ -315,24 +336,23 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
     for (int k = 0; k < MC / 32; ++k) {
       const int c = k * 32 + sub;
       const float wgt = c < nchunks ? expf(mc[k] - M) : 0.f;
-      s_w[dl][c] = wgt;
+      if (tid < EL) s_w[dl1][c] = wgt;
       z += wgt * zc[k];
     }
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) z += __shfl_xor(z, o);
-    if (sub == 0) s_z[dl] = z;
+    if (tid < EL && sub == 0) s_z[dl1] = z;
   }
   __syncthreads();
   {
-    const int cg = tid / EL, rem = tid - cg * EL, dl = rem >> 5;
-    const int i = part * EL + rem;                         // element d*32+e of the head's context
     float s = 0.f;
     for (int c0 = cg; c0 < nchunks; c0 += 16 * CG) {       // chunks cg, cg + CG, ...: 16 loads in flight
-      float v[16];
+      if (c0 != cg) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = (c0 + k * CG < nchunks) ? src[(size_t)(c0 + k * CG) * CTX_STRIDE + i] : 0.f;
+        for (int k = 0; k < 16; ++k) v[k] = src[(size_t)(c0 + k * CG < nchunks ? c0 + k * CG : 0) * CTX_STRIDE + i];
+      }
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s = fmaf(s_w[dl][c0 + k * CG < nchunks ? c0 + k * CG : 0], v[k], s);
+      for (int k = 0; k < 16; ++k) s = fmaf(c0 + k * CG < nchunks ? s_w[dl][c0 + k * CG] : 0.f, v[k], s);
     }
     if constexpr (CG == 1) {
       s_ctx[dl * 33 + (rem & 31)] = s / s_z[dl];
@@ -348,15 +368,19 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
-  const int hidden = heads * 32, mt_total = C / 16;
   T* dst = w_packed + (size_t)b * C * hidden;
-  for (int idx = tid; idx < C * DR; idx += 256) {
+  for (int idx = tid; idx < nout; idx += 256) {
     const int co = idx / DR, d8 = idx - co * DR, ci = h * 32 + part * DR + d8;
     const float* wrow = w_out + (size_t)co * hidden + h * 32;
     const float* crow = s_ctx + d8 * 33;
     float m = 0.f;
+    if (idx == tid) {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) m = fmaf(wr[e >> 2][e & 3], crow[e], m);
+    } else {
 #pragma unroll 8
-    for (int e = 0; e < 32; ++e) m = fmaf(wrow[e], crow[e], m);
+      for (int e = 0; e < 32; ++e) m = fmaf(wrow[e], crow[e], m);
+    }
     const int mt = co >> 4, ii = co & 15;
     int ch = ci / CK, kq = (ci % CK) / E, e = ci % E;
     if (perm) { ch = ci >> 5; kq = (ci >> 2) & 3; e = ((ci >> 4) & 1) * 4 + (ci & 3); }

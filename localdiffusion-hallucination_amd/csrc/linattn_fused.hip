@@ -435,10 +435,30 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kq = lane >> 4;
   const int n = a.n, C = a.C;
   const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * n * C;
-  // W_q and M_b are staged once per workgroup and reused for LINOUT_TPB consecutive pixel tiles
-  for (int u = tid; u < NCW * 8 * 64; u += 256) *reinterpret_cast<uint4*>(s_wq + u * 16) = a.wq[u];
+  // W_q and M_b are staged once per workgroup and reused for LINOUT_TPB consecutive pixel tiles.  Every request of the
+  // head -- both matrices, the first x tile, bias and gain -- leaves before the first wait: written as two
+  // `lds[u] = global[u]` loops in front of the x loads, the head was three dependent round trips (load, wait,
+  // ds_write per loop; tools/scan_head_chain.py)
+  constexpr int WQ_IT = NCW * 8 * 64 / 256, MF_IT = 4 * MT2 * 64 / 256;
   const uint4* mf = a.mfold + (size_t)b * 4 * MT2 * 64;
-  for (int u = tid; u < 4 * MT2 * 64; u += 256) *reinterpret_cast<uint4*>(s_mf + u * 16) = mf[u];
+  // (native vectors: a `uint4` copy is a memcpy in the IR, and with a scheduling barrier between the copy in and the
+  // copy out the register array stays a private-memory array -- scratch traffic)
+  u32x4 wq_r[WQ_IT], mf_r[MF_IT];
+  u32x4 x_r[NCH][NW];
+#pragma unroll
+  for (int i = 0; i < WQ_IT; ++i) wq_r[i] = *reinterpret_cast<const u32x4*>(a.wq + tid + i * 256);
+#pragma unroll
+  for (int i = 0; i < MF_IT; ++i) mf_r[i] = *reinterpret_cast<const u32x4*>(mf + tid + i * 256);
+  {
+    const int p0 = blockIdx.x * LINOUT_TPB * NPT;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int it = 0; it < NW; ++it) {
+        const int p = p0 + (it * 4 + wv) * 16 + li;
+        x_r[c][it] = *reinterpret_cast<const u32x4*>(xb + (size_t)(p < n ? p : n - 1) * C + c * 32 + kq * 8);   // branch-free; masked at use
+      }
+  }
   // bias and the RMSNorm gain of this lane's output channels: loaded once, not inside the per-pixel epilogue
   float4 bvr[MT2], gvr[MT2];
 #pragma unroll
@@ -446,11 +466,15 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
     bvr[m2] = *reinterpret_cast<const float4*>(a.bias + m2 * 16 + kq * 4);
     gvr[m2] = *reinterpret_cast<const float4*>(a.g2 + m2 * 16 + kq * 4);
   }
-  float qs2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.qshift) {
+  // the q bound as a (uniform) VECTOR load in the same batch: as scalar loads through the pointer it was one more
+  // dependent round trip behind the kernel arguments, and hipcc put it behind the vector waits
+  const float4 qsv = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.qshift ? a.qshift : a.bias) + (lane & 0));
+  __builtin_amdgcn_sched_barrier(0);                     // every request above leaves before the first wait below
+  const float qs2[4] = {qsv.x * 1.4426950408889634f, qsv.y * 1.4426950408889634f, qsv.z * 1.4426950408889634f, qsv.w * 1.4426950408889634f};
 #pragma unroll
-    for (int hh = 0; hh < 4; ++hh) qs2[hh] = a.qshift[hh] * 1.4426950408889634f;
-  }
+  for (int i = 0; i < WQ_IT; ++i) *reinterpret_cast<u32x4*>(s_wq + (tid + i * 256) * 16) = wq_r[i];
+#pragma unroll
+  for (int i = 0; i < MF_IT; ++i) *reinterpret_cast<u32x4*>(s_mf + (tid + i * 256) * 16) = mf_r[i];
   for (int tl = 0; tl < LINOUT_TPB; ++tl) {
   const int p0 = (blockIdx.x * LINOUT_TPB + tl) * NPT;
   if (p0 >= n) break;
@@ -465,7 +489,8 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
       const int qq = (it * 4 + wv) * 16 + li, p = p0 + qq;
       uint4 raw = make_uint4(0u, 0u, 0u, 0u);
       if (p < n) {
-        raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * C + c * 32 + kq * 8);
+        if (LINOUT_TPB == 1 || tl == 0) raw = make_uint4(x_r[c][it][0], x_r[c][it][1], x_r[c][it][2], x_r[c][it][3]);
+        else raw = *reinterpret_cast<const uint4*>(xb + (size_t)p * C + c * 32 + kq * 8);
         float v[8];
         unpack16<T>(raw, v);
 #pragma unroll
@@ -479,6 +504,10 @@ __global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
     r = kq4_sum(r);
     if (kq == 0) s_rinv[(it * 4 + wv) * 16 + li] = rms_rinv<false>(r);
   }
+  // bias / gain were requested with the head's batch and are first USED in the epilogue: retire them here (free: the
+  // batch has landed), or hipcc's wait for them sits behind the first output store and drains it (the vector-memory
+  // counter is in order and counts stores; tools/scan_store_waits.py)
+  if (tl == 0) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt / lgkmcnt untouched
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
