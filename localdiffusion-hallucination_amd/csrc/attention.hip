@@ -132,17 +132,28 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T, int TKV>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                             int n, int heads) {
+// KS = 2 (launches with at most one 256-thread workgroup per CU -- every launch of the two-sub-batch regime and of
+// cfg5): the workgroup is TWO groups of 4 waves, group g walks the g-th half of the keys with its own LDS tiles for the
+// SAME 64 queries, and group 0 merges the two (m, l, O) states at the end (flash-decoding's split, inside a
+// workgroup).  One wave per SIMD left the softmax VALU and the MFMAs of a tile strictly serial; with two waves per
+// SIMD one group's exponentials run under the other's matrix products, and each wave's chain of tiles is half as long.
+template <typename T, int TKV, int KS>
+__global__ __launch_bounds__(256 * KS) void attention_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+                                                                  int n, int heads) {
   constexpr int NKT = TKV / 16, NST = TKV / 64;          // 16-key MFMA tiles per tile; staging rows per thread
-  __shared__ __attribute__((aligned(16))) uint4 s_k[4][TKV + 1];   // +1: the 4 chunk lanes of a key write 4 distinct bank quads
-  __shared__ __attribute__((aligned(16))) char s_v[TKV * VROW];
+  constexpr int KBYTES = 4 * (TKV + 1) * 16, VBYTES = TKV * VROW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];         // per group: K planes [4][TKV + 1][16 B], V rows [TKV][VROW]
+  const int grp = KS == 1 ? 0 : (int)(threadIdx.x >> 8);
+  uint4 (*s_k)[TKV + 1] = reinterpret_cast<uint4 (*)[TKV + 1]>(smem + grp * (KBYTES + VBYTES));   // +1: the 4 chunk lanes of a key write 4 distinct bank quads
+  char* s_v = smem + grp * (KBYTES + VBYTES) + KBYTES;
   const int hidden = heads * D;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kg = lane >> 4;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6, li = lane & 15, kg = lane >> 4;
   const size_t rowstride = (size_t)3 * hidden;
   const T* base = qkv + (size_t)b * n * rowstride;
+  // keys of this group: [kbeg, kend); every group runs the same number of tiles (the barriers are workgroup-wide)
+  const int span = ((n + KS * TKV - 1) / (KS * TKV)) * TKV;
+  const int kbeg = grp * span, kend = min(n, kbeg + span);
   const int qi = q0 + wv * 16 + li;
   uint4 qf = make_uint4(0u, 0u, 0u, 0u);
   if (qi < n) qf = *reinterpret_cast<const uint4*>(base + (size_t)qi * rowstride + h * D + kg * 8);
@@ -161,14 +172,14 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
       const int j = j0 + u * 64 + skey;
       kk[u] = make_uint4(0u, 0u, 0u, 0u);
       vv[u] = kk[u];
-      if (j < n) {
+      if (j < kend) {
         const T* rp = base + (size_t)j * rowstride + h * D + schunk * 8;
         kk[u] = *reinterpret_cast<const uint4*>(rp + hidden);
         vv[u] = *reinterpret_cast<const uint4*>(rp + 2 * hidden);
       }
     }
   };
-  request(0);
+  request(kbeg);
   // The normaliser l = sum_j P_ij comes out of the matrix pipe: a third A tile of ONES beside the two V^T tiles makes
   // every row of its product the column sum of P^T (of the P that is actually multiplied: the storage-rounded one, so
   // the output is an exactly normalised average of V rows).  32 dependent v_add per 128 keys become 4 MFMAs on a pipe
@@ -176,9 +187,9 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
   const unsigned one2 = pack2<T>(1.0f, 1.0f);
   const uint4 ones = make_uint4(one2, one2, one2, one2);
   f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
-  // One 128-key tile.  FULL: no key of the tile is past n (every tile at the model's sizes): the four instructions per
-  // score that masked such keys (index, compare, mask merge, select: 128 of the ~400 instructions of a tile) exist
-  // only in the ragged variant.
+  // One TKV-key tile.  FULL: no key of the tile is past the group's range (every tile at the model's sizes): the four
+  // instructions per score that masked such keys (index, compare, mask merge, select: 128 of the ~400 instructions of
+  // a tile) exist only in the ragged variant.
   auto tile = [&](int j0, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     f32x4 s[NKT];
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if constexpr (!FULL) {
-          if ((j0 + kt * 16 + kg * 4 + r) >= n) s[kt][r] = -1e30f;
+          if ((j0 + kt * 16 + kg * 4 + r) >= kend) s[kt][r] = -1e30f;
         }
         mx = fmaxf(mx, s[kt][r]);
       }
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
       mma16<T>(lacc, ones, pf);
     }
   };
-  for (int j0 = 0; j0 < n; j0 += TKV) {
+  for (int j0 = kbeg; j0 < kbeg + span; j0 += TKV) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NST; ++u) {
@@ -235,20 +246,52 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const T* __restrict
       *reinterpret_cast<uint4*>(s_v + (u * 64 + skey) * VROW + schunk * 16) = vv[u];
     }
     __syncthreads();
-    if (j0 + TKV < n) request(j0 + TKV);
-    if (j0 + TKV <= n) tile(j0, std::true_type{});
+    if (j0 + TKV < kend) request(j0 + TKV);
+    if (j0 + TKV <= kend) tile(j0, std::true_type{});
     else tile(j0, std::false_type{});
+  }
+  float lsum = lacc[0];
+  if constexpr (KS == 2) {
+    // group 1 hands (m, l, O^T fragment) over through LDS (its tiles are dead); group 0 merges.  A group without a
+    // single key in range (short sequences) has m = -1e30: its weight underflows to exactly 0.
+    __syncthreads();
+    float* s_mrg = reinterpret_cast<float*>(smem);       // [10][256]
+    if (grp == 1) {
+      s_mrg[0 * 256 + tid] = m;
+      s_mrg[1 * 256 + tid] = lsum;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s_mrg[(2 + r) * 256 + tid] = o0[r]; s_mrg[(6 + r) * 256 + tid] = o1[r]; }
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    const float m1 = s_mrg[0 * 256 + tid], l1 = s_mrg[1 * 256 + tid];
+    const float M = fmaxf(m, m1);
+    const float f0 = __builtin_amdgcn_exp2f((m - M) * 1.4426950408889634f), f1 = __builtin_amdgcn_exp2f((m1 - M) * 1.4426950408889634f);
+    lsum = lsum * f0 + l1 * f1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o0[r] = o0[r] * f0 + s_mrg[(2 + r) * 256 + tid] * f1;
+      o1[r] = o1[r] * f0 + s_mrg[(6 + r) * 256 + tid] * f1;
+    }
   }
   {
     // the head's two 16-channel halves leave as ONE 16-byte store per lane (pair_frag16: the exchange runs on every
     // lane, only the store is predicated)
-    const float inv = 1.0f / lacc[0];
+    const float inv = 1.0f / lsum;
     char* op = reinterpret_cast<char*>(out + ((size_t)b * n + (qi < n ? qi : 0)) * hidden + h * D);
     float r0[4] = {o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv};
     float r1[4] = {o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
     const uint4 w16 = pair_frag16<T>(r0, r1);
     if (qi < n) *reinterpret_cast<uint4*>(op + pair_frag16_off(kg)) = w16;
   }
+}
+
+template <typename T, int TKV, int KS>
+int launch_mfma(dim3 grid, hipStream_t st, const void* qkv, void* out, int n, int heads) {
+  const size_t lds = (size_t)KS * (4 * (TKV + 1) * 16 + TKV * VROW);
+  if (ld_allow_lds(attention_mfma_kernel<T, TKV, KS>, lds) != hipSuccess) return ld_fail(LD_EHIP, "ld_attention: %zu bytes of LDS refused", lds);
+  LD_LAUNCH((attention_mfma_kernel<T, TKV, KS>), grid, dim3(256 * KS), lds, st, (const T*)qkv, (T*)out, n, heads);
+  return LD_OK;
 }
 }  // namespace
 
@@ -261,11 +304,16 @@ extern "C" int ld_attention(const void* qkv, void* out, int B, int n, int heads,
   if (dtype == LD_F32)
     LD_LAUNCH(attention_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, (float*)out, n, heads);
   else if (ld_dtype_16(dtype))
-    LD_DISPATCH16(dtype, [&] {
-      // long sequences (cfg5: n = 4,096): 256-key tiles halve the barriers, row reductions and rescales per key
-      if (n >= 2048) LD_LAUNCH((attention_mfma_kernel<T, 256>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n, heads);
-      else LD_LAUNCH((attention_mfma_kernel<T, 128>), grid, dim3(256), 0, st, (const T*)qkv, (T*)out, n, heads);
-      return 0;
+    return LD_DISPATCH16(dtype, [&] {
+      // long sequences (cfg5: n = 4,096): 256-key tiles halve the barriers, row reductions and rescales per key;
+      // launches of at most attn_split_max_wgs workgroups (tuning table; default 256 = one per CU): two key groups
+      const bool split = (long)grid.x * grid.y * grid.z <= ld_tuning().attn_split_max_wgs && n >= 256;
+      int rc;
+      if (n >= 2048) rc = split ? launch_mfma<T, 256, 2>(grid, st, qkv, out, n, heads) : launch_mfma<T, 256, 1>(grid, st, qkv, out, n, heads);
+      else rc = split ? launch_mfma<T, 128, 2>(grid, st, qkv, out, n, heads) : launch_mfma<T, 128, 1>(grid, st, qkv, out, n, heads);
+      if (rc != LD_OK) return rc;
+      LD_LAUNCH_CHECK("attention");
+      return (int)LD_OK;
     }());
   else
     return ld_fail(LD_EINVAL, "ld_attention: bad dtype %d", dtype);

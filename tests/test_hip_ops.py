@@ -236,6 +236,37 @@ def test_full_attention(dtype, n_hw):
     assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,n_hw", [(1, (64, 64)), (2, (18, 18)), (2, (20, 20)), (4, (32, 32)), (1, (48, 48))])
+def test_full_attention_two_key_groups(dtype, B, n_hw):
+    """Launches of at most attn_split_max_wgs workgroups run as two key groups per workgroup (attention.hip, KS = 2):
+    against the fp32 reference, and against the one-group kernel (routing switched through the tuning table) -- full
+    tiles, a ragged last tile, and a second group whose last tile has no key in range (n = 324)."""
+    from localdiffusion_hallucination_amd.tuning import kernel_table
+    hid = 128
+    H, W = n_hw
+    n = H * W
+    qkv = _q(hh.rand((B, 3 * hid, H, W), 61, -1.5, 1.5), dtype)
+    q, k, v = [t.reshape(B, 4, 32, n).transpose(-1, -2) for t in qkv.chunk(3, dim=1)]
+    ref = ((q @ k.transpose(-1, -2)).softmax(dim=-1) @ v).transpose(-1, -2).reshape(B, hid, H, W)
+    qd = hh.nhwc(qkv, dtype)
+    lib = cabi.lib()
+    keep = kernel_table(lib)
+    outs = {}
+    try:
+        for name, wgs in (("split", 1 << 30), ("one", 0)):
+            cabi.check(lib.ld_tuning_set(b"attn_split_max_wgs", wgs), "tuning_set")
+            out = torch.empty(B, H, W, hid, dtype=hh.TDT[dtype], device=hh.DEV)
+            cabi.check(lib.ld_attention(qd.data_ptr(), out.data_ptr(), B, n, 4, 32, cabi.dtype_code(dtype), hh.st()), "attention")
+            outs[name] = hh.nchw(out)
+            assert hh.rel_err(outs[name], ref) < hh.RTOL[dtype], name
+    finally:
+        for kname, val in keep.items():
+            cabi.check(lib.ld_tuning_set(kname.encode(), val), "tuning_set")
+    # the two differ only in where the running maximum is taken (P is rounded to storage against it)
+    assert hh.rel_err(outs["split"], outs["one"]) < hh.RTOL[dtype] / 2
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("c,H,W", [(32, 28, 28), (64, 14, 14), (32, 64, 96)])
 def test_linear_attention_block(dtype, c, H, W):
