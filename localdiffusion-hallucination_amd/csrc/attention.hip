@@ -307,7 +307,9 @@ extern "C" int ld_attention(const void* qkv, void* out, int B, int n, int heads,
     return LD_DISPATCH16(dtype, [&] {
       // long sequences (cfg5: n = 4,096): 256-key tiles halve the barriers, row reductions and rescales per key;
       // launches of at most attn_split_max_wgs workgroups (tuning table; default 256 = one per CU): two key groups
-      const bool split = (long)grid.x * grid.y * grid.z <= ld_tuning().attn_split_max_wgs && n >= 256;
+      // (measured: n = 4,096 at B = 1 alone 27.6 -> 23.8 us, cfg5 +0.3 %; n = 1,024 at B = 4 alone 9.2 -> 8.5 us but in
+      //  the two-sub-batch step +0.2 % -- the other stream's launch already is the second wave per SIMD: long sequences only)
+      const bool split = (long)grid.x * grid.y * grid.z <= ld_tuning().attn_split_max_wgs && n >= ld_tuning().attn_split_min_n;
       int rc;
       if (n >= 2048) rc = split ? launch_mfma<T, 256, 2>(grid, st, qkv, out, n, heads) : launch_mfma<T, 256, 1>(grid, st, qkv, out, n, heads);
       else rc = split ? launch_mfma<T, 128, 2>(grid, st, qkv, out, n, heads) : launch_mfma<T, 128, 1>(grid, st, qkv, out, n, heads);

@@ -239,7 +239,7 @@ def test_full_attention(dtype, n_hw):
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("B,n_hw", [(1, (64, 64)), (2, (18, 18)), (2, (20, 20)), (4, (32, 32)), (1, (48, 48))])
 def test_full_attention_two_key_groups(dtype, B, n_hw):
-    """Launches of at most attn_split_max_wgs workgroups run as two key groups per workgroup (attention.hip, KS = 2):
+    """Launches of at most attn_split_max_wgs workgroups and at least attn_split_min_n keys run as two key groups per workgroup (attention.hip, KS = 2):
     against the fp32 reference, and against the one-group kernel (routing switched through the tuning table) -- full
     tiles, a ragged last tile, and a second group whose last tile has no key in range (n = 324)."""
     from localdiffusion_hallucination_amd.tuning import kernel_table
@@ -254,6 +254,7 @@ def test_full_attention_two_key_groups(dtype, B, n_hw):
     keep = kernel_table(lib)
     outs = {}
     try:
+        cabi.check(lib.ld_tuning_set(b"attn_split_min_n", 256), "tuning_set")
         for name, wgs in (("split", 1 << 30), ("one", 0)):
             cabi.check(lib.ld_tuning_set(b"attn_split_max_wgs", wgs), "tuning_set")
             out = torch.empty(B, H, W, hid, dtype=hh.TDT[dtype], device=hh.DEV)
