@@ -217,6 +217,17 @@ size_t ld_stem_packed_bytes(void);
 int ld_pack_stem_weight(const float* w_oihw /*[32,Cin,7,7]*/, void* out_packed, int Cin, void* stream);
 int ld_conv_stem(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H, int W,
                  int dtype /* LD_BF16 or LD_F16: type of the stored output */, void* stream);
+/* ld_step_begin_film's arguments (below) as a struct, and ld_conv_stem with that head-of-step work folded into the SAME
+ * launch: a few extra workgroups zero the arenas, move the step counter and copy the timestep's FiLM row beside the
+ * convolution, which reads none of them -- init_conv is the first operation of Unet.forward (ddpm.py:413) and no
+ * launch before the third of an evaluation consumes statistics or FiLM, so an evaluation loses its first launch. */
+typedef struct ld_step_begin_args {
+  void* zero_a; size_t bytes_a; void* zero_b; size_t bytes_b;
+  int32_t* t_ptr; int delta; int32_t* idx_ptr; const int32_t* t_table;
+  const float* film_rows; int row_floats; float* film_cur;
+} ld_step_begin_args;
+int ld_conv_stem_begin(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H, int W,
+                       int dtype, const ld_step_begin_args* begin, void* stream);
 
 
 /* ---- GroupNorm apply (+FiLM) + activation + residual, optional second normalised input ----- */

@@ -48,6 +48,11 @@ class GnApplyArgs(C.Structure):
                 ("H", i32), ("W", i32), ("t_ptr", vp), ("dtype", i32)]
 
 
+class StepBeginArgs(C.Structure):
+    _fields_ = [("zero_a", vp), ("bytes_a", C.c_size_t), ("zero_b", vp), ("bytes_b", C.c_size_t), ("t_ptr", vp), ("delta", i32),
+                ("idx_ptr", vp), ("t_table", vp), ("film_rows", vp), ("row_floats", i32), ("film_cur", vp)]
+
+
 # name -> (restype, argtypes); must list every function include/localdiff_hip.h declares
 _SIGS = {
     "ld_last_error": (C.c_char_p, []),
@@ -79,6 +84,7 @@ _SIGS = {
     "ld_stem_packed_bytes": (C.c_size_t, []),
     "ld_pack_stem_weight": (C.c_int, [vp, vp, C.c_int, vp]),
     "ld_conv_stem": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "ld_conv_stem_begin": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(StepBeginArgs), vp]),
     "ld_gn_apply": (C.c_int, [C.POINTER(GnApplyArgs), vp]),
     "ld_linattn_kmax": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_linattn_ctx": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -280,6 +280,45 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// ---------------------------------------------------------------- head-of-step work (pointwise.hip: step_begin_kernel;
+// conv_image.hip: the stem convolution's extra workgroups, ld_conv_stem_begin)
+struct StepBeginDev {
+  uint4* a; long na; uint4* b; long nb;          // arenas to zero, in 16-byte units
+  int* t; int delta; int* idx; const int* t_table;
+  const float* film_rows; int row_floats; float* film_cur;
+};
+// Part `e` of `ne` (whole workgroups): zero the arenas; part 0 also moves the step counter and copies the new
+// timestep's FiLM row to its fixed address.  s_t: one int of shared memory.
+__device__ __forceinline__ void step_begin_work(const StepBeginDev& s, long e, long ne, int* s_t) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  const long stride = ne * blockDim.x;
+  for (long i = e * blockDim.x + threadIdx.x; i < s.na; i += stride) s.a[i] = z;
+  for (long i = e * blockDim.x + threadIdx.x; i < s.nb; i += stride) s.b[i] = z;
+  if (e == 0) {
+    if (threadIdx.x == 0) {
+      int tn = s.t ? *s.t : 0;
+      if (s.idx && s.t_table) {           // strided (DDIM) sampling: advance the pair counter, look the timestep up
+        const int k = *s.idx + 1;
+        *s.idx = k;
+        tn = s.t_table[k];
+        if (s.t) *s.t = tn;
+      } else if (s.t && s.delta != 0) {
+        tn += s.delta;
+        *s.t = tn;
+      }
+      *s_t = tn;
+    }
+    if (s.film_rows) {                    // (uniform)
+      __syncthreads();
+      const float4* src = reinterpret_cast<const float4*>(s.film_rows + (size_t)*s_t * s.row_floats);
+      float4* dst = reinterpret_cast<float4*>(s.film_cur);
+      for (int i = threadIdx.x; i < s.row_floats / 4; i += blockDim.x) dst[i] = src[i];
+    }
+  }
+}
+int ld_step_begin_check(const void* zero_a, size_t bytes_a, const void* zero_b, size_t bytes_b, const void* t_ptr, const void* idx_ptr,
+                        const void* t_table, const void* film_rows, int row_floats, const void* film_cur);
+
 // ---------------------------------------------------------------- activations
 template <bool PRECISE> __device__ __forceinline__ float silu_f(float v) {
   // parity mode: libm expf + IEEE divide.  Storage-bf16 mode: v_exp_f32 / v_rcp_f32 (1 ulp each, far below the

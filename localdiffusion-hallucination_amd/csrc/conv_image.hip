@@ -120,15 +120,26 @@ __global__ void stem_pack_kernel(const float* __restrict__ w, unsigned short* __
   out[STEM_NCHK * 2 * 64 * 8 + slot] = __builtin_bit_cast(unsigned short, lo);
 }
 
-template <typename T>
+// BEGIN (ld_conv_stem_begin): the first `nbeg` workgroups in x are not convolution workgroups -- they do the head-of-step
+// work (step_begin_work: zero the statistics arenas, move the step counter, copy the timestep's FiLM row) beside the
+// convolution, which reads none of it: the evaluation's first launch disappears into its second.
+template <typename T, bool BEGIN>
 __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                              const float* __restrict__ bias, T* out, int B, int Cin,
-                                                             int H, int W, int tiles_x, int ntiles) {
+                                                             int H, int W, int tiles_x, int ntiles, StepBeginDev sb, int nbeg) {
   constexpr int KS = 7, PAD = 3, TSX = 16, TSY = 32, HSX = TSX + KS - 1 + 1, HSY = TSY + KS - 1, NCHK = STEM_NCHK;
   constexpr int NIN = 3 * HSY * HSX, NLD = (NIN + 255) / 256;
   __shared__ unsigned s_in[NIN + 8];                     // per input pixel: bf16 hi part | bf16 lo part << 16
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y;
+  if constexpr (BEGIN) {
+    if ((int)blockIdx.x < nbeg) {                        // (uniform per workgroup)
+      __shared__ int s_t;
+      step_begin_work(sb, (long)blockIdx.x * gridDim.y + blockIdx.y, (long)nbeg * gridDim.y, &s_t);
+      return;
+    }
+  }
+  const int bx = BEGIN ? (int)blockIdx.x - nbeg : (int)blockIdx.x, gdx = BEGIN ? (int)gridDim.x - nbeg : (int)gridDim.x;
   uint4 Ahi[NCHK][2], Alo[NCHK][2];                      // this lane's weight fragments, straight from the packed image
 #pragma unroll
   for (int ch = 0; ch < NCHK; ++ch)
@@ -163,8 +174,8 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(const float* __rest
       stage[r] = v;
     }
   };
-  if ((int)blockIdx.x < ntiles) request(blockIdx.x);
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  if (bx < ntiles) request(bx);
+  for (int t = bx; t < ntiles; t += gdx) {
     const int y0 = (t / tiles_x) * TSY, x0 = (t % tiles_x) * TSX;
     __syncthreads();                                     // previous tile's gathers are done
 #pragma unroll
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(const float* __rest
       }
     }
     __syncthreads();
-    if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);
+    if (t + gdx < ntiles) request(t + gdx);
     const int gx = x0 + px;
 #pragma unroll 2
     for (int j = 0; j < TSY / 4; ++j) {
@@ -256,19 +267,50 @@ extern "C" int ld_pack_stem_weight(const float* w_oihw, void* out_packed, int Ci
   return LD_OK;
 }
 
-extern "C" int ld_conv_stem(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H,
-                            int W, int dtype, void* stream) {
+namespace {
+int stem_launch(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H, int W, int dtype,
+                const StepBeginDev* sb, void* stream) {
   LD_REQUIRE(x && w_packed && bias && out, "ld_conv_stem: null pointer");
   LD_REQUIRE(ld_dtype_16(dtype), "ld_conv_stem: 16-bit storage only (fp32 uses ld_conv_image), got dtype %d", dtype);
   LD_REQUIRE(Cin >= 1 && Cin <= 3 && B > 0 && H > 0 && W > 0, "ld_conv_stem: bad shape (Cin %d)", Cin);
   const int tiles_x = (W + 15) / 16, tiles_y = (H + 31) / 32, ntiles = tiles_x * tiles_y;
   int G = (512 + B - 1) / B;                             // ~2 persistent workgroups per CU
   if (G > ntiles) G = ntiles;
-  LD_DISPATCH16(dtype, [&] {
-    LD_LAUNCH(conv_stem_mfma_kernel<T>, dim3(G, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
-              (const uint4*)w_packed, bias, (T*)out, B, Cin, H, W, tiles_x, ntiles);
-    return 0;
-  }());
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (sb) {
+    // head-of-step workgroups: 8 stores of 16 bytes per thread, at most 8 workgroups per image
+    long nbeg = ((sb->na + sb->nb) / (256L * 8) + B) / B;
+    if (nbeg < 1) nbeg = 1;
+    if (nbeg > 8) nbeg = 8;
+    LD_DISPATCH16(dtype, [&] {
+      LD_LAUNCH((conv_stem_mfma_kernel<T, true>), dim3(G + (int)nbeg, B), dim3(256), 0, st, x, (const uint4*)w_packed, bias, (T*)out,
+                B, Cin, H, W, tiles_x, ntiles, *sb, (int)nbeg);
+      return 0;
+    }());
+  } else {
+    const StepBeginDev none{};
+    LD_DISPATCH16(dtype, [&] {
+      LD_LAUNCH((conv_stem_mfma_kernel<T, false>), dim3(G, B), dim3(256), 0, st, x, (const uint4*)w_packed, bias, (T*)out,
+                B, Cin, H, W, tiles_x, ntiles, none, 0);
+      return 0;
+    }());
+  }
   LD_LAUNCH_CHECK("conv_stem");
   return LD_OK;
+}
+}  // namespace
+
+extern "C" int ld_conv_stem(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H,
+                            int W, int dtype, void* stream) {
+  return stem_launch(x, w_packed, bias, out, B, Cin, H, W, dtype, nullptr, stream);
+}
+
+extern "C" int ld_conv_stem_begin(const float* x, const void* w_packed, const float* bias, void* out, int B, int Cin, int H,
+                                  int W, int dtype, const ld_step_begin_args* g, void* stream) {
+  LD_REQUIRE(g != nullptr, "ld_conv_stem_begin: null step-begin arguments");
+  if (int rc = ld_step_begin_check(g->zero_a, g->bytes_a, g->zero_b, g->bytes_b, g->t_ptr, g->idx_ptr, g->t_table, g->film_rows,
+                                   g->row_floats, g->film_cur)) return rc;
+  const StepBeginDev sb{(uint4*)g->zero_a, (long)(g->bytes_a / 16), (uint4*)g->zero_b, (long)(g->bytes_b / 16), g->t_ptr, g->delta,
+                        g->idx_ptr, g->t_table, g->film_rows, g->row_floats, g->film_cur};
+  return stem_launch(x, w_packed, bias, out, B, Cin, H, W, dtype, &sb, stream);
 }

@@ -45,33 +45,9 @@ __global__ void step_add_kernel(int* t, int delta) { if (threadIdx.x == 0 && blo
 // from the [T, row_floats] table into a fixed buffer, so that the ~20 launches of a step that apply FiLM read it from a
 // known address instead of first loading the step counter and then the row it selects -- one dependent global round trip
 // less at the head of every workgroup of those launches.  Block 0 does it: it is the one that knows the new timestep.
-__global__ void step_begin_kernel(uint4* a, long na, uint4* b, long nb, int* t, int delta, int* idx, const int* t_table,
-                                  const float* film_rows, int row_floats, float* film_cur) {
+__global__ void step_begin_kernel(StepBeginDev sb) {
   __shared__ int s_t;
-  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  GRID_STRIDE(i, na) a[i] = z;
-  GRID_STRIDE(i, nb) b[i] = z;
-  if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) {
-      int tn = t ? *t : 0;
-      if (idx && t_table) {               // strided (DDIM) sampling: advance the pair counter, look the timestep up
-        const int k = *idx + 1;
-        *idx = k;
-        tn = t_table[k];
-        if (t) *t = tn;
-      } else if (t && delta != 0) {
-        tn += delta;
-        *t = tn;
-      }
-      s_t = tn;
-    }
-    if (film_rows) {                      // (uniform)
-      __syncthreads();
-      const float4* src = reinterpret_cast<const float4*>(film_rows + (size_t)s_t * row_floats);
-      float4* dst = reinterpret_cast<float4*>(film_cur);
-      for (int i = threadIdx.x; i < row_floats / 4; i += blockDim.x) dst[i] = src[i];
-    }
-  }
+  step_begin_work(sb, blockIdx.x, gridDim.x, &s_t);
 }
 
 // ---------------------------------------------------------------- DDPM / DDIM steps
@@ -390,13 +366,8 @@ extern "C" int ld_step_add(int32_t* t_ptr, int delta, void* stream) {
   LD_LAUNCH_CHECK("step_add");
   return LD_OK;
 }
-extern "C" int ld_step_begin(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
-                             int32_t* idx_ptr, const int32_t* t_table, void* stream) {
-  return ld_step_begin_film(zero_a, bytes_a, zero_b, bytes_b, t_ptr, delta, idx_ptr, t_table, nullptr, 0, nullptr, stream);
-}
-extern "C" int ld_step_begin_film(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
-                                  int32_t* idx_ptr, const int32_t* t_table, const float* film_rows, int row_floats,
-                                  float* film_cur, void* stream) {
+int ld_step_begin_check(const void* zero_a, size_t bytes_a, const void* zero_b, size_t bytes_b, const void* t_ptr, const void* idx_ptr,
+                        const void* t_table, const void* film_rows, int row_floats, const void* film_cur) {
   LD_REQUIRE((idx_ptr == nullptr) == (t_table == nullptr), "ld_step_begin: idx_ptr and t_table go together");
   LD_REQUIRE((film_rows == nullptr) == (film_cur == nullptr), "ld_step_begin_film: film_rows and film_cur go together");
   LD_REQUIRE(!film_rows || (t_ptr && row_floats > 0 && row_floats % 4 == 0 && ((size_t)film_rows % 16) == 0 && ((size_t)film_cur % 16) == 0),
@@ -404,9 +375,19 @@ extern "C" int ld_step_begin_film(void* zero_a, size_t bytes_a, void* zero_b, si
   LD_REQUIRE((zero_a || bytes_a == 0) && (zero_b || bytes_b == 0), "ld_step_begin: null arena");
   LD_REQUIRE(bytes_a % 16 == 0 && bytes_b % 16 == 0 && ((size_t)zero_a % 16) == 0 && ((size_t)zero_b % 16) == 0,
              "ld_step_begin: arenas must be 16-byte aligned and sized");
+  return LD_OK;
+}
+extern "C" int ld_step_begin(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
+                             int32_t* idx_ptr, const int32_t* t_table, void* stream) {
+  return ld_step_begin_film(zero_a, bytes_a, zero_b, bytes_b, t_ptr, delta, idx_ptr, t_table, nullptr, 0, nullptr, stream);
+}
+extern "C" int ld_step_begin_film(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_b, int32_t* t_ptr, int delta,
+                                  int32_t* idx_ptr, const int32_t* t_table, const float* film_rows, int row_floats,
+                                  float* film_cur, void* stream) {
+  if (int rc = ld_step_begin_check(zero_a, bytes_a, zero_b, bytes_b, t_ptr, idx_ptr, t_table, film_rows, row_floats, film_cur)) return rc;
   const long na = (long)(bytes_a / 16), nb = (long)(bytes_b / 16);
-  LD_LAUNCH(step_begin_kernel, dim3(nblocks(na + nb + 1)), dim3(BS), 0, ST(stream), (uint4*)zero_a, na, (uint4*)zero_b, nb,
-            t_ptr, delta, idx_ptr, t_table, film_rows, row_floats, film_cur);
+  const StepBeginDev sb{(uint4*)zero_a, na, (uint4*)zero_b, nb, t_ptr, delta, idx_ptr, t_table, film_rows, row_floats, film_cur};
+  LD_LAUNCH(step_begin_kernel, dim3(nblocks(na + nb + 1)), dim3(BS), 0, ST(stream), sb);
   LD_LAUNCH_CHECK("step_begin");
   return LD_OK;
 }

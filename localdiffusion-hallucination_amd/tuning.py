@@ -24,6 +24,7 @@ class Tuning:
     sub_resync_early: int = 1            # ... and in front of each of the first steps
     sub_ahead: int = 2                   # the host enqueues at most this many replayed steps ahead of the GPU (0 = no limit)
     fused_final_step: bool = True        # final_conv + posterior update + noise draw as one launch
+    fused_step_begin: bool = True        # the head-of-step work (arena reset, step counter, FiLM row) inside init_conv's launch (16-bit storage)
     # ---- plan builder (unet.py)
     weight_split_levels: int = 0         # two-term (hi + lo) weights on the first N resolution levels (accuracy mode)
     separate_act: bool = True            # block1's GroupNorm + FiLM + SiLU as its own pass on small, wide maps
@@ -40,7 +41,8 @@ class Tuning:
         "LD_SUB_RESYNC": ("sub_resync", int), "LD_SUB_RESYNC_EARLY": ("sub_resync_early", int),
         "LD_SUB_AHEAD": ("sub_ahead", int), "LD_WEIGHT_SPLIT_LEVELS": ("weight_split_levels", int),
         "LD_SEP_ACT_MAX_PX": ("sep_act_max_px", int), "LD_SEP_ACT_MIN_C": ("sep_act_min_c", int),
-        "LD_NO_FUSED_FINAL": ("fused_final_step", lambda v: False), "LD_NO_SEPARATE_ACT": ("separate_act", lambda v: False),
+        "LD_NO_FUSED_FINAL": ("fused_final_step", lambda v: False), "LD_NO_FUSED_BEGIN": ("fused_step_begin", lambda v: False),
+        "LD_NO_SEPARATE_ACT": ("separate_act", lambda v: False),
         "LD_NO_FUSION_FOLD": ("fusion_fold", lambda v: False),
         "LD_LINATTN_CHUNK_PX": ("linattn_chunk_px", lambda v: tuple(int(x) for x in (v.split(",") * 3)[:3])),
     }

@@ -720,6 +720,14 @@ class _Plan:
         if self.dt != cabi.LD_F32 and cfg.init_dim == 32:        # implicit GEMM on MFMA (hi/lo split: fp32-accurate)
             wstem = self.P["stem"]
             self.keep.append(wstem)
+
+            def stem_begin(st, delta, idx_ptr, t_table):        # init_conv + the head-of-step work in ONE launch (ld_conv_stem_begin)
+                za, ba, zb, bb = self._begin_args
+                rows, row_floats, cur = self._film_args
+                g = cabi.StepBeginArgs(za, ba, zb, bb, self._t_dev_ptr, int(delta), idx_ptr, t_table, rows, row_floats, cur)
+                cabi.check(lib.ld_conv_stem_begin(self.x_in.data_ptr(), wstem.data_ptr(), bi.data_ptr(), r.data_ptr(), B, cfg.channels,
+                                                  H, W, self.dt, C.byref(g), st), "init_conv + step_begin")
+            self._stem_begin = stem_begin
             self._raw(ops, lambda st: cabi.check(lib.ld_conv_stem(
                 self.x_in.data_ptr(), wstem.data_ptr(), bi.data_ptr(), r.data_ptr(), B, cfg.channels, H, W, self.dt, st),
                 "init_conv"), "conv_image7x7",
@@ -842,13 +850,17 @@ class _Plan:
         the counter -- one launch where two memsets and ld_step_add were three)."""
         self.lib.ld_range_push(b"step")            # roctx: host-side issue of one denoiser evaluation (or its capture)
         try:
-            if idx_ptr is not None:                # strided sampling: t_dev = t_table[++idx] (ld_step_begin)
+            ops = self.ops_main[:-1] if skip_final else self.ops_main
+            stem_begin = getattr(self, "_stem_begin", None) if self.tn.fused_step_begin else None
+            if stem_begin is not None:             # 16-bit storage: the head-of-step work rides in init_conv's launch
+                stem_begin(st, 0 if idx_ptr is not None else int(step_delta), idx_ptr, t_table)
+                ops = ops[1:]
+            elif idx_ptr is not None:              # strided sampling: t_dev = t_table[++idx] (ld_step_begin)
                 cabi.check(self.lib.ld_step_begin_film(*self._begin_args, self._t_dev_ptr, 0, idx_ptr, t_table, *self._film_args, st),
                            "step_begin")
             else:
                 cabi.check(self.lib.ld_step_begin_film(*self._begin_args, self._t_dev_ptr, int(step_delta), None, None,
                                                        *self._film_args, st), "step_begin")
-            ops = self.ops_main[:-1] if skip_final else self.ops_main
             for op in ops:
                 op(st)
         finally:
