@@ -5,17 +5,17 @@
 
 namespace {
 
-struct Conv3Dev {
+struct Conv3Dev {    // pointers together, scalars together: the argument block arrives in few, wide s_loads (finding 67)
   SrcDev s[2];
-  int nsrc;
   const void* w;
   const float* bias;
   void* out;
   double* ostats;
-  int ogroups;
-  int B, H, W, Cout;
   const int* t_ptr;
   const void* addend;
+  int nsrc;
+  int ogroups;
+  int B, H, W, Cout;
   int tiles_x;
   int wsplit;  // 1: two-term weights (pack.hip): 2*nch virtual chunks, source chunk v >> 1, weight chunk v
   int dbg;     // ablation switches (LD_CONV_DEBUG env, 0 in production): 1 no halo loads, 2 no weight loads, 4 no MFMA, 8 no stores
