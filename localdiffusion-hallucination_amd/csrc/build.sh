@@ -7,7 +7,9 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off"
+# -amdgpu-kernarg-preload-count: leading scalar kernel arguments (up to 14 dwords) arrive in SGPRs with the wave -- no scalar
+# round trip in front of the first requests (docs/findings.md 83); by-value structs are never preloaded
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=16"
 CLEAN=0
 for arg in "$@"; do
   case "$arg" in

@@ -47,7 +47,8 @@ int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   const int tiles_y = (a.H + TR - 1) / TR;
   dim3 grid(d.tiles_x * tiles_y, a.Cout / (16 * MT), a.B);
   if (lds > 65536) LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>, lds));   // cached per device
-  LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>), grid, dim3(SK ? 512 : 256), lds, st, d);
+  LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>), grid, dim3(SK ? 512 : 256), lds, st, d.s[0].data, d.w, d.H, d.W, d.tiles_x,
+            d.s[0].C, d.s[0].ld, d.s[0].ups, d.nsrc, d.wsplit, d.Cout, d);
   LD_LAUNCH_CHECK("conv3x3");
   return LD_OK;
 }

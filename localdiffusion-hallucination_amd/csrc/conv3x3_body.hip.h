@@ -41,9 +41,14 @@ __device__ unsigned long long g_conv_span[1024][2];
 // those scalar tests, branches and register copies sit on the chunk loop's critical path (DESIGN finding 42).
 // The kernel body as a device function of the (virtual) workgroup index: conv3x3_kernel calls it with its own index,
 // the archived stage-program experiment (tools/experiments/stage_programs.hip) with the tiles it takes from its work counter.
+typedef const Conv3Dev __attribute__((address_space(4)))* Conv3KernargPtr;   // the block in kernel-argument (constant) memory: scalar loads
 template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
-__device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, const int by, const int bz, const int gdx, const int gdz,
-                                             char* smem) {
+__device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargPtr rest, const int bx, const int by, const int bz,
+                                             const int gdx, const int gdz, char* smem) {
+  // `head`: the fields the first requests need (conv3x3_kernel's preloaded arguments; everything else unset).  `rest`:
+  // the whole block in kernel-argument memory, read in ONE batch behind those requests (below).  Direct callers that
+  // hold a complete block pass it as `head` and rest = nullptr.
+  Conv3Dev a = head;
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int TR = 4 * NW, TC = 16, HR = TR + 2, HC = TC + 2;
   constexpr int NPIX = HR * HC, NPIXP = (NPIX + 15) / 16 * 16, PLANE = NPIXP * 16;
@@ -56,11 +61,13 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   char* s_x = smem + half * STAGE;
   char* s_w = s_x + 4 * PLANE;
   float* s_coef = reinterpret_cast<float*>(smem + (SK ? 2 : 1) * STAGE);
-  const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
+  // (everything in front of the first requests is computed from the PRELOADED arguments only -- conv3x3_kernel: scalar
+  //  loads return out of order, so the first use of ANY field of the argument block waits for all of it; the fields of
+  //  the second source, the channel total and the chunk count are therefore taken behind issue_loads)
   // fp64 scratch: [4 waves][2][16*MT] per-wave channel sums (also the stripe-reduction scratch of
   // build_gn_coef, 32 doubles).  Per-lane/per-wave partials are fp32 over <= 16*NW values; every
   // sum across waves and workgroups is fp64, so E[x^2]-mean^2 does not see fp32 partial-sum rounding.
-  double* s_stat = reinterpret_cast<double*>(s_coef + 2 * ctot);
+  double* s_stat;
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;   // within the half
   unsigned long long tr_t[24] = {0};
@@ -74,7 +81,8 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   const int H = a.H, W = a.W;
   const int nch0 = a.s[0].C / CK;
   const int ws = a.wsplit;
-  const int nch = (nch0 + (a.nsrc > 1 ? a.s[1].C / CK : 0)) << ws;      // virtual chunks (two per source chunk with two-term weights)
+  int nch = 0;                                          // virtual chunks (two per source chunk with two-term weights)
+  if constexpr (SK) nch = (nch0 + (a.nsrc > 1 ? a.s[1].C / CK : 0)) << ws;
   const int mt_total = a.Cout / 16;
   const uint4* wg = reinterpret_cast<const uint4*>(a.w);
 
@@ -116,12 +124,35 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
     }
     sbase0 = src_base(a.s[0], hoffb0);
     sbase1 = sbase0;
-    if (a.nsrc > 1) sbase1 = src_base(a.s[1], hoffb1);
-    else {
+    if constexpr (SK) {                                   // (SK: half 1's first chunk may belong to the second source)
+      if (a.nsrc > 1) sbase1 = src_base(a.s[1], hoffb1);
+      else {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) hoffb1[it] = hoffb0[it];
+      }
+    }
+  }
+  auto second_source = [&]() {                            // behind the first requests (non-SK): see the note at s_coef
+    if (a.nsrc > 1) {
+      auto src_base1 = [&](const SrcDev& S) -> const char* {
+        const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
+        const int row0 = S.ups ? (ty0 - 1) >> 1 : ty0 - 1, col0 = S.ups ? (tx0 - 1) >> 1 : tx0 - 1;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int q = (it * 4 + wv) * 16 + px;
+          const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;
+          const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
+          const int r = (S.ups ? gy >> 1 : gy) - row0, c = (S.ups ? gx >> 1 : gx) - col0;
+          hoffb1[it] = (__umul24(__umul24(r, Ws) + c, S.ld) + kq * E) * (unsigned)sizeof(T);
+        }
+        return reinterpret_cast<const char*>(S.data) + (((long)b * Hs + row0) * Ws + col0) * S.ld * (long)sizeof(T);
+      };
+      sbase1 = src_base1(a.s[1]);
+    } else {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) hoffb1[it] = hoffb0[it];
     }
-  }
+  };
   unsigned woffb[WU];                                   // byte offsets into a chunk's packed weights; ~0u = none
 #pragma unroll
   for (int k = 0; k < WU; ++k) {
@@ -130,9 +161,10 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
     woffb[k] = (u < UNITS && !(DBG & 2)) ? (__umul24(tap, mt_total) + m0) * 1024u + r * 16u : ~0u;
   }
   const long wstride = 9L * mt_total * 1024;            // bytes per chunk
-  auto issue_loads = [&](int ch, uint4 (&hx)[ITER], uint4 (&wx)[WU]) {
+  auto issue_loads = [&](int ch, uint4 (&hx)[ITER], uint4 (&wx)[WU], auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;    // chunk 0 of the first source: nothing of the second source is touched
     const int cs = ch >> ws;                              // source chunk of this (virtual) chunk
-    const int si = cs >= nch0 ? 1 : 0;
+    const int si = FIRST ? 0 : (cs >= nch0 ? 1 : 0);
     const char* sp = (si ? sbase1 : sbase0) + (long)(cs - si * nch0) * CK * (long)sizeof(T);
     // two-term weights: the lo pass (odd virtual chunk) multiplies the SAME halo tile, which is still in LDS
     const bool same_halo = !SK && !DEEP && ws && (ch & 1);
@@ -146,7 +178,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         hx[it] = make_uint4(0u, 0u, 0u, 0u);
-        if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sp + (si ? hoffb1[it] : hoffb0[it]));
+        if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sp + (FIRST ? hoffb0[it] : (si ? hoffb1[it] : hoffb0[it])));
       }
     }
   };
@@ -187,8 +219,33 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   };
 
   TR_STAMP(1);
-  if (!SK || half < nch) issue_loads(half, hxA, wxA);     // half h owns chunks h, h+2, ...
+  if constexpr (SK) { if (half < nch) issue_loads(half, hxA, wxA, std::false_type{}); }     // half h owns chunks h, h+2, ...
+  else issue_loads(0, hxA, wxA, std::true_type{});
   TR_STAMP(2);
+  if (rest) {
+    // the pointer is laundered HERE: loads through it cannot be hoisted in front of the requests above (scalar loads
+    // return out of order -- a wait for any of them is a wait for all of them)
+    Conv3KernargPtr pr = rest;
+    asm volatile("" : "+s"(pr));
+    a.s[1].data = pr->s[1].data; a.s[1].stats = pr->s[1].stats; a.s[1].gamma = pr->s[1].gamma; a.s[1].beta = pr->s[1].beta;
+    a.s[1].film = pr->s[1].film; a.s[1].C = pr->s[1].C; a.s[1].ld = pr->s[1].ld; a.s[1].ups = pr->s[1].ups;
+    a.s[1].groups = pr->s[1].groups; a.s[1].act = pr->s[1].act; a.s[1].film_tstride = pr->s[1].film_tstride;
+    a.s[1].film_bstride = pr->s[1].film_bstride;
+    a.s[0].stats = pr->s[0].stats; a.s[0].gamma = pr->s[0].gamma; a.s[0].beta = pr->s[0].beta; a.s[0].film = pr->s[0].film;
+    a.s[0].groups = pr->s[0].groups; a.s[0].act = pr->s[0].act; a.s[0].film_tstride = pr->s[0].film_tstride;
+    a.s[0].film_bstride = pr->s[0].film_bstride;
+    a.bias = pr->bias; a.out = pr->out; a.ostats = pr->ostats; a.t_ptr = pr->t_ptr; a.addend = pr->addend;
+    a.ogroups = pr->ogroups; a.B = pr->B; a.dbg = pr->dbg;
+  }
+  if constexpr (!SK) second_source();
+  {
+    const int c1 = a.nsrc > 1 ? a.s[1].C : 0;
+    nch = (nch0 + c1 / CK) << ws;
+    s_stat = reinterpret_cast<double*>(s_coef + 2 * (a.s[0].C + c1));
+  }
+  // the rest of the argument block in ONE scalar batch
+  asm volatile("" ::"s"(a.bias), "s"(a.out), "s"(a.ostats), "s"(a.ogroups), "s"(a.addend), "s"(a.s[1].C), "s"(a.s[1].ld), "s"(a.s[1].ups),
+               "s"(a.s[1].data), "s"(a.s[0].stats), "s"(a.s[0].gamma), "s"(a.s[0].beta), "s"(a.s[0].film), "s"(a.s[0].groups), "s"(a.s[0].act));
   float4 bias[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + (m0 + m) * 16 + kq * 4);
@@ -257,7 +314,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
       if ((k & 1) == half) {         // staging phase: chunk k (mine) into my buffers, request chunk k+2
         if (k < nch) {
           write_lds(k, hxA, wxA);
-          if (k + 2 < nch) issue_loads(k + 2, hxA, wxA);
+          if (k + 2 < nch) issue_loads(k + 2, hxA, wxA, std::false_type{});
         }
       } else if (k >= 1) {           // matrix phase: chunk k-1 (mine, staged in the previous interval)
         compute();
@@ -294,7 +351,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
       __syncthreads();
       if (ch == 0) TR_STAMP(6);
       if (ch == 2) TR_STAMP(13);
-      if (ch + 1 < nch) issue_loads(ch + 1, hxA, wxA);
+      if (ch + 1 < nch) issue_loads(ch + 1, hxA, wxA, std::false_type{});
       if (ch == 2) TR_STAMP(14);
       compute();
       if (ch == 0) TR_STAMP(7);
@@ -304,18 +361,18 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   } else {
     // prefetch distance 2 with two register sets (the launches that use this variant run one wave per SIMD,
     // so the 512-entry register file is theirs): chunk k+2 is requested before chunk k is computed
-    if (nch > 1) issue_loads(1, hxB, wxB);
+    if (nch > 1) issue_loads(1, hxB, wxB, std::false_type{});
     for (int ch = 0; ch < nch; ch += 2) {
       __syncthreads();
       write_lds(ch, hxA, wxA);
       __syncthreads();
-      if (ch + 2 < nch) issue_loads(ch + 2, hxA, wxA);
+      if (ch + 2 < nch) issue_loads(ch + 2, hxA, wxA, std::false_type{});
       compute();
       if (ch + 1 < nch) {
         __syncthreads();
         write_lds(ch + 1, hxB, wxB);
         __syncthreads();
-        if (ch + 3 < nch) issue_loads(ch + 3, hxB, wxB);
+        if (ch + 3 < nch) issue_loads(ch + 3, hxB, wxB, std::false_type{});
         compute();
       }
     }
@@ -496,15 +553,30 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& a, const int bx, co
   }
 }
 
+// What the first requests of a workgroup need -- the first source, the weights, the geometry: 13 dwords -- are leading
+// SCALAR kernel arguments: the file is built with -amdgpu-kernarg-preload-count, so the command processor puts them
+// (up to 14 dwords) into SGPRs before the wave starts and the halo / weight requests leave without a scalar round trip
+// in front of them (a by-value struct is never preloaded: finding 67).  The rest of the block (`rest`: second source,
+// GroupNorm operands, bias, outputs) is fetched in ONE batch that is pinned BEHIND those requests (conv3x3_tile).
 template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
-__global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(SK ? 2 : (MT == 2 ? 3 : 1), SK ? 2 : (MT == 2 ? 3 : 2)))) void conv3x3_kernel(Conv3Dev a) {
+__global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(SK ? 2 : (MT == 2 ? 3 : 1), SK ? 2 : (MT == 2 ? 3 : 2))))
+void conv3x3_kernel(const void* data0, const void* w, int H, int W, int tiles_x, int C0, int ld0, int ups0, int nsrc, int wsplit, int Cout,
+                    Conv3Dev rest) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // Every scalar argument the setup needs, requested in ONE batch: left to itself hipcc loads the argument block in
-  // four or five dependent batches (s_load ... s_waitcnt lgkmcnt(0), each ~200 cycles) spread over the address arithmetic.
-  asm volatile("" ::"s"(a.H), "s"(a.W), "s"(a.Cout), "s"(a.tiles_x), "s"(a.nsrc), "s"(a.wsplit), "s"(a.s[0].C), "s"(a.s[0].ld),
-               "s"(a.s[0].ups), "s"(a.s[0].data), "s"(a.s[1].C), "s"(a.s[1].ld), "s"(a.s[1].ups), "s"(a.s[1].data), "s"(a.w),
-               "s"(a.bias), "s"(a.out));
-  conv3x3_tile<T, MT, NW, DEEP, DBG, SK, RAW>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z, smem);
+  Conv3Dev a{};
+  a.s[0].data = data0; a.w = w; a.H = H; a.W = W; a.tiles_x = tiles_x; a.s[0].C = C0; a.s[0].ld = ld0; a.s[0].ups = ups0;
+  a.nsrc = nsrc; a.wsplit = wsplit; a.Cout = Cout;
+  // `rest` in kernel-argument memory: behind the two pointers and nine ints, at the struct's 8-byte alignment
+  constexpr unsigned REST_OFF = (2 * 8 + 9 * 4 + 7) & ~7u;
+  typedef const char __attribute__((address_space(4)))* KChar;
+  Conv3KernargPtr pr = (Conv3KernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF);
+  if constexpr (SK) {       // (the split-K variant sets its second source up in front of its first requests: whole block now)
+    a = rest;
+    a.tiles_x = tiles_x;
+    conv3x3_tile<T, MT, NW, DEEP, DBG, SK, RAW>(a, nullptr, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z, smem);
+  } else {
+    conv3x3_tile<T, MT, NW, DEEP, DBG, SK, RAW>(a, pr, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z, smem);
+  }
 }
 
 }  // namespace
