@@ -37,9 +37,14 @@ struct KvCtxArgs {
   const float* kshift;  // optional [heads*32]: softmax_n(k) shift per k-channel (>= max_n k): single-sweep mode
   int wsplit;           // 1: two-term weights (wave-per-head kernel, C = 32 / 64)
 };
+// The kernels take the 13 dwords as SCALAR arguments: all of them are preloaded into SGPRs with the wave (finding 83) --
+// no scalar round trip in front of the first requests.  A by-value struct is never preloaded.
+#define KVCTX_PARAMS const void* x_, const uint4* wkv_, float* ctx_part_, int n_, int C_, int heads_, int nchunks_, const float* kshift_, int wsplit_
+#define KVCTX_ARGS(a) (a).x, (a).wkv, (a).ctx_part, (a).n, (a).C, (a).heads, (a).nchunks, (a).kshift, (a).wsplit
 
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void kvctx_kernel(KvCtxArgs a) {
+__global__ __launch_bounds__(256) void kvctx_kernel(KVCTX_PARAMS) {
+  const KvCtxArgs a{x_, wkv_, ctx_part_, n_, C_, heads_, nchunks_, kshift_, wsplit_};
   constexpr int PLANE = KTN * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_x = smem;                                     // [NCH][4][KTN][16 B]
@@ -209,7 +214,8 @@ constexpr int SROW = 32;                  // pixels per wave-private P/V strip (
 // SINGLE (caller-supplied shift): the max sweep, its registers and its code are compiled out.
 // WS = 1: two-term weights (ld_pack_conv_weight_terms): 2 * NCH weight chunks, chunk v multiplies x chunk v >> 1.
 template <typename T, int NCH, bool SINGLE, int WS = 0>
-__global__ __launch_bounds__(256) void kvctx_wph_kernel(KvCtxArgs a) {
+__global__ __launch_bounds__(256) void kvctx_wph_kernel(KVCTX_PARAMS) {
+  const KvCtxArgs a{x_, wkv_, ctx_part_, n_, C_, heads_, nchunks_, kshift_, wsplit_};
   constexpr int NCW = NCH << WS;                        // weight chunks
   constexpr int PLANE = KTN * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -421,9 +427,15 @@ struct LinOutArgs {
   const float* qshift;   // optional [4]: per head an upper bound of q (softmax_d shift): skips the max reduction
   int wsplit;            // 1: two-term W_q (C = 32 / 64)
 };
+// scalar kernel arguments, what the head's requests need first: 14 dwords are preloaded (finding 83); out / q_scale / wsplit
+// arrive by an ordinary scalar load that nothing in the head waits for
+#define LINOUT_PARAMS const void* x_, const uint4* wq_, const uint4* mfold_, const float* bias_, const float* g2_, const float* qshift_, \
+                      int n_, int C_, void* out_, float q_scale_, int wsplit_
+#define LINOUT_ARGS(a) (a).x, (a).wq, (a).mfold, (a).bias, (a).g2, (a).qshift, (a).n, (a).C, (a).out, (a).q_scale, (a).wsplit
 
 template <typename T, int NCH, int WS = 0>
-__global__ __launch_bounds__(256) void linout_kernel(LinOutArgs a) {
+__global__ __launch_bounds__(256) void linout_kernel(LINOUT_PARAMS) {
+  const LinOutArgs a{x_, wq_, mfold_, bias_, g2_, out_, n_, C_, q_scale_, qshift_, wsplit_};
   constexpr int NW = 2, NPT = 64 * NW, PLANE = NPT * 16, MT2 = 2 * NCH;
   constexpr int NCW = NCH << WS;                         // weight chunks of W_q (two per x chunk with two-term weights)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -608,23 +620,23 @@ int kvctx_launch(const KvCtxArgs& a, int B, hipStream_t st) {
     if (a.wsplit) {                                        // two-term weights: the full- and half-resolution blocks
       LD_REQUIRE(nch <= 2, "ld_linattn_kvctx: two-term weights are built for C = 32 / 64 (got %d)", a.C);
       if (nch == 1) {
-        if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 1, true, 1>), grid2, dim3(256), lds2, st, a);
-        else LD_LAUNCH((kvctx_wph_kernel<T, 1, false, 1>), grid2, dim3(256), lds2, st, a);
+        if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 1, true, 1>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
+        else LD_LAUNCH((kvctx_wph_kernel<T, 1, false, 1>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
       } else {
-        if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 2, true, 1>), grid2, dim3(256), lds2, st, a);
-        else LD_LAUNCH((kvctx_wph_kernel<T, 2, false, 1>), grid2, dim3(256), lds2, st, a);
+        if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 2, true, 1>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
+        else LD_LAUNCH((kvctx_wph_kernel<T, 2, false, 1>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
       }
     } else if (nch == 1) {
-      if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 1, true>), grid2, dim3(256), lds2, st, a);
-      else LD_LAUNCH((kvctx_wph_kernel<T, 1, false>), grid2, dim3(256), lds2, st, a);
+      if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 1, true>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
+      else LD_LAUNCH((kvctx_wph_kernel<T, 1, false>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
     } else if (nch == 2) {
-      if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 2, true>), grid2, dim3(256), lds2, st, a);
-      else LD_LAUNCH((kvctx_wph_kernel<T, 2, false>), grid2, dim3(256), lds2, st, a);
+      if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 2, true>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
+      else LD_LAUNCH((kvctx_wph_kernel<T, 2, false>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
     } else {
       if (kshift) LD_HIP(ld_allow_lds((kvctx_wph_kernel<T, 4, true>), lds2));      // cached per device
       else LD_HIP(ld_allow_lds((kvctx_wph_kernel<T, 4, false>), lds2));
-      if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 4, true>), grid2, dim3(256), lds2, st, a);
-      else LD_LAUNCH((kvctx_wph_kernel<T, 4, false>), grid2, dim3(256), lds2, st, a);
+      if (kshift) LD_LAUNCH((kvctx_wph_kernel<T, 4, true>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
+      else LD_LAUNCH((kvctx_wph_kernel<T, 4, false>), grid2, dim3(256), lds2, st, KVCTX_ARGS(a));
     }
     LD_LAUNCH_CHECK("linattn_kvctx(wave-per-head)");
     return LD_OK;
@@ -633,13 +645,13 @@ int kvctx_launch(const KvCtxArgs& a, int B, hipStream_t st) {
   dim3 grid(nchunks, heads, B);
   const size_t lds = (size_t)nch * 4 * KTN * 16 + 2 * KTN * PROW + KTN * sizeof(float) + 128 * sizeof(float);
   if (nch == 1) {
-    LD_LAUNCH((kvctx_kernel<T, 1>), grid, dim3(256), lds, st, a);
+    LD_LAUNCH((kvctx_kernel<T, 1>), grid, dim3(256), lds, st, KVCTX_ARGS(a));
   } else if (nch == 2) {
     LD_HIP(ld_allow_lds((kvctx_kernel<T, 2>), lds));
-    LD_LAUNCH((kvctx_kernel<T, 2>), grid, dim3(256), lds, st, a);
+    LD_LAUNCH((kvctx_kernel<T, 2>), grid, dim3(256), lds, st, KVCTX_ARGS(a));
   } else {
     LD_HIP(ld_allow_lds((kvctx_kernel<T, 4>), lds));
-    LD_LAUNCH((kvctx_kernel<T, 4>), grid, dim3(256), lds, st, a);
+    LD_LAUNCH((kvctx_kernel<T, 4>), grid, dim3(256), lds, st, KVCTX_ARGS(a));
   }
   LD_LAUNCH_CHECK("linattn_kvctx");
   return LD_OK;
@@ -652,15 +664,15 @@ int linout_launch(const LinOutArgs& a, int B, hipStream_t st) {
   const size_t lds = (size_t)nch * 4 * 128 * 16 + ((size_t)nch << a.wsplit) * 8 * 1024 + (size_t)4 * 2 * nch * 1024 + 128 * sizeof(float);
   if (a.wsplit) {
     LD_REQUIRE(nch <= 2, "ld_linattn_out: two-term weights are built for C = 32 / 64 (got %d)", a.C);
-    if (nch == 1) LD_LAUNCH((linout_kernel<T, 1, 1>), grid, dim3(256), lds, st, a);
-    else LD_LAUNCH((linout_kernel<T, 2, 1>), grid, dim3(256), lds, st, a);
+    if (nch == 1) LD_LAUNCH((linout_kernel<T, 1, 1>), grid, dim3(256), lds, st, LINOUT_ARGS(a));
+    else LD_LAUNCH((linout_kernel<T, 2, 1>), grid, dim3(256), lds, st, LINOUT_ARGS(a));
   } else if (nch == 1) {
-    LD_LAUNCH((linout_kernel<T, 1>), grid, dim3(256), lds, st, a);
+    LD_LAUNCH((linout_kernel<T, 1>), grid, dim3(256), lds, st, LINOUT_ARGS(a));
   } else if (nch == 2) {
-    LD_LAUNCH((linout_kernel<T, 2>), grid, dim3(256), lds, st, a);
+    LD_LAUNCH((linout_kernel<T, 2>), grid, dim3(256), lds, st, LINOUT_ARGS(a));
   } else {
     LD_HIP(ld_allow_lds((linout_kernel<T, 4>), lds));
-    LD_LAUNCH((linout_kernel<T, 4>), grid, dim3(256), lds, st, a);
+    LD_LAUNCH((linout_kernel<T, 4>), grid, dim3(256), lds, st, LINOUT_ARGS(a));
   }
   LD_LAUNCH_CHECK("linattn_out");
   return LD_OK;
