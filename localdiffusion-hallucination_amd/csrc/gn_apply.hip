@@ -24,7 +24,16 @@ int run(const GnDev& g, hipStream_t st) {
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks, g.B);
   const size_t lds = 4 * g.a.C * sizeof(float) + 64 * sizeof(double);
-  if (g.has_b) {
+  // the sampling loop's launches: preloaded leading arguments (gn_apply_lead_kernel)
+  const bool lead = !g.pool && !g.t_ptr && g.a.film_bstride == 0 && !(g.has_b && g.b.stats) && g.a.C < 1024 && g.a.groups < 64 &&
+                    (long)g.H * g.W < (1L << 31) && 256 % (g.a.C / E) == 0;
+  if (lead) {
+    const int cg = g.a.C | (g.a.groups << 10) | ((int)blocks << 16), hw = g.H * g.W;     // blocks <= 2048
+    if (g.has_b) LD_LAUNCH((gn_apply_lead_kernel<T, true>), grid, dim3(256), lds, st, g.a.data, g.b.data, g.a.stats, g.a.gamma, g.a.beta,
+                           g.a.film, cg, hw, g);
+    else LD_LAUNCH((gn_apply_lead_kernel<T, false>), grid, dim3(256), lds, st, g.a.data, g.b.data, g.a.stats, g.a.gamma, g.a.beta,
+                   g.a.film, cg, hw, g);
+  } else if (g.has_b) {
     if (g.pool) LD_LAUNCH((gn_apply_kernel<T, true, true>), grid, dim3(256), lds, st, g);
     else LD_LAUNCH((gn_apply_kernel<T, true, false>), grid, dim3(256), lds, st, g);
   } else {

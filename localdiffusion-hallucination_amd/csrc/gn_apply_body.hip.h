@@ -47,9 +47,14 @@ __device__ __forceinline__ void eval_pixel(const GnDev& g, const float* ca, cons
 
 // The kernel body as a device function of the (virtual) workgroup index (gn_apply_kernel: its own index; tools/experiments/stage_programs.hip: the
 // blocks a persistent workgroup takes from its work counter).  bx / gdx: block and number of blocks of image `b`.
+typedef const GnDev __attribute__((address_space(4)))* GnKernargPtr;   // the block in kernel-argument (constant) memory
+// `rest` (gn_apply_lead_kernel): `head` holds only what the head's requests need (preloaded kernel arguments); the
+// activation kinds and the output pointer are read from the block BEHIND those requests (finding 83).
 template <typename T, bool HAS_B, bool POOL>
-__device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, const int gdx, const int b, float* s_coef) {
+__device__ __forceinline__ void gn_apply_tile(const GnDev& head, const int bx, const int gdx, const int b, float* s_coef,
+                                              GnKernargPtr rest = nullptr) {
   constexpr int E = DT<T>::E;
+  GnDev g = head;
   const int C = g.a.C, tid = threadIdx.x;
   const int trow = g.t_ptr ? *g.t_ptr : 0;
   const long npix_in = (long)g.H * g.W;
@@ -57,7 +62,6 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, cons
   const int fpp = C / E;                               // fragments per pixel
   const int Ho = POOL ? g.H / 2 : g.H, Wo = POOL ? g.W / 2 : g.W;
   const int npix_out = Ho * Wo;
-  T* out = reinterpret_cast<T*>(g.out) + (size_t)b * npix_out * C;
   const size_t in0 = (size_t)b * npix_in * C;
   // The thread's first pixel pair is requested BEFORE the coefficients are built: the data does not depend on them,
   // and behind them it was a second dependent round trip in a launch that is two round trips long (nearly every
@@ -78,6 +82,12 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, cons
   }
   build_gn_coef<DT<T>::precise>(g.a, b, trow, npix_in, s_coef, red, tid, 256);
   if (HAS_B && g.b.stats) build_gn_coef<DT<T>::precise>(g.b, b, trow, npix_in, s_coef + 2 * C, red, tid, 256);
+  if (rest) {
+    GnKernargPtr pr = rest;
+    asm volatile("" : "+s"(pr));
+    g.a.act = pr->a.act; g.b.act = pr->b.act; g.final_act = pr->final_act; g.out = pr->out;
+  }
+  T* out = reinterpret_cast<T*>(g.out) + (size_t)b * npix_out * C;
   auto one = [&](int opix, int c, const float* ca, const float* sa, const float* cb, const float* sb) {
     float v[E];
     if (!POOL) {
@@ -147,6 +157,25 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& g, const int bx, cons
       one(opix, c, s_coef + c, s_coef + C + c, s_coef + 2 * C + c, s_coef + 3 * C + c);
     }
   }
+}
+
+// The launches of the sampling loop (no pooling, one normalised operand, FiLM shared by the batch, no step counter):
+// 14 leading scalar dwords -- both operands, the GroupNorm tables, C | groups << 10 | gridDim.x << 16 (the grid size is a
+// HIDDEN kernel argument: read through gridDim it is a scalar load in front of everything), pixels per image -- are
+// preloaded into SGPRs with the wave, so the pixel requests and the coefficient requests leave without a scalar round trip.
+template <typename T, bool HAS_B>
+__global__ __launch_bounds__(256) void gn_apply_lead_kernel(const void* a_data, const void* b_data, const double* a_stats, const float* a_gamma,
+                                                            const float* a_beta, const float* a_film, int c_groups, int hw, GnDev rest) {
+  extern __shared__ __attribute__((aligned(16))) float s_coef[];
+  GnDev g{};
+  g.a.data = a_data; g.a.stats = a_stats; g.a.gamma = a_gamma; g.a.beta = a_beta; g.a.film = a_film;
+  g.a.C = c_groups & 0x3ff; g.a.groups = (c_groups >> 10) & 0x3f; g.a.ld = g.a.C;
+  g.b.data = b_data; g.b.C = g.a.C; g.b.ld = g.a.C;
+  g.has_b = HAS_B; g.H = hw; g.W = 1;
+  constexpr unsigned REST_OFF = 6 * 8 + 2 * 4;          // six pointers, two ints; GnDev is 8-byte aligned
+  typedef const char __attribute__((address_space(4)))* KChar;
+  gn_apply_tile<T, HAS_B, false>(g, blockIdx.x, (int)((unsigned)c_groups >> 16), blockIdx.y, s_coef,
+                                 (GnKernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF));
 }
 
 template <typename T, bool HAS_B, bool POOL>
