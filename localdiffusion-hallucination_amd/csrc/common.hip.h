@@ -375,9 +375,12 @@ static inline SrcDev to_dev(const ld_src& s) {
 // PRECISE (fp32 storage, the parity mode): IEEE fp64 divide and square root for 1/n and 1/sqrt(var + eps).  16-bit
 // storage: v_rcp_f32 / v_rsq_f32 (1 ulp of fp32 each, four orders below the storage rounding) -- the two fp64 divisions
 // and the square root are ~100 dependent instructions at the head of every consumer workgroup.
-template <bool PRECISE = true>
+// after_issue: called once every request of the head has left and before the first wait -- a caller whose remaining
+// kernel arguments are read late (finding 84) requests them there, under the statistics' round trip.
+struct GnNoHook { __device__ __forceinline__ void operator()() const {} };
+template <bool PRECISE = true, typename F = GnNoHook>
 __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, long npix, float* coef,
-                                              double* red, int tid, int nthreads) {
+                                              double* red, int tid, int nthreads, F after_issue = F()) {
   const int C = S.C, G = S.groups, gs = C / G;
   float* gstat = reinterpret_cast<float*>(red);          // after the stripe sum: [G] mean, [G] rstd (floats)
   // ONE global round trip in front of the arithmetic: gamma / beta / FiLM of this thread's first channel (their addresses
@@ -402,6 +405,7 @@ __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, 
     for (int s = 0; s < LD_STAT_STRIPES; ++s) { st1[s] = p[(size_t)s * G * 2]; st2[s] = p[(size_t)s * G * 2 + 1]; }
     __builtin_amdgcn_sched_barrier(0);
   }
+  after_issue();
   // (opaque from here on: hipcc otherwise computes `f0 + 1` right behind its load, in front of the statistics requests)
   asm volatile("" : "+v"(g0), "+v"(b0), "+v"(f0), "+v"(f1));
   if (tid < G) {

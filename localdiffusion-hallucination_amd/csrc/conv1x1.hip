@@ -47,23 +47,26 @@ struct Conv1Dev {       // what the setup reads first sits together (pointers, t
 // three workgroups still fit a CU; staging the whole K extent at once -- the shelved tools/experiments/ variant of
 // finding 28 -- left one workgroup per CU and lost on the launches with several workgroups per CU).
 constexpr int KG = 4;
-template <typename T, int MT, int NW, int EPI, int G = 1>
-__global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
+typedef const Conv1Dev __attribute__((address_space(4)))* Conv1KernargPtr;   // the block in kernel-argument (constant) memory
+// TLEAD (conv1x1_taillead_kernel, the GroupNorm-tail launches): `head` holds only the tail operand -- preloaded scalar
+// kernel arguments, so the coefficient requests and the second-operand requests leave without a scalar round trip -- and
+// everything else is read from `rest` under the statistics' round trip (build_gn_coef's after_issue hook; finding 84).
+template <typename T, int MT, int NW, int EPI, int G, bool TLEAD>
+__device__ __forceinline__ void conv1x1_body(const Conv1Dev& head, Conv1KernargPtr rest) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int NPT = 64 * NW, PLANE = NPT * 16;
   constexpr int XCH = 4 * PLANE, WCHB = MT * 1024;                    // bytes of one staged chunk: tile, weights
-  // every scalar argument the setup needs, requested in ONE batch (left alone hipcc fetches the block in four dependent ones)
-  asm volatile("" ::"s"(a.H), "s"(a.W), "s"(a.Cout), "s"(a.nsrc), "s"(a.unshuffle), "s"(a.rms_in), "s"(a.wsplit), "s"(a.s[0].C),
-               "s"(a.s[0].ld), "s"(a.s[0].data), "s"(a.s[1].C), "s"(a.s[1].ld), "s"(a.s[1].data), "s"(a.w), "s"(a.w_bstride),
-               "s"(a.res), "s"(a.out));
-  if constexpr (EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES)
-    asm volatile("" ::"s"(a.tail.data), "s"(a.tail.stats), "s"(a.tail.gamma), "s"(a.tail.beta), "s"(a.tail.film), "s"(a.tail.C),
-                 "s"(a.tail.groups), "s"(a.tail.act), "s"(a.tail.film_bstride));
-
-  // K-chunk bookkeeping: plain = chunks of src0 then src1; unshuffle = 4 sub-pixels x chunks of src0
-  const int nc0 = a.s[0].C / CK;
-  const int ws = a.wsplit;
-  const int nch = (a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / CK : 0)) << ws;     // virtual chunks
+  static_assert(!TLEAD || EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES, "tail-lead variant: GroupNorm-tail epilogues only");
+  Conv1Dev a = head;
+  if constexpr (!TLEAD) {
+    // every scalar argument the setup needs, requested in ONE batch (left alone hipcc fetches the block in four dependent ones)
+    asm volatile("" ::"s"(a.H), "s"(a.W), "s"(a.Cout), "s"(a.nsrc), "s"(a.unshuffle), "s"(a.rms_in), "s"(a.wsplit), "s"(a.s[0].C),
+                 "s"(a.s[0].ld), "s"(a.s[0].data), "s"(a.s[1].C), "s"(a.s[1].ld), "s"(a.s[1].data), "s"(a.w), "s"(a.w_bstride),
+                 "s"(a.res), "s"(a.out));
+    if constexpr (EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES)
+      asm volatile("" ::"s"(a.tail.data), "s"(a.tail.stats), "s"(a.tail.gamma), "s"(a.tail.beta), "s"(a.tail.film), "s"(a.tail.C),
+                   "s"(a.tail.groups), "s"(a.tail.act), "s"(a.tail.film_bstride));
+  }
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_x = smem;                                                  // [G][4][PLANE]
@@ -73,11 +76,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, kq = lane >> 4;
   const int b = blockIdx.z, m0 = blockIdx.y * MT;
-  const int HW = a.H * a.W, p0 = blockIdx.x * NPT;
+  const int HW = a.H * a.W, p0 = blockIdx.x * NPT;      // (TLEAD: head.H = pixels, head.W = 1, head.Cout set)
   const int mt_total = a.Cout / 16;
-
-  if (EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES)
-    build_gn_coef<DT<T>::precise>(a.tail, b, 0, (long)HW, s_tcoef, reinterpret_cast<double*>(s_tcoef + 2 * a.Cout), tid, 256);
 
   f32x4 acc[MT][NW];
 #pragma unroll
@@ -129,6 +129,27 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
     }
   };
   if constexpr (HAS_OP2) load_op(reinterpret_cast<const T*>(TAIL ? a.tail.data : a.res), op2);
+  if constexpr (TAIL) {
+    double* red = reinterpret_cast<double*>(s_tcoef + 2 * a.Cout);
+    if constexpr (TLEAD) {
+      build_gn_coef<DT<T>::precise>(a.tail, b, 0, (long)HW, s_tcoef, red, tid, 256, [&]() {
+        Conv1KernargPtr pr = rest;                       // laundered here: read under the statistics' round trip, not in front of it
+        asm volatile("" : "+s"(pr));
+        a.s[0].data = pr->s[0].data; a.s[0].C = pr->s[0].C; a.s[0].ld = pr->s[0].ld;
+        a.s[1].data = pr->s[1].data; a.s[1].C = pr->s[1].C; a.s[1].ld = pr->s[1].ld;
+        a.w = pr->w; a.w_bstride = pr->w_bstride; a.res = pr->res; a.out = pr->out;
+        a.nsrc = pr->nsrc; a.unshuffle = pr->unshuffle; a.rms_in = pr->rms_in; a.H = pr->H; a.W = pr->W;
+        a.wsplit = pr->wsplit; a.hidden = pr->hidden; a.q_scale = pr->q_scale; a.bias = pr->bias; a.g2 = pr->g2; a.kmax = pr->kmax;
+        a.tail.act = pr->tail.act;
+      });
+    } else {
+      build_gn_coef<DT<T>::precise>(a.tail, b, 0, (long)HW, s_tcoef, red, tid, 256);
+    }
+  }
+  // K-chunk bookkeeping: plain = chunks of src0 then src1; unshuffle = 4 sub-pixels x chunks of src0
+  const int nc0 = a.s[0].C / CK;
+  const int ws = a.wsplit;
+  const int nch = (a.unshuffle ? 4 * nc0 : nc0 + (a.nsrc > 1 ? a.s[1].C / CK : 0)) << ws;     // virtual chunks
   const uint4* wg = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w) + (size_t)b * a.w_bstride);
 
   // global address of this thread's fragment of chunk `ch` for tile pixel slot `it` (nullptr: past the image)
@@ -405,6 +426,23 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
   }
 }
 
+template <typename T, int MT, int NW, int EPI, int G = 1>
+__global__ __launch_bounds__(256) void conv1x1_kernel(Conv1Dev a) {
+  conv1x1_body<T, MT, NW, EPI, G, false>(a, nullptr);
+}
+// the GroupNorm-tail launches: the tail operand as 12 preloaded dwords (cout_groups: Cout | groups << 16)
+template <typename T, int MT, int NW, int EPI, int G>
+__global__ __launch_bounds__(256) void conv1x1_taillead_kernel(const void* t_data, const double* t_stats, const float* t_gamma, const float* t_beta,
+                                                               const float* t_film, int cout_groups, int hw, Conv1Dev rest) {
+  Conv1Dev a{};
+  a.tail.data = t_data; a.tail.stats = t_stats; a.tail.gamma = t_gamma; a.tail.beta = t_beta; a.tail.film = t_film;
+  a.Cout = cout_groups & 0xffff; a.tail.C = a.Cout; a.tail.ld = a.Cout; a.tail.groups = (int)((unsigned)cout_groups >> 16);
+  a.H = hw; a.W = 1;
+  constexpr unsigned REST_OFF = 5 * 8 + 2 * 4;          // five pointers, two ints; Conv1Dev is 8-byte aligned
+  typedef const char __attribute__((address_space(4)))* KChar;
+  conv1x1_body<T, MT, NW, EPI, G, true>(a, (Conv1KernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF));
+}
+
 template <typename T, int MT, int NW, int EPI>
 int launch_epi(const Conv1Dev& a, hipStream_t st) {
   constexpr int NPT = 64 * NW;
@@ -412,6 +450,26 @@ int launch_epi(const Conv1Dev& a, hipStream_t st) {
   const size_t chunk = 4 * NPT * 16 + MT * 1024;
   const int HW = a.H * a.W;
   dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
+  // the GroupNorm-tail launches of the sampling loop (FiLM shared by the batch): preloaded tail operand
+  constexpr bool CAN_TLEAD = EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES;
+  const bool tlead = CAN_TLEAD && a.tail.film_bstride == 0 && a.tail.film_tstride == 0 && a.Cout < 65536 && a.tail.groups < 32768 &&
+                     a.tail.C == a.Cout && a.tail.ld == a.Cout && (long)HW < (1L << 31);
+#define LD_C1_TLEAD_ARGS a.tail.data, a.tail.stats, a.tail.gamma, a.tail.beta, a.tail.film, a.Cout | (a.tail.groups << 16), HW, a
+  if constexpr (CAN_TLEAD) {
+    if (tlead && (a.group == KG || a.group == 2)) {
+      const size_t lds = (size_t)a.group * chunk + tail;
+      if (a.group == KG) {
+        if (lds > 65536) LD_HIP(ld_allow_lds((conv1x1_taillead_kernel<T, MT, NW, EPI, KG>), lds));
+        LD_LAUNCH((conv1x1_taillead_kernel<T, MT, NW, EPI, KG>), grid, dim3(256), lds, st, LD_C1_TLEAD_ARGS);
+      } else {
+        if (lds > 65536) LD_HIP(ld_allow_lds((conv1x1_taillead_kernel<T, MT, NW, EPI, 2>), lds));
+        LD_LAUNCH((conv1x1_taillead_kernel<T, MT, NW, EPI, 2>), grid, dim3(256), lds, st, LD_C1_TLEAD_ARGS);
+      }
+      LD_LAUNCH_CHECK("conv1x1(GroupNorm tail, lead)");
+      return LD_OK;
+    }
+  }
+#undef LD_C1_TLEAD_ARGS
   if (a.group == KG) {
     const size_t lds = KG * chunk + tail;
     if (lds > 65536) LD_HIP(ld_allow_lds((conv1x1_kernel<T, MT, NW, EPI, KG>), lds));   // cached per device
