@@ -51,14 +51,19 @@ typedef const Conv1Dev __attribute__((address_space(4)))* Conv1KernargPtr;   // 
 // TLEAD (conv1x1_taillead_kernel, the GroupNorm-tail launches): `head` holds only the tail operand -- preloaded scalar
 // kernel arguments, so the coefficient requests and the second-operand requests leave without a scalar round trip -- and
 // everything else is read from `rest` under the statistics' round trip (build_gn_coef's after_issue hook; finding 84).
-template <typename T, int MT, int NW, int EPI, int G, bool TLEAD>
+template <typename T, int MT, int NW, int EPI, int G, bool TLEAD, bool KLEAD = false>
 __device__ __forceinline__ void conv1x1_body(const Conv1Dev& head, Conv1KernargPtr rest) {
   constexpr int E = DT<T>::E, CK = DT<T>::CK;
   constexpr int NPT = 64 * NW, PLANE = NPT * 16;
   constexpr int XCH = 4 * PLANE, WCHB = MT * 1024;                    // bytes of one staged chunk: tile, weights
   static_assert(!TLEAD || EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES, "tail-lead variant: GroupNorm-tail epilogues only");
   Conv1Dev a = head;
-  if constexpr (!TLEAD) {
+  if constexpr (KLEAD) {
+    // conv1x1_klead_kernel: sources, weights, second operand and geometry are preloaded arguments; what the epilogue
+    // needs is read from the block (invariant scalar loads that nothing in the head waits for)
+    a.out = rest->out; a.bias = rest->bias; a.g2 = rest->g2; a.kmax = rest->kmax; a.hidden = rest->hidden; a.q_scale = rest->q_scale;
+  }
+  if constexpr (!TLEAD && !KLEAD) {
     // every scalar argument the setup needs, requested in ONE batch (left alone hipcc fetches the block in four dependent ones)
     asm volatile("" ::"s"(a.H), "s"(a.W), "s"(a.Cout), "s"(a.nsrc), "s"(a.unshuffle), "s"(a.rms_in), "s"(a.wsplit), "s"(a.s[0].C),
                  "s"(a.s[0].ld), "s"(a.s[0].data), "s"(a.s[1].C), "s"(a.s[1].ld), "s"(a.s[1].data), "s"(a.w), "s"(a.w_bstride),
@@ -443,6 +448,21 @@ __global__ __launch_bounds__(256) void conv1x1_taillead_kernel(const void* t_dat
   conv1x1_body<T, MT, NW, EPI, G, true>(a, (Conv1KernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF));
 }
 
+// the other grouped launches: both sources, the weights, the second operand and the geometry as 14 preloaded dwords
+// (c0_flags: s[0].C | nsrc << 16 | unshuffle << 18 | rms_in << 19 | wsplit << 20; c1_ld1: s[1].C | s[1].ld << 16); code order unchanged
+template <typename T, int MT, int NW, int EPI, int G>
+__global__ __launch_bounds__(256) void conv1x1_klead_kernel(const void* data0, const void* w, const void* data1, const void* res, int H, int W,
+                                                            int Cout, int c0_flags, int ld0, int c1_ld1, Conv1Dev rest) {
+  Conv1Dev a{};
+  a.s[0].data = data0; a.s[0].C = c0_flags & 0xffff; a.s[0].ld = ld0;
+  a.s[1].data = data1; a.s[1].C = c1_ld1 & 0xffff; a.s[1].ld = (int)((unsigned)c1_ld1 >> 16);
+  a.w = w; a.res = res; a.H = H; a.W = W; a.Cout = Cout;
+  a.nsrc = (c0_flags >> 16) & 3; a.unshuffle = (c0_flags >> 18) & 1; a.rms_in = (c0_flags >> 19) & 1; a.wsplit = (c0_flags >> 20) & 1;
+  constexpr unsigned REST_OFF = 4 * 8 + 6 * 4;          // four pointers, six ints; Conv1Dev is 8-byte aligned
+  typedef const char __attribute__((address_space(4)))* KChar;
+  conv1x1_body<T, MT, NW, EPI, G, false, true>(a, (Conv1KernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF));
+}
+
 template <typename T, int MT, int NW, int EPI>
 int launch_epi(const Conv1Dev& a, hipStream_t st) {
   constexpr int NPT = 64 * NW;
@@ -470,6 +490,25 @@ int launch_epi(const Conv1Dev& a, hipStream_t st) {
     }
   }
 #undef LD_C1_TLEAD_ARGS
+  if constexpr (!CAN_TLEAD) {
+    const bool klead = (a.group == KG || a.group == 2) && a.w_bstride == 0 && a.s[0].C < 65536 && a.s[1].C < 65536 && a.s[1].ld < 65536;
+    if (klead) {
+      const int c0f = a.s[0].C | (a.nsrc << 16) | (a.unshuffle ? 1 << 18 : 0) | (a.rms_in ? 1 << 19 : 0) | (a.wsplit ? 1 << 20 : 0);
+      const int c1l = (a.nsrc > 1 ? a.s[1].C : 0) | ((a.nsrc > 1 ? a.s[1].ld : 0) << 16);
+      const size_t lds = (size_t)a.group * chunk + tail;
+#define LD_C1_KLEAD_ARGS a.s[0].data, a.w, a.s[1].data, a.res, a.H, a.W, a.Cout, c0f, a.s[0].ld, c1l, a
+      if (a.group == KG) {
+        if (lds > 65536) LD_HIP(ld_allow_lds((conv1x1_klead_kernel<T, MT, NW, EPI, KG>), lds));
+        LD_LAUNCH((conv1x1_klead_kernel<T, MT, NW, EPI, KG>), grid, dim3(256), lds, st, LD_C1_KLEAD_ARGS);
+      } else {
+        if (lds > 65536) LD_HIP(ld_allow_lds((conv1x1_klead_kernel<T, MT, NW, EPI, 2>), lds));
+        LD_LAUNCH((conv1x1_klead_kernel<T, MT, NW, EPI, 2>), grid, dim3(256), lds, st, LD_C1_KLEAD_ARGS);
+      }
+#undef LD_C1_KLEAD_ARGS
+      LD_LAUNCH_CHECK("conv1x1(grouped K, lead)");
+      return LD_OK;
+    }
+  }
   if (a.group == KG) {
     const size_t lds = KG * chunk + tail;
     if (lds > 65536) LD_HIP(ld_allow_lds((conv1x1_kernel<T, MT, NW, EPI, KG>), lds));   // cached per device
