@@ -101,58 +101,36 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
   unsigned hoffb0[ITER], hoffb1[ITER];                  // byte offsets from sbase0 / sbase1
   const char* sbase0;
   const char* sbase1;
-  {
-    auto src_base = [&](const SrcDev& S, unsigned (&hoffb)[ITER]) -> const char* {
-      const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
-      const int row0 = S.ups ? (ty0 - 1) >> 1 : ty0 - 1, col0 = S.ups ? (tx0 - 1) >> 1 : tx0 - 1;
-#pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int q = (it * 4 + wv) * 16 + px;
-        const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;        // q / 18 for q < 400
-        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
-        const int r = (S.ups ? gy >> 1 : gy) - row0, c = (S.ups ? gx >> 1 : gx) - col0;   // 0 .. HR, 0 .. HC
-        hoffb[it] = (__umul24(__umul24(r, Ws) + c, S.ld) + kq * E) * (unsigned)sizeof(T);
-      }
-      return reinterpret_cast<const char*>(S.data) + (((long)b * Hs + row0) * Ws + col0) * S.ld * (long)sizeof(T);
-    };
+  auto src_base = [&](const SrcDev& S, unsigned (&hoffb)[ITER]) -> const char* {
+    const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
+    const int row0 = S.ups ? (ty0 - 1) >> 1 : ty0 - 1, col0 = S.ups ? (tx0 - 1) >> 1 : tx0 - 1;
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int q = (it * 4 + wv) * 16 + px;
-      const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;
+      const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;        // q / 18 for q < 400
       const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
-      if (q < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && !(DBG & 1)) hvalid |= 1u << it;
+      const int r = (S.ups ? gy >> 1 : gy) - row0, c = (S.ups ? gx >> 1 : gx) - col0;   // 0 .. HR, 0 .. HC
+      hoffb[it] = (__umul24(__umul24(r, Ws) + c, S.ld) + kq * E) * (unsigned)sizeof(T);
     }
-    sbase0 = src_base(a.s[0], hoffb0);
-    sbase1 = sbase0;
-    if constexpr (SK) {                                   // (SK: half 1's first chunk may belong to the second source)
-      if (a.nsrc > 1) sbase1 = src_base(a.s[1], hoffb1);
-      else {
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) hoffb1[it] = hoffb0[it];
-      }
-    }
-  }
-  auto second_source = [&]() {                            // behind the first requests (non-SK): see the note at s_coef
-    if (a.nsrc > 1) {
-      auto src_base1 = [&](const SrcDev& S) -> const char* {
-        const int Hs = S.ups ? H / 2 : H, Ws = S.ups ? W / 2 : W;
-        const int row0 = S.ups ? (ty0 - 1) >> 1 : ty0 - 1, col0 = S.ups ? (tx0 - 1) >> 1 : tx0 - 1;
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-          const int q = (it * 4 + wv) * 16 + px;
-          const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;
-          const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
-          const int r = (S.ups ? gy >> 1 : gy) - row0, c = (S.ups ? gx >> 1 : gx) - col0;
-          hoffb1[it] = (__umul24(__umul24(r, Ws) + c, S.ld) + kq * E) * (unsigned)sizeof(T);
-        }
-        return reinterpret_cast<const char*>(S.data) + (((long)b * Hs + row0) * Ws + col0) * S.ld * (long)sizeof(T);
-      };
-      sbase1 = src_base1(a.s[1]);
-    } else {
+    return reinterpret_cast<const char*>(S.data) + (((long)b * Hs + row0) * Ws + col0) * S.ld * (long)sizeof(T);
+  };
+  auto second_source = [&]() {     // SK: in front of the first requests (half 1's first chunk may belong to it); else behind them (note at s_coef)
+    if (a.nsrc > 1) sbase1 = src_base(a.s[1], hoffb1);
+    else {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) hoffb1[it] = hoffb0[it];
     }
   };
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int q = (it * 4 + wv) * 16 + px;
+    const int hy = (q * 3641) >> 16, hx_ = q - hy * HC;
+    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx_;
+    if (q < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && !(DBG & 1)) hvalid |= 1u << it;
+  }
+  sbase0 = src_base(a.s[0], hoffb0);
+  sbase1 = sbase0;
+  if constexpr (SK) second_source();
   unsigned woffb[WU];                                   // byte offsets into a chunk's packed weights; ~0u = none
 #pragma unroll
   for (int k = 0; k < WU; ++k) {
