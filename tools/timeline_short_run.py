@@ -65,7 +65,7 @@ for rep in range(5):
             dm._align_streams(sub.streams)
         for i, gs in enumerate(sub.streams):
             cabi.check(lib.ld_graph_launch(ex[i], gs.cuda_stream), "l")
-            if k in (0, 1, 2, K - 1):
+            if k in (0, 1, 2, K - 1) or k % 10 == 0:
                 marks[(i, k)] = ev()
                 marks[(i, k)].record(gs)
         pace.step_enqueued()
@@ -93,3 +93,6 @@ for rep in range(5):
         m = lambda k: e0.elapsed_time(marks[(i, k)])           # noqa: E731
         print(f"   stream {i}: scatter done {m('copy'):.3f}, encoder done {m('enc'):.3f}, step 0 done {m(0):.3f}, step 1 {m(1):.3f}, "
               f"step 2 {m(2):.3f}, step {K - 1} {m(K - 1):.3f}; steady step {(m(K - 1) - m(2)) / (K - 3):.4f}")
+        if K > 30:            # how the step time settles: mean step time per window of 10 steps
+            ks = [k for k in range(10, K, 10)]
+            print("      per 10 steps from step 10 on: " + " ".join(f"{(m(b_) - m(a_)) / 10:.4f}" for a_, b_ in zip(ks[:-1], ks[1:])))
