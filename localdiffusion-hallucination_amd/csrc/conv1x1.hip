@@ -472,7 +472,7 @@ int launch_epi(const Conv1Dev& a, hipStream_t st) {
   dim3 grid((HW + NPT - 1) / NPT, a.Cout / (16 * MT), a.B);
   // the GroupNorm-tail launches of the sampling loop (FiLM shared by the batch): preloaded tail operand
   constexpr bool CAN_TLEAD = EPI == LD_EPI_GN_TAIL || EPI == EPI_GN_TAIL_RES;
-  const bool tlead = CAN_TLEAD && a.tail.film_bstride == 0 && a.tail.film_tstride == 0 && a.Cout < 65536 && a.tail.groups < 32768 &&
+  const bool tlead = CAN_TLEAD && ld_tuning().lead_args && a.tail.film_bstride == 0 && a.tail.film_tstride == 0 && a.Cout < 65536 && a.tail.groups < 32768 &&
                      a.tail.C == a.Cout && a.tail.ld == a.Cout && (long)HW < (1L << 31);
 #define LD_C1_TLEAD_ARGS a.tail.data, a.tail.stats, a.tail.gamma, a.tail.beta, a.tail.film, a.Cout | (a.tail.groups << 16), HW, a
   if constexpr (CAN_TLEAD) {
@@ -491,7 +491,7 @@ int launch_epi(const Conv1Dev& a, hipStream_t st) {
   }
 #undef LD_C1_TLEAD_ARGS
   if constexpr (!CAN_TLEAD) {
-    const bool klead = (a.group == KG || a.group == 2) && a.w_bstride == 0 && a.s[0].C < 65536 && a.s[1].C < 65536 && a.s[1].ld < 65536;
+    const bool klead = ld_tuning().lead_args && (a.group == KG || a.group == 2) && a.w_bstride == 0 && a.s[0].C < 65536 && a.s[1].C < 65536 && a.s[1].ld < 65536;
     if (klead) {
       const int c0f = a.s[0].C | (a.nsrc << 16) | (a.unshuffle ? 1 << 18 : 0) | (a.rms_in ? 1 << 19 : 0) | (a.wsplit ? 1 << 20 : 0);
       const int c1l = (a.nsrc > 1 ? a.s[1].C : 0) | ((a.nsrc > 1 ? a.s[1].ld : 0) << 16);

@@ -25,7 +25,7 @@ int run(const GnDev& g, hipStream_t st) {
   dim3 grid((unsigned)blocks, g.B);
   const size_t lds = 4 * g.a.C * sizeof(float) + 64 * sizeof(double);
   // the sampling loop's launches: preloaded leading arguments (gn_apply_lead_kernel)
-  const bool lead = !g.pool && !g.t_ptr && g.a.film_bstride == 0 && !(g.has_b && g.b.stats) && g.a.C < 1024 && g.a.groups < 64 &&
+  const bool lead = ld_tuning().lead_args && !g.pool && !g.t_ptr && g.a.film_bstride == 0 && !(g.has_b && g.b.stats) && g.a.C < 1024 && g.a.groups < 64 &&
                     (long)g.H * g.W < (1L << 31) && 256 % (g.a.C / E) == 0;
   if (lead) {
     const int cg = g.a.C | (g.a.groups << 10) | ((int)blocks << 16), hw = g.H * g.W;     // blocks <= 2048

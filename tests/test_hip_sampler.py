@@ -391,6 +391,31 @@ def test_host_pacing_does_not_change_the_samples():
     check("ahead 3 vs unthrottled", outs[2], outs[0], 1e-5)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_lead_argument_kernels_give_the_same_samples(dtype):
+    """gn_apply and the grouped / GroupNorm-tail conv1x1 launches of the sampling loop run as kernels whose first operands
+    are preloaded leading arguments (tuning table: lead_args = 1; docs/findings.md 84-85).  Same arithmetic in the same
+    order: one batch on one stream (no concurrent atomics) gives BIT-identical samples with the routing on and off."""
+    from localdiffusion_hallucination_amd import _cabi as cabi
+    from localdiffusion_hallucination_amd.tuning import kernel_table
+    lib = cabi.lib()
+    keep = kernel_table(lib)
+    cond = torch.from_numpy(rng.uniform((4, 1, 32, 32), 9, 1, 0.0, 2.0))
+    outs = {}
+    try:
+        for lead in (1, 0):
+            cabi.check(lib.ld_tuning_set(b"lead_args", lead), "tuning_set")
+            gd = make(dict(mode="mri"), dict(data="mri"), 32, 10, dtype=dtype)
+            gd.noise_source = "device"
+            gd.sub_batches = 1
+            outs[lead] = run(gd, cond, None, 4)
+            assert np.isfinite(outs[lead]).all()
+    finally:
+        for kname, val in keep.items():
+            cabi.check(lib.ld_tuning_set(kname.encode(), val), "tuning_set")
+    assert np.array_equal(outs[1], outs[0]), float(np.abs(outs[1] - outs[0]).max())
+
+
 @pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 5e-2), ("fp16", 1e-2)])
 def test_branch_phase_as_concurrent_sub_batches(dtype, tol, fuse):
