@@ -280,6 +280,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// ---------------------------------------------------------------- kernel-argument layout
+// Byte offset, in the kernel-argument segment, of the argument that follows leading arguments of types Lead... and has
+// alignment `align` (each argument sits at its natural alignment, in order): where a kernel finds its trailing by-value
+// struct when it reads it through __builtin_amdgcn_kernarg_segment_ptr() (docs/findings.md 83).
+template <typename... Lead>
+constexpr unsigned ld_kernarg_offset(unsigned align) {
+  unsigned off = 0;
+  const unsigned sizes[] = {(unsigned)sizeof(Lead)...}, aligns[] = {(unsigned)alignof(Lead)...};
+  for (unsigned i = 0; i < sizeof...(Lead); ++i) off = ((off + aligns[i] - 1) / aligns[i]) * aligns[i] + sizes[i];
+  return ((off + align - 1) / align) * align;
+}
+
 // ---------------------------------------------------------------- head-of-step work (pointwise.hip: step_begin_kernel;
 // conv_image.hip: the stem convolution's extra workgroups, ld_conv_stem_begin)
 struct StepBeginDev {

@@ -443,7 +443,8 @@ __global__ __launch_bounds__(256) void conv1x1_taillead_kernel(const void* t_dat
   a.tail.data = t_data; a.tail.stats = t_stats; a.tail.gamma = t_gamma; a.tail.beta = t_beta; a.tail.film = t_film;
   a.Cout = cout_groups & 0xffff; a.tail.C = a.Cout; a.tail.ld = a.Cout; a.tail.groups = (int)((unsigned)cout_groups >> 16);
   a.H = hw; a.W = 1;
-  constexpr unsigned REST_OFF = 5 * 8 + 2 * 4;          // five pointers, two ints; Conv1Dev is 8-byte aligned
+  constexpr unsigned REST_OFF = ld_kernarg_offset<const void*, const double*, const float*, const float*, const float*, int, int>(alignof(Conv1Dev));
+  static_assert(REST_OFF == 48, "conv1x1_taillead_kernel: leading arguments changed");
   typedef const char __attribute__((address_space(4)))* KChar;
   conv1x1_body<T, MT, NW, EPI, G, true>(a, (Conv1KernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF));
 }
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(256) void conv1x1_klead_kernel(const void* data0, c
   a.s[1].data = data1; a.s[1].C = c1_ld1 & 0xffff; a.s[1].ld = (int)((unsigned)c1_ld1 >> 16);
   a.w = w; a.res = res; a.H = H; a.W = W; a.Cout = Cout;
   a.nsrc = (c0_flags >> 16) & 3; a.unshuffle = (c0_flags >> 18) & 1; a.rms_in = (c0_flags >> 19) & 1; a.wsplit = (c0_flags >> 20) & 1;
-  constexpr unsigned REST_OFF = 4 * 8 + 6 * 4;          // four pointers, six ints; Conv1Dev is 8-byte aligned
+  constexpr unsigned REST_OFF = ld_kernarg_offset<const void*, const void*, const void*, const void*, int, int, int, int, int, int>(alignof(Conv1Dev));
+  static_assert(REST_OFF == 56, "conv1x1_klead_kernel: leading arguments changed");
   typedef const char __attribute__((address_space(4)))* KChar;
   conv1x1_body<T, MT, NW, EPI, G, false, true>(a, (Conv1KernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF));
 }

@@ -545,7 +545,8 @@ void conv3x3_kernel(const void* data0, const void* w, int H, int W, int tiles_x,
   a.s[0].data = data0; a.w = w; a.H = H; a.W = W; a.tiles_x = tiles_x; a.s[0].C = C0; a.s[0].ld = ld0; a.s[0].ups = ups0;
   a.nsrc = nsrc; a.wsplit = wsplit; a.Cout = Cout;
   // `rest` in kernel-argument memory: behind the two pointers and nine ints, at the struct's 8-byte alignment
-  constexpr unsigned REST_OFF = (2 * 8 + 9 * 4 + 7) & ~7u;
+  constexpr unsigned REST_OFF = ld_kernarg_offset<const void*, const void*, int, int, int, int, int, int, int, int, int>(alignof(Conv3Dev));
+  static_assert(REST_OFF == 56, "conv3x3_kernel: leading arguments changed");
   typedef const char __attribute__((address_space(4)))* KChar;
   Conv3KernargPtr pr = (Conv3KernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF);
   if constexpr (SK) {       // (the split-K variant sets its second source up in front of its first requests: whole block now)

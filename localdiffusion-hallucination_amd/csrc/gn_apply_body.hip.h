@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void gn_apply_lead_kernel(const void* a_data, 
   g.a.C = c_groups & 0x3ff; g.a.groups = (c_groups >> 10) & 0x3f; g.a.ld = g.a.C;
   g.b.data = b_data; g.b.C = g.a.C; g.b.ld = g.a.C;
   g.has_b = HAS_B; g.H = hw; g.W = 1;
-  constexpr unsigned REST_OFF = 6 * 8 + 2 * 4;          // six pointers, two ints; GnDev is 8-byte aligned
+  constexpr unsigned REST_OFF = ld_kernarg_offset<const void*, const void*, const double*, const float*, const float*, const float*, int, int>(alignof(GnDev));
+  static_assert(REST_OFF == 56, "gn_apply_lead_kernel: leading arguments changed");
   typedef const char __attribute__((address_space(4)))* KChar;
   gn_apply_tile<T, HAS_B, false>(g, blockIdx.x, (int)((unsigned)c_groups >> 16), blockIdx.y, s_coef,
                                  (GnKernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF));
