@@ -29,6 +29,7 @@ rank 0's JSON line; it exits non-zero if a rank fails or fewer than N GPUs are v
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -182,19 +183,64 @@ def patch_conditions(cond, masks):
     return torch.cat(out, 0)
 
 
-def cpu_baseline(cfg, sd, H, seconds_budget=15.0):
-    """Oracle forward+update on the host cores: bounded sample, fp32, all threads."""
+def _cpu_steps(cfg, sd, H, seconds_budget, max_steps=40):
+    """Oracle reverse steps of ONE patch on the current intra-op pool until the budget is used -> (steps, seconds per step)."""
     from oracle import unet_ref
     from localdiffusion_hallucination_amd import rng
-    B = 1
-    x = torch.from_numpy(rng.randn((B, cfg.channels, H, H), 3, 0))
-    cond = torch.from_numpy(rng.uniform((B, cfg.cond_in_channels, H, H), 3, 1, 0.0, 2.0))
-    t = torch.full((B,), 500, dtype=torch.long)
+    x = torch.from_numpy(rng.randn((1, cfg.channels, H, H), 3, 0))
+    cond = torch.from_numpy(rng.uniform((1, cfg.cond_in_channels, H, H), 3, 1, 0.0, 2.0))
+    t = torch.full((1,), 500, dtype=torch.long)
     with torch.no_grad():
-        # the GPU box exposes far more logical CPUs than this process may use; oversubscribing the
-        # intra-op pool makes the oracle ~100x slower, so pick the fastest of a few pool sizes
+        unet_ref.unet_forward(sd, cfg, x, cond, t)        # warm-up
+        n, t0 = 0, time.time()
+        while True:
+            y = unet_ref.unet_forward(sd, cfg, x, cond, t)
+            x = 0.9 * x + 0.1 * y.clamp(0, 2)
+            n += 1
+            if time.time() - t0 > seconds_budget or n >= max_steps:
+                break
+    return n, (time.time() - t0) / n
+
+
+def cpu_worker_main(argv):
+    """``bench.py --cpu-worker H first_cpu threads seconds``: one worker of the whole-box CPU baseline -- a separate
+    process pinned to its own CPUs that steps one patch on the oracle and prints {"steps", "s_per_step"}.  Touches no GPU."""
+    H, first, threads, seconds = int(argv[0]), int(argv[1]), int(argv[2]), float(argv[3])
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, set(cpus[first:first + threads]) or set(cpus))
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(threads)
+    import localdiffusion_hallucination_amd as ldh
+    from localdiffusion_hallucination_amd import weights
+    net = ldh.Unet(dim=32, init_dim=32, channels=3, out_dim=3, mode="mvtec")
+    sd = {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()}
+    n, dt = _cpu_steps(net.cfg, sd, H, seconds)
+    print(json.dumps({"steps": n, "s_per_step": dt}))
+    return 0
+
+
+def cpu_baseline(cfg, sd, H, patches, seconds_budget=12.0):
+    """The oracle (the CPU restatement of the reference path, oracle/unet_ref.py) on the box's host cores, fp32, a bounded
+    sample.  Two figures: ``value`` = the WORKLOAD on the box -- the batch's ``patches`` patches stepped concurrently by
+    that many worker processes, each pinned to its own block of CPUs (one patch on 16 threads leaves
+    most of a 256-CPU box idle) -- and ``single_patch`` = one patch on the fastest intra-op pool (the latency figure the
+    earlier rounds reported)."""
+    with torch.no_grad():
+        # the GPU box exposes far more logical CPUs than one intra-op pool can use (oversubscribing it makes the oracle
+        # ~100x slower): the fastest of a few pool sizes, one timed forward each
+        from oracle import unet_ref
+        from localdiffusion_hallucination_amd import rng
+        x = torch.from_numpy(rng.randn((1, cfg.channels, H, H), 3, 0))
+        cond = torch.from_numpy(rng.uniform((1, cfg.cond_in_channels, H, H), 3, 1, 0.0, 2.0))
+        t = torch.full((1,), 500, dtype=torch.long)
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            usable = os.cpu_count()
         best = None
-        for nt in sorted({min(os.cpu_count(), k) for k in (8, 16, 32, 64)}):
+        for nt in sorted({min(usable, k) for k in (8, 16, 32)}):
             torch.set_num_threads(nt)
             unet_ref.unet_forward(sd, cfg, x, cond, t)        # warm-up
             t0 = time.time()
@@ -205,19 +251,32 @@ def cpu_baseline(cfg, sd, H, seconds_budget=15.0):
             if dt1 > 5.0:
                 break
         torch.set_num_threads(best[1])
-        n, t0 = 0, time.time()
-        while True:
-            y = unet_ref.unet_forward(sd, cfg, x, cond, t)
-            x = 0.9 * x + 0.1 * y.clamp(0, 2)
-            n += 1
-            if time.time() - t0 > seconds_budget or n >= 40:
-                break
-        dt = (time.time() - t0) / n
-    return dict(value=1.0 / (T_STEPS * dt), unit="patches/s", cores=torch.get_num_threads(), kind="port",
-                host_logical_cpus=os.cpu_count(), host_cpu=cpu_model(),
-                sample=f"{n} consecutive reverse steps of 1 patch ({cfg.channels}x{H}x{H}, fp32, oracle/unet_ref.py) on "
-                       f"{torch.get_num_threads()} threads (fastest of 8/16/32/64; the box has {os.cpu_count()} logical CPUs), "
-                       f"{dt*1e3:.1f} ms/step, extrapolated to T={T_STEPS}")
+    n1, dt_single = _cpu_steps(cfg, sd, H, seconds_budget / 2, max_steps=20)
+    single = dict(value=1.0 / (T_STEPS * dt_single), unit="patches/s", cores=best[1],
+                  sample=f"{n1} consecutive reverse steps of 1 patch on {best[1]} threads (fastest of 8/16/32), {dt_single*1e3:.1f} ms/step")
+    # the whole workload: one worker process per patch, each on its own CPUs
+    threads = max(1, min(best[1], usable // max(1, patches)))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(H), str(i * threads), str(threads),
+                               str(seconds_budget)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+             for i in range(patches)]
+    rates, steps = [], []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=40 * seconds_budget + 300)
+            d = json.loads(out.strip().splitlines()[-1])
+            rates.append(1.0 / (T_STEPS * d["s_per_step"]))
+            steps.append(d["steps"])
+        except Exception:                                       # a worker that died or hung is reported, not hidden
+            pr.kill()
+    if len(rates) != patches:
+        return dict(single, kind="port", host_logical_cpus=os.cpu_count(), host_cpu=cpu_model(),
+                    sample=single["sample"] + f"; whole-box leg failed ({len(rates)} of {patches} workers answered)")
+    ms = 1e3 / (T_STEPS * (sum(rates) / len(rates)))
+    return dict(value=sum(rates), unit="patches/s", cores=threads * patches, kind="port",
+                host_logical_cpus=os.cpu_count(), host_usable_cpus=usable, host_cpu=cpu_model(), single_patch=single,
+                sample=f"the batch's {patches} patches ({cfg.channels}x{H}x{H}, fp32, oracle/unet_ref.py) stepped concurrently by {patches} "
+                       f"worker processes x {threads} threads, each pinned to its own CPUs: {min(steps)}-{max(steps)} consecutive reverse "
+                       f"steps per worker in ~{seconds_budget:.0f} s, mean {ms:.1f} ms/step per patch, extrapolated to T={T_STEPS}")
 
 
 def _family_table(acc, plan, nsteps):
@@ -493,6 +552,8 @@ def bench_cfg5(a, rank, world, dev, dist):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        sys.exit(cpu_worker_main(sys.argv[2:]))
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(launch_ranks(a))
@@ -651,7 +712,7 @@ def main():
                                        "steps": k2, "ms_per_step": 1e3 * e3 / k2}
             net.set_weight_split_levels(0)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:        # contract: CPU baseline on rank 0 at N=1 only
-        out["cpu_baseline"] = cpu_baseline(net.cfg, sd, H)
+        out["cpu_baseline"] = cpu_baseline(net.cfg, sd, H, P)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -102,6 +102,7 @@ const char* ld_tuning_name(int index);              /* NULL past the end */
  * graph capture counts once, its replays do not): lets a test assert WHICH kernel a shape ran on. */
 #define LD_COUNTER_CONV3X3_C32 0      /* ld_conv3x3 calls taken by the persistent LDS-DMA kernel (conv3x3_c32.hip) */
 #define LD_COUNTER_CONV3X3_GENERIC 1  /* ... by the register-staged generic kernel (conv3x3.hip) */
+#define LD_COUNTER_CONV3X3_S32 2      /* ... by the lean Cout = 32 large-map kernel (conv3x3_s32.hip) */
 #define LD_COUNTER_MAX 8
 long long ld_counter(int which);
 int ld_range_push(const char* name /* host string */);
@@ -377,7 +378,8 @@ int ld_step_begin_film(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_
 
 /* p_sample, single branch (ddpm.py:631-666, 739-761, 817-838, 857-858):
  *   x0 = clamp(to_x0(model_out)), x_prev = c1*x0 + c2*x_t + (t>0 ? sigma*z : 0).
- * x0_out may be NULL.  noise may be NULL when t == 0 is guaranteed. */
+ * x0_out may be NULL.  noise may be NULL when t == 0 is guaranteed.  `t_ptr` NULL = row mode: `sched` points at the step's
+ * own row of the table and the draw is added iff `noise` is non-NULL (pass NULL at t == 0). */
 int ld_ddpm_step(const float* x_t, const float* model_out, const float* noise, float* x_prev,
                  float* x0_out, const float* sched, const int32_t* t_ptr, float lo, float hi,
                  int objective, int64_t n, void* stream);

@@ -17,7 +17,9 @@ def configure_runtime(graph_packet_capture=False):
     ROCm 7.2's captured AQL packets a replayed kernel node carries ~0.4 us more on the GPU side -- cfg3's step 1.585 ->
     1.570 ms with it off, a 64^2 x 4-patch step 0.818 -> 0.773 ms, no workload slower (DESIGN finding 47); the host
     then needs ~300 us instead of 36 us per replay, still below the step.  Returns the settings it applied."""
+    from . import tuning as _tuning
     from .tuning import runtime_env_default
+    _tuning.RUNTIME_CONFIGURED = True         # (what the sampler's one-time warning tests: the call, not the variable)
     applied = {}
     if not graph_packet_capture and runtime_env_default("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0"):
         applied["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"

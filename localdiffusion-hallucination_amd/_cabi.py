@@ -19,7 +19,7 @@ EPI_PLAIN, EPI_QKV_LINEAR, EPI_QKV_FULL, EPI_RMS_RES, EPI_RES, EPI_GN_TAIL = 0, 
 OBJ = {"pred_x0": 0, "pred_noise": 1, "pred_v": 2}
 SCHED_COLS = 8
 STAT_STRIPES = 16      # LD_STAT_STRIPES
-COUNTER_CONV3X3_C32, COUNTER_CONV3X3_GENERIC = 0, 1
+COUNTER_CONV3X3_C32, COUNTER_CONV3X3_GENERIC, COUNTER_CONV3X3_S32 = 0, 1, 2
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
 

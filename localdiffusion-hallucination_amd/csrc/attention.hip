@@ -139,7 +139,7 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
 // SIMD one group's exponentials run under the other's matrix products, and each wave's chain of tiles is half as long.
 template <typename T, int TKV, int KS>
 __global__ __launch_bounds__(256 * KS) void attention_mfma_kernel(const T* __restrict__ qkv, T* __restrict__ out,
-                                                                  int n, int heads) {
+                                                                  int n, int heads, int xcd_map) {
   constexpr int NKT = TKV / 16, NST = TKV / 64;          // 16-key MFMA tiles per tile; staging rows per thread
   constexpr int KBYTES = 4 * (TKV + 1) * 16, VBYTES = TKV * VROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];         // per group: K planes [4][TKV + 1][16 B], V rows [TKV][VROW]
@@ -147,7 +147,31 @@ __global__ __launch_bounds__(256 * KS) void attention_mfma_kernel(const T* __res
   uint4 (*s_k)[TKV + 1] = reinterpret_cast<uint4 (*)[TKV + 1]>(smem + grp * (KBYTES + VBYTES));   // +1: the 4 chunk lanes of a key write 4 distinct bank quads
   char* s_v = smem + grp * (KBYTES + VBYTES) + KBYTES;
   const int hidden = heads * D;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  // Workgroup -> (image, head, query tile).  The grid is ONE-dimensional and workgroups are dealt round-robin over the 8
+  // XCDs (id % 8 says which workgroups share an XCD's L2: observed, for speed only -- any placement computes the same).
+  // Every query tile of an (image, head) re-reads that head's whole K and V; with the natural order the 16-64 tiles of a
+  // head sat on all eight XCDs and each L2 fetched its own copy (rocprofv3 FETCH_SIZE: 4.9x the algorithmic bytes at
+  // n = 1,024).  Here XCD x owns whole (image, head) pairs -- adjacent heads of one image, whose 64-byte K / V slices
+  // share 128-byte lines -- or, with fewer pairs than XCDs (cfg5: one image), an interleaved share of one pair's tiles.
+  int b, h, q0;
+  {
+    const int nq = (n + 63) / 64, npair = (int)gridDim.x / nq, id = blockIdx.x;
+    const int x = id & 7, s = id >> 3;
+    int pair = id / nq, qt = id % nq;                      // natural order (any grid)
+    if (!xcd_map) {
+    } else if ((npair & 7) == 0) {                         // XCD x: pairs [x G, (x + 1) G), all their tiles
+      const int G = npair >> 3;
+      pair = x * G + s / nq;
+      qt = s % nq;
+    } else if (npair < 8 && 8 % npair == 0 && nq % (8 / npair) == 0) {   // a pair spans R XCDs, tile q on XCD (q mod R)
+      const int R = 8 / npair;
+      pair = x / R;
+      qt = s * R + x % R;
+    }
+    b = pair / heads;
+    h = pair - b * heads;
+    q0 = qt * 64;
+  }
   const int tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6, li = lane & 15, kg = lane >> 4;
   const size_t rowstride = (size_t)3 * hidden;
   const T* base = qkv + (size_t)b * n * rowstride;
@@ -290,7 +314,8 @@ template <typename T, int TKV, int KS>
 int launch_mfma(dim3 grid, hipStream_t st, const void* qkv, void* out, int n, int heads) {
   const size_t lds = (size_t)KS * (4 * (TKV + 1) * 16 + TKV * VROW);
   if (ld_allow_lds(attention_mfma_kernel<T, TKV, KS>, lds) != hipSuccess) return ld_fail(LD_EHIP, "ld_attention: %zu bytes of LDS refused", lds);
-  LD_LAUNCH((attention_mfma_kernel<T, TKV, KS>), grid, dim3(256 * KS), lds, st, (const T*)qkv, (T*)out, n, heads);
+  LD_LAUNCH((attention_mfma_kernel<T, TKV, KS>), dim3(grid.x * grid.y * grid.z), dim3(256 * KS), lds, st, (const T*)qkv, (T*)out, n, heads,
+            (int)ld_tuning().attn_xcd_map);
   return LD_OK;
 }
 }  // namespace
@@ -309,7 +334,10 @@ extern "C" int ld_attention(const void* qkv, void* out, int B, int n, int heads,
       // launches of at most attn_split_max_wgs workgroups (tuning table; default 256 = one per CU): two key groups
       // (measured: n = 4,096 at B = 1 alone 27.6 -> 23.8 us, cfg5 +0.3 %; n = 1,024 at B = 4 alone 9.2 -> 8.5 us but in
       //  the two-sub-batch step +0.2 % -- the other stream's launch already is the second wave per SIMD: long sequences only)
-      const bool split = (long)grid.x * grid.y * grid.z <= ld_tuning().attn_split_max_wgs && n >= ld_tuning().attn_split_min_n;
+      // (and only when the second group owns at least one key, n > tile size: a group whose every score is the masking
+      //  constant has exp2(rounding error of -1e30 * log2 e) = +inf weights and its inf * 0 products are NaN for every query)
+      const int tkv = n >= 2048 ? 256 : 128;
+      const bool split = (long)grid.x * grid.y * grid.z <= ld_tuning().attn_split_max_wgs && n >= ld_tuning().attn_split_min_n && n > tkv;
       int rc;
       if (n >= 2048) rc = split ? launch_mfma<T, 256, 2>(grid, st, qkv, out, n, heads) : launch_mfma<T, 256, 1>(grid, st, qkv, out, n, heads);
       else rc = split ? launch_mfma<T, 128, 2>(grid, st, qkv, out, n, heads) : launch_mfma<T, 128, 1>(grid, st, qkv, out, n, heads);

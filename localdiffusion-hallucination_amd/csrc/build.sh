@@ -22,7 +22,7 @@ if [ $CLEAN = 1 ]; then rm -rf build liblocaldiff_hip.so; fi
 mkdir -p build
 if [ "$(cat build/.flags 2>/dev/null)" != "$FLAGS" ]; then rm -f build/*.o; echo "$FLAGS" > build/.flags; fi
 pids=()
-for f in runtime collective pack conv3x3 conv3x3_c32 conv1x1 conv_image gn_apply linattn linattn_fused attention time_embed pointwise; do
+for f in runtime collective pack conv3x3 conv3x3_c32 conv3x3_s32 conv1x1 conv_image gn_apply linattn linattn_fused attention time_embed pointwise; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.hip.h -nt build/$f.o ] || [ ../../include/localdiff_hip.h -nt build/$f.o ] || [ -n "$(find . -maxdepth 1 -name '*.hip.h' -newer build/$f.o)" ]; then
     # MFMA results in VGPRs (no v_accvgpr_read/mov traffic in the epilogues that post-process accumulators);
     # the register-staged generic conv measured 1.5 % slower with it and keeps the default AGPR form

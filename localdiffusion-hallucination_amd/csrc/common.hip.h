@@ -65,7 +65,8 @@ struct LdTuning {
   long long c1_group, c1_group_max_px, c1_group_min_ch, c1_pair_max_px, c1_small_min;
   long long conv_raw, conv_mt4_min_wgs, conv_big_min, conv_sk, conv_sk_max_wgs;
   long long conv_c32, conv_c32_min_tiles;
-  long long gn_frags_per_block, fold_split_min, attn_split_max_wgs, attn_split_min_n, lead_args;
+  long long conv_s32, conv_s32_min_tiles;
+  long long gn_frags_per_block, fold_split_min, attn_split_max_wgs, attn_split_min_n, lead_args, attn_xcd_map;
 };
 const LdTuning& ld_tuning();
 

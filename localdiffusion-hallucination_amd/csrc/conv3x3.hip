@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 int ld_conv3x3_c32_try(const ld_conv3x3_args* p, hipStream_t st);   // conv3x3_c32.hip
+int ld_conv3x3_s32_try(const ld_conv3x3_args* p, hipStream_t st);   // conv3x3_s32.hip
 #ifdef LD_DEBUG_VARIANTS
 int ld_conv3x3_ksplit_try(const ld_conv3x3_args* p, hipStream_t st);   // tools/experiments/conv3x3_ksplit.hip (shelved, finding 52)
 int ld_conv3x3_ring_try(const ld_conv3x3_args* p, hipStream_t st);     // tools/experiments/conv3x3_ring.hip (finding 58)
@@ -205,7 +206,11 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
 #endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (p->weight_terms != 2) {   // (the persistent kernel keeps ONE chunk of weights in registers)
-    const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages
+    const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages (>= 2,048 tiles)
+    if (rc != 0) return rc < 0 ? rc : LD_OK;
+  }
+  {
+    const int rc = ld_conv3x3_s32_try(p, st);        // lean kernel for the Cout=32 stages (the ResBlock conv path)
     if (rc != 0) return rc < 0 ? rc : LD_OK;
   }
 #ifdef LD_DEBUG_VARIANTS

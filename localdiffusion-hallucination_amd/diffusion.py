@@ -162,6 +162,39 @@ class _SubBatches:
         self.graphs[key] = g
         return ran
 
+    def _ensure_joint_graph(self, lo, hi, base):
+        """ONE graph of one step of EVERY sub-batch (Tuning.sub_joint_graph): captured on stream 0, forked to the other
+        streams through an event they wait for and joined through events stream 0 waits for -- one host launch per step
+        instead of S, the sub-batches start each step together (the in-phase regime of finding 44 by construction) and
+        meet again at its end.  Requires the per-sub-batch graphs to exist (their capture ran the lazy set-up eagerly)."""
+        import ctypes as C
+        lib = cabi.lib()
+        key = ("joint", float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset)
+        if key in self.graphs:
+            return self.graphs[key]
+        s0 = self.streams[0]
+        for gs in self.streams:
+            gs.synchronize()
+        fork = torch.cuda.Event()
+        joins = [torch.cuda.Event() for _ in self.streams[1:]]
+        cabi.check(lib.ld_graph_begin(s0.cuda_stream), "graph_begin")
+        try:
+            fork.record(s0)
+            for gs in self.streams[1:]:
+                gs.wait_event(fork)                      # joins the capture
+            for i, gs in enumerate(self.streams):
+                with torch.cuda.stream(gs):
+                    self._step(i, gs.cuda_stream, lo, hi, base)
+            for ev, gs in zip(joins, self.streams[1:]):
+                ev.record(gs)
+                s0.wait_event(ev)
+        finally:
+            g = C.c_void_p()
+            rc = lib.ld_graph_end(s0.cuda_stream, C.byref(g))
+        cabi.check(rc, "graph_end")
+        self.graphs[key] = g
+        return g
+
     def _trim(self, lo, hi, base):
         """Many different noise bases (a bench that wraps over samples) would pile up graphs: start over."""
         if (0, float(lo), float(hi), base, self.gd.noise_seed, self.gd.noise_offset) in self.graphs or len(self.graphs) < 8 * self.S:
@@ -198,6 +231,20 @@ class _SubBatches:
         # again every LD_SUB_RESYNC steps (default 32; 0: never).
         h0 = time.perf_counter()
         tn = self.gd.tuning
+        if tn.sub_joint_graph and self.S > 1 and min(todo) == max(todo):
+            gj = self._ensure_joint_graph(lo, hi, base)
+            s0 = self.streams[0]
+            for gs in self.streams[1:]:
+                s0.wait_stream(gs)                       # their scatter / encoder precede the forked step
+            pace = _Pace(self.streams[:1], tn.sub_ahead)
+            lib.ld_range_push(b"steps (one forked graph per step, %d sub-batches)" % self.S)
+            for k in range(todo[0]):
+                cabi.check(lib.ld_graph_launch(gj, s0.cuda_stream), "graph_launch")
+                pace.step_enqueued()
+            lib.ld_range_pop()
+            for gs in self.streams[1:]:
+                gs.wait_stream(s0)
+            todo = [0] * self.S
         pace = _Pace(self.streams, tn.sub_ahead)
         lib.ld_range_push(b"steps (graph replay, %d sub-batches)" % self.S)
         for k in range(max(todo)):
@@ -588,7 +635,8 @@ class GaussianDiffusion(nn.Module):
             self._noise(z, int(draw))
         x_prev, x0 = torch.empty_like(x), torch.empty_like(x)
         row = self._sched_table()[t:t + 1].contiguous()
-        cabi.check(lib.ld_ddpm_step(x.data_ptr(), model_out.data_ptr(), z.data_ptr(), x_prev.data_ptr(),
+        # (row mode: the kernel adds the draw iff it gets a noise pointer -- none at t = 0, ddpm.py:857)
+        cabi.check(lib.ld_ddpm_step(x.data_ptr(), model_out.data_ptr(), z.data_ptr() if t > 0 else None, x_prev.data_ptr(),
                                     x0.data_ptr(), row.data_ptr(), None, float(min_max_val[0]),
                                     float(min_max_val[1]), cabi.OBJ[self.objective], x.numel(), st), "ddpm_step")
         return x_prev, x0
@@ -1225,6 +1273,226 @@ class GaussianDiffusion(nn.Module):
             step(jp.x_in, jp.model_out, t, t_next, z if t_next >= 0 else None)
             idx += 1
         return jp.x_in.clone()
+
+    # ------------------------------------------------------------------ the K-mask loop in two halves (dist.sample_kmask_sharded)
+    # SURVEY 8e "Collective": in the reference's fusion mode the exchange sits at t = start_timestep (ddpm.py:779-810,
+    # :1021-1042): every branch contributes its state x_t and its prediction x0_hat, then the remaining steps run on the
+    # recomposed image.  The unit of work before that point is a BRANCH-PATCH u = k * B + b (branch k of image b, the
+    # layout of _kmask_setup's plan); after it, an image.  kmask_branch_units runs units [u_lo, u_hi) up to the exchange,
+    # kmask_fuse_joint takes the gathered (x_t, x0_hat) of ALL units and finishes images [i_lo, i_hi).  Called with the
+    # full ranges the two halves are _p_sample_loop_kmask / _ddim_sample_kmask (tests/test_hip_dist.py).
+    def kmask_flags(self, masks):
+        """(branch, fuse, mask_x) of a K-mask call as sample() would take them now; the per-call state that outlives the
+        call is moved by ``advance_call_state`` (once per rank, shard or no shard)."""
+        if bool(self.config.get("classifier", False)):
+            raise ValueError("the classifier gate re-branches on a data-dependent score (ddpm.py:883-916): not defined across ranks")
+        c = self.config
+        mask_x = self._mask_x_get() or bool(c.get("ood_AD", False)) or bool(c.get("ood_confidence", False))
+        return bool(c["branch_out"]) or self.branch_out, bool(c["start_intermediate"]) or self.start_intermediate, mask_x
+
+    def _kmask_start(self, shape, gt):
+        """x_T of the WHOLE image batch (every branch of image b starts from x_T[b], ddpm.py:955-957) and the first t."""
+        lib, st, dev = cabi.lib(), self._st(), self.device
+        x_T = torch.empty(shape, dtype=torch.float32, device=dev)
+        self._noise(x_T, 0)
+        start_t = self.num_timesteps - 1
+        if (not self.is_ddim_sampling and (bool(self.config["start_intermediate"]) or self.start_intermediate)
+                and self.config.get("use_gt", False)):
+            t0 = int(self.config["use_gt_timestep"])              # ddpm.py:937-944
+            hr = gt.to(dev, torch.float32).contiguous()
+            cabi.check(lib.ld_q_sample(hr.data_ptr(), x_T.data_ptr(), x_T.data_ptr(), float(self.sqrt_alphas_cumprod[t0]),
+                                       float(self.sqrt_one_minus_alphas_cumprod[t0]), x_T.numel(), st), "q_sample")
+            start_t = t0 - 1
+        return x_T, start_t
+
+    def _ddim_scalars(self, t, t_next):
+        a, an = self.alphas_cumprod[t], self.alphas_cumprod[t_next]
+        sigma = self.ddim_sampling_eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()     # ddpm.py:1017-1018
+        return float(an.sqrt()), float((1 - an - sigma ** 2).sqrt()), float(sigma)
+
+    @torch.inference_mode()
+    def kmask_branch_units(self, cond_img, masks, min_max_val, u_lo, u_hi, gt=None):
+        """Branch phase of the K-mask reverse process for units [u_lo, u_hi) (u = k * B + b; masks [B,K,H,W]).  Returns
+        ``(payload [n_units, 2, C, H, W], where)``: row 0 the unit's state, row 1 its prediction; with fusion these are
+        x_t and x0_hat AT the fusion step (state not yet stepped: ddpm.py:779-797 recomposes x_t and x0_hat of the same t),
+        without fusion the final states (row 1 unused).  ``where`` = (t or pair index of the exchange, next draw)."""
+        self._sync_model()
+        lib, st, dev = cabi.lib(), self._st(), self.device
+        branch, fuse, mask_x = self.kmask_flags(masks)
+        assert branch and self.objective == "pred_x0", "branch mode exists only for pred_x0 (ddpm.py:739-749)"
+        B, K, H, W = masks.shape
+        C, HW = self.channels, H * W
+        shape = (B, C, H, W)
+        lo, hi = float(min_max_val[0]), float(min_max_val[1])
+        masks = masks.to(dev, torch.float32).contiguous()
+        cond = cond_img.to(dev, torch.float32).contiguous()
+        m0 = masks[:, 0:1].contiguous()
+        if mask_x:
+            assert len(torch.unique((m0 >= 1.0).float())) == 2, "mask should be binary"   # ddpm.py:698
+        lo_clip = 0.5 if self.config["data"] == "mnist" else 0.95
+        cond_k = torch.empty((K,) + tuple(cond.shape), dtype=torch.float32, device=dev)
+        cabi.check(lib.ld_branch_conditions_k(cond.data_ptr(), masks.data_ptr(), cond_k.data_ptr(), lo_clip, B,
+                                              cond.shape[1], K, HW, st), "branch_conditions_k")
+        replaced = self._replaced_out(mask_x)
+        x_T, start_t = self._kmask_start(shape, gt)
+        n_units = u_hi - u_lo
+        n0 = max(0, min(u_hi, B) - u_lo) if replaced else 0       # leading units whose denoiser evaluation is skipped (:704-708)
+        nb = n_units - n0
+        pay = torch.empty((n_units, 2, C, H, W), dtype=torch.float32, device=dev)
+        # (a rank without units walks the same loop -- it needs `where`, and the loop is where that is decided)
+        plan = self.model.plan(nb, H, W, table_T=self.num_timesteps_ori) if nb else None
+        ub = [u % B for u in range(u_lo, u_hi)]
+        X0 = torch.empty((n0, C, H, W), dtype=torch.float32, device=dev)     # states of the skipped units
+        if n0:
+            X0.copy_(x_T[u_lo:u_lo + n0])
+        if nb:
+            idx = torch.tensor(ub[n0:], device=dev)
+            plan.x_in.copy_(x_T[idx])
+            plan.cond_in.copy_(cond_k.reshape(K * B, *cond.shape[1:])[u_lo + n0:u_hi])
+            plan.run_cond(st)
+        # runs of units that share k: rows [i0, i1) of the local list <-> images [b0, b1)
+        runs, i = [], 0
+        while i < n_units:
+            k, b0 = (u_lo + i) // B, (u_lo + i) % B
+            j = min(n_units, i + B - b0)
+            runs.append((k, i, j, b0, b0 + (j - i)))
+            i = j
+
+        def rows(i0, i1):
+            """(state, prediction) views of local rows [i0, i1) (a run never straddles the skipped / evaluated boundary)."""
+            if i1 <= n0:
+                return X0[i0:i1], cond_k[0][u_lo + i0:u_lo + i1]
+            return plan.x_in[i0 - n0:i1 - n0], plan.model_out[i0 - n0:i1 - n0]
+
+        def evaluate(t):
+            if nb:
+                plan.set_step(t)
+                plan.run_main(st)
+            if mask_x and not replaced:
+                for k, i0, i1, b0, b1 in runs:
+                    if k == 0:
+                        cabi.check(lib.ld_mask_out(rows(i0, i1)[1].data_ptr(), m0[b0:b1].data_ptr(), lo, b1 - b0, C, HW, st), "mask_out")
+
+        def finish(where):
+            for k, i0, i1, b0, b1 in runs:
+                xv, mv = rows(i0, i1)
+                pay[i0:i1, 0].copy_(xv)
+                pay[i0:i1, 1].copy_(mv)
+            return pay, where
+
+        z = torch.zeros(shape, dtype=torch.float32, device=dev)
+        sched, obj = self._sched_table(), cabi.OBJ[self.objective]
+        if not self.is_ddim_sampling:
+            t, draw = start_t, 1
+            while t >= 0:
+                evaluate(t)
+                if t > 0:
+                    self._noise(z, draw)
+                    draw += 1
+                if fuse and t <= int(self.config["start_timestep"]):
+                    return finish((t, draw))
+                row = sched[t:t + 1].contiguous()
+                for k, i0, i1, b0, b1 in runs:               # one shared draw for every branch of an image (ddpm.py:852-858)
+                    xv, mv = rows(i0, i1)
+                    cabi.check(lib.ld_ddpm_step(xv.data_ptr(), mv.data_ptr(), z[b0:b1].data_ptr() if t > 0 else None, xv.data_ptr(), None,
+                                                row.data_ptr(), None, lo, hi, obj, xv.numel(), st), "ddpm_step")
+                t -= 1
+            return finish((-1, draw))
+        T, S = self.num_timesteps, self.sampling_timesteps
+        times, pairs = schedule.ddim_time_pairs(T, S)
+        t_fuse = times[-int(self.config["start_timestep"]) - 2]                 # ddpm.py:987
+        draw, idx = 1, 0
+        while idx < len(pairs):
+            t, t_next = pairs[idx]
+            evaluate(t)
+            last = 1 if t_next < 0 else 0
+            if not last:
+                self._noise(z, draw)
+                draw += 1
+                if fuse and t <= t_fuse:
+                    return finish((idx, draw))
+            san, c, sigma = (0.0, 0.0, 0.0) if last else self._ddim_scalars(t, t_next)
+            for k, i0, i1, b0, b1 in runs:
+                xv, mv = rows(i0, i1)
+                cabi.check(lib.ld_ddim_step(xv.data_ptr(), mv.data_ptr(), None if last else z[b0:b1].data_ptr(), xv.data_ptr(),
+                                            float(self.sqrt_recip_alphas_cumprod[t]), float(self.sqrt_recipm1_alphas_cumprod[t]),
+                                            float(self.sqrt_alphas_cumprod[t]), float(self.sqrt_one_minus_alphas_cumprod[t]),
+                                            san, c, sigma, lo, hi, obj, last, xv.numel(), st), "ddim_step")
+            idx += 1
+        return finish((len(pairs), draw))
+
+    @torch.inference_mode()
+    def kmask_fuse_joint(self, cond_img, masks, min_max_val, payload, where, i_lo, i_hi):
+        """Second half: ``payload`` [K*B, 2, C, H, W] = every unit's (x_t, x0_hat) at the fusion step ``where`` (all ranks'
+        kmask_branch_units results, gathered); recompose images [i_lo, i_hi) (ld_fuse_ddpm_k / ld_fuse_ddim_k:
+        ddpm.py:779-810, :1021-1042) and run their remaining steps.  The image's draws are those of the unsharded batch
+        (noise stream positioned at image i_lo).  Returns [i_hi - i_lo, C, H, W]."""
+        self._sync_model()
+        lib, st, dev = cabi.lib(), self._st(), self.device
+        B, K, H, W = masks.shape
+        C, HW, nl = self.channels, H * W, i_hi - i_lo
+        lo, hi = float(min_max_val[0]), float(min_max_val[1])
+        if nl <= 0:
+            return torch.empty((0, C, H, W), dtype=torch.float32, device=dev)
+        masks_l = masks[i_lo:i_hi].to(dev, torch.float32).contiguous()
+        cond_l = cond_img[i_lo:i_hi].to(dev, torch.float32).contiguous()
+        pk = payload.to(dev, torch.float32).reshape(K, B, 2, C, H, W)[:, i_lo:i_hi]
+        x_first, mo_first = pk[0, :, 0].contiguous(), pk[0, :, 1].contiguous()
+        x_rest = pk[1:, :, 0].reshape((K - 1) * nl, C, H, W).contiguous()
+        mo_rest = pk[1:, :, 1].reshape((K - 1) * nl, C, H, W).contiguous()
+        jp = self.model.plan(nl, H, W, table_T=self.num_timesteps_ori)
+        shape = (nl, C, H, W)
+        z = torch.zeros(shape, dtype=torch.float32, device=dev)
+        n = nl * C * HW
+        keep = self.noise_offset
+        self.noise_offset = keep + i_lo * C * HW
+        try:
+            if not self.is_ddim_sampling:
+                t, draw = where
+                if t > 0:
+                    self._noise(z, draw - 1)                   # the fusion step's draw (taken before the exchange)
+                x0f = torch.empty(shape, dtype=torch.float32, device=dev)
+                cabi.check(lib.ld_fuse_ddpm_k(x_first.data_ptr(), x_rest.data_ptr(), mo_first.data_ptr(), mo_rest.data_ptr(),
+                                              masks_l.data_ptr(), jp.x_in.data_ptr(), x0f.data_ptr(), lo, hi, nl, C, K, HW, st),
+                           "fuse_ddpm_k")
+                jp.set_step(t)
+                cabi.check(lib.ld_posterior_step(jp.x_in.data_ptr(), x0f.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(),
+                                                 self._sched_table().data_ptr(), jp.t_dev.data_ptr(), n, st), "posterior_step")
+                t -= 1
+                jp.cond_in.copy_(cond_l)
+                if t >= 0:
+                    self.encode_cond(jp, t + 1)
+                    self.run_joint_steps(jp, t, t + 1, lo, hi, z, draw)
+                return jp.x_in.clone()
+            idx, draw = where
+            times, pairs = schedule.ddim_time_pairs(self.num_timesteps, self.sampling_timesteps)
+            obj = cabi.OBJ[self.objective]
+            t, t_next = pairs[idx]
+            self._noise(z, draw - 1)
+            san, c, sigma = self._ddim_scalars(t, t_next)
+            cabi.check(lib.ld_fuse_ddim_k(x_first.data_ptr(), x_rest.data_ptr(), mo_first.data_ptr(), mo_rest.data_ptr(),
+                                          masks_l.data_ptr(), z.data_ptr(), jp.x_in.data_ptr(), float(self.sqrt_recip_alphas_cumprod[t]),
+                                          float(self.sqrt_recipm1_alphas_cumprod[t]), san, c, sigma, lo, hi, nl, C, K, HW, st), "fuse_ddim_k")
+            idx += 1
+            jp.cond_in.copy_(cond_l)
+            jp.run_cond(st)
+            while idx < len(pairs):
+                t, t_next = pairs[idx]
+                jp.set_step(t)
+                jp.run_main(st)
+                last = 1 if t_next < 0 else 0
+                if not last:
+                    self._noise(z, draw)
+                    draw += 1
+                san, c, sigma = (0.0, 0.0, 0.0) if last else self._ddim_scalars(t, t_next)
+                cabi.check(lib.ld_ddim_step(jp.x_in.data_ptr(), jp.model_out.data_ptr(), None if last else z.data_ptr(), jp.x_in.data_ptr(),
+                                            float(self.sqrt_recip_alphas_cumprod[t]), float(self.sqrt_recipm1_alphas_cumprod[t]),
+                                            float(self.sqrt_alphas_cumprod[t]), float(self.sqrt_one_minus_alphas_cumprod[t]),
+                                            san, c, sigma, lo, hi, obj, last, n, st), "ddim_step")
+                idx += 1
+            return jp.x_in.clone()
+        finally:
+            self.noise_offset = keep
 
     def _gated_joint_steps(self, jp, t, lo, hi, z, draw, x0_buf, x_branchout, cond, cond_out, cond_in, mask,
                            mask_x, after):

@@ -99,6 +99,10 @@ class LdComm:
             run_id = rendezvous_run_id()
         if run_id is not None:
             id_file = f"{id_file}.{run_id}"
+        # a sequence number per bootstrap of this process (identical on all ranks: bootstrap is collective): a fast rank
+        # entering the NEXT bootstrap can no longer find the previous one's file before rank 0 has unlinked it
+        cls._bootstraps = getattr(cls, "_bootstraps", 0) + 1
+        id_file = f"{id_file}.{cls._bootstraps}"
         if rank == 0:
             with open(id_file + ".tmp", "wb") as f:
                 f.write(cls.make_unique_id())
@@ -128,6 +132,10 @@ class LdComm:
         if getattr(self, "_comm", None):
             cabi.check(cabi.lib().ld_comm_destroy(self._comm), "comm_destroy")
             self._comm = None
+
+
+def _world_rank(comm):
+    return (comm.world, comm.rank) if comm is not None else (dist.get_world_size(), dist.get_rank())
 
 
 def gather_patches(local, n_items, group=None, comm=None, dtype=None):
@@ -267,3 +275,38 @@ def sample_images_sharded(diffusion, cond_img, gt, masks, min_max_val, **sample_
         full = gather_patches(out.transpose(0, 1).contiguous(), n).transpose(0, 1).contiguous()
         return [full[0], full[1]] if as_list else full
     return gather_patches(out, n)
+
+
+def sample_kmask_sharded(diffusion, cond_img, gt, masks, min_max_val, comm=None, gather_dtype=None):
+    """The reference's fusion semantics generalised to K masks, with the K branch-patches of EVERY image spread over the
+    ranks (SURVEY 8e "Collective"; ddpm.py:779-810, 955-962, DDIM :1021-1042).  masks: [B, K, H, W].
+
+      1. branch phase: unit u = k * B + b (branch k of image b) -> rank by contiguous blocks; every rank runs its units
+         from t = T-1 down to the fusion step with no traffic (all branches of an image share each step's draw, :852-858);
+      2. ONE all-gather of [x_t, x0_hat] per unit, taken at t = start_timestep (in ``gather_dtype``, None = fp32);
+      3. images -> ranks by contiguous blocks: recomposition (ld_fuse_ddpm_k / ld_fuse_ddim_k) and the remaining
+         <= start_timestep joint steps for the rank's images;
+      4. ONE all-gather of the finished images.
+
+    Without fusion (``start_intermediate`` off) step 2's gather returns the K branch states and nothing follows
+    ([K, B, C, H, W] for DDPM, a K-list for DDIM: what the unsharded loops return).  With K * B < world the surplus ranks
+    idle in step 1, with B < world in step 3 (SURVEY 8e "If K*B < G").  The result equals
+    ``diffusion.sample(cond_img, gt, mask=masks)`` sample for sample: every unit and image draws its slice of the one noise
+    stream.  ``comm``: an ``LdComm`` (the C ABI's ld_allgather) instead of torch.distributed."""
+    B, K = int(masks.shape[0]), int(masks.shape[1])
+    world, rank = _world_rank(comm)
+    branch, fuse, _ = diffusion.kmask_flags(masks)
+    assert branch and K >= 2, "sample_kmask_sharded: branch mode with K >= 2 masks [B, K, H, W]"
+    U = K * B
+    ulo, uhi = shard_bounds(U, world, rank)
+    pay, where = diffusion.kmask_branch_units(cond_img, masks, min_max_val, ulo, uhi, gt=gt)
+    allpay = gather_patches(pay, U, comm=comm, dtype=gather_dtype)
+    if not fuse:
+        states = allpay[:, 0].to(torch.float32).reshape(K, B, *allpay.shape[2:])
+        out = [states[k] for k in range(K)] if diffusion.is_ddim_sampling else states
+    else:
+        ilo, ihi = shard_bounds(B, world, rank)
+        x = diffusion.kmask_fuse_joint(cond_img, masks, min_max_val, allpay, where, ilo, ihi)
+        out = gather_patches(x, B, comm=comm)
+    diffusion.advance_call_state(masks)              # what sample() leaves behind, on every rank alike
+    return out

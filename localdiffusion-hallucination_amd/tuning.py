@@ -23,6 +23,7 @@ class Tuning:
     sub_resync: int = 32                 # steps between phase alignments of the sub-batch streams (0 = never)
     sub_resync_early: int = 1            # ... and in front of each of the first steps
     sub_ahead: int = 2                   # the host enqueues at most this many replayed steps ahead of the GPU (0 = no limit)
+    sub_joint_graph: bool = False        # ONE captured graph per step that forks to every sub-batch stream and joins (one host launch per step)
     fused_final_step: bool = True        # final_conv + posterior update + noise draw as one launch
     fused_step_begin: bool = True        # the head-of-step work (arena reset, step counter, FiLM row) inside init_conv's launch (16-bit storage)
     # ---- plan builder (unet.py)
@@ -39,7 +40,7 @@ class Tuning:
     _ENV = {
         "LD_SUB_BATCHES": ("sub_batches", int), "LD_MIN_SUB_BATCH": ("min_sub_batch", int),
         "LD_SUB_RESYNC": ("sub_resync", int), "LD_SUB_RESYNC_EARLY": ("sub_resync_early", int),
-        "LD_SUB_AHEAD": ("sub_ahead", int), "LD_WEIGHT_SPLIT_LEVELS": ("weight_split_levels", int),
+        "LD_SUB_AHEAD": ("sub_ahead", int), "LD_SUB_JOINT_GRAPH": ("sub_joint_graph", lambda v: v not in ("0", "")), "LD_WEIGHT_SPLIT_LEVELS": ("weight_split_levels", int),
         "LD_SEP_ACT_MAX_PX": ("sep_act_max_px", int), "LD_SEP_ACT_MIN_C": ("sep_act_min_c", int),
         "LD_NO_FUSED_FINAL": ("fused_final_step", lambda v: False), "LD_NO_FUSED_BEGIN": ("fused_step_begin", lambda v: False),
         "LD_NO_SEPARATE_ACT": ("separate_act", lambda v: False),
@@ -104,5 +105,10 @@ def rendezvous_run_id() -> Optional[str]:
     return _PROCESS_ENV.get("TORCHELASTIC_RUN_ID") or _PROCESS_ENV.get("MASTER_PORT")
 
 
+RUNTIME_CONFIGURED = False      # set by configure_runtime(), whatever it was asked to apply
+
+
 def runtime_configured(var: str = "DEBUG_CLR_GRAPH_PACKET_CAPTURE") -> bool:
-    return var in _PROCESS_ENV
+    """Did the caller decide the runtime settings -- by calling ``configure_runtime`` (with any arguments) or by setting
+    the variable in the environment?"""
+    return RUNTIME_CONFIGURED or var in _PROCESS_ENV

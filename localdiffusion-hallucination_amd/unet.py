@@ -274,7 +274,11 @@ class Unet(nn.Module):
         f = self.downsample_factor
         assert H % f == 0 and W % f == 0, \
             f"your input dimensions {(H, W)} need to be divisible by {f}, given the unet"   # ddpm.py:405
-        key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels)
+        # (the plan-builder fields of the tuning are part of the key: assigning another Tuning after the first plan must
+        #  not silently keep plans built under the old one -- ADVICE r4)
+        tn = self.tuning
+        key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels,
+               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.fused_step_begin, tn.linattn_chunk_px)
         if key not in self._plans:
             self._plans[key] = _Plan(self, B, H, W, table_T)
         return self._plans[key]
@@ -454,6 +458,13 @@ class _Plan:
                 and w % 16 == 0 and (w // 16) * (h // 16) * self.B >= self._kt("conv_c32_min_tiles")
                 and self._kt("conv_c32") and a.weight_terms != 2):
             fam = f"conv3x3_c32<{dname}>"              # the persistent LDS-DMA kernel takes it (conv3x3_c32.hip)
+        elif (self.dt != cabi.LD_F32 and cout == 32 and addend is None and a.weight_terms != 2 and h % 16 == 0 and w % 16 == 0
+              and (w // 16) * (h // 16) * self.B >= self._kt("conv_s32_min_tiles") and not any(s.upsample for s in srcs)
+              and cin in (32, 64) and (len(srcs) == 1 or all(s.C == 32 for s in srcs)) and groups in (1, 2, 4, 8)):
+            pro = any(s.gn_stats for s in srcs)        # mirrors ld_conv3x3_s32_try (conv3x3_s32.hip)
+            bit = 2 if pro else (1 if cin == 32 else 4)
+            if (self._kt("conv_s32") & bit) and (not pro or (len(srcs) == 1 and srcs[0].C == 32 and srcs[0].gn_groups == 8)):
+                fam = f"conv3x3_s32<{dname}>"
         in_el = sum(s.C * (npx // 4 if s.upsample else npx) for s in srcs)
         self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname,
                    dict(family=fam, bytes=(in_el + npx * cout + 9 * cin * cout) * self.esize + 4 * cout,

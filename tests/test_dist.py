@@ -206,6 +206,91 @@ def test_idle_rank_carries_the_call_state_world2_gloo():
     assert dict(q.get(timeout=10) for _ in range(world)) == {0: True, 1: True}
 
 
+class _StubKmask:
+    """Stands for GaussianDiffusion in dist.sample_kmask_sharded: the two halves are pure functions of (unit or image, its
+    conditioning, its masks, its slice of the portable noise stream), so the sharded result can be compared with the same
+    halves run over the full ranges -- which is what the unsharded K-mask loop is."""
+    channels, image_size = 3, 4
+
+    def __init__(self, fuse, ddim=False):
+        self.fuse, self.is_ddim_sampling, self.noise_offset, self.advanced = fuse, ddim, 0, 0
+
+    def kmask_flags(self, masks):
+        return True, self.fuse, True
+
+    def advance_call_state(self, masks):
+        self.advanced += 1
+
+    def kmask_branch_units(self, cond, masks, mm, u_lo, u_hi, gt=None):
+        from localdiffusion_hallucination_amd import rng
+        B, K = masks.shape[:2]
+        z = torch.from_numpy(rng.randn((B, 3, 4, 4), 10, 1, self.noise_offset))        # one draw per IMAGE, shared by its branches
+        pay = torch.zeros(u_hi - u_lo, 2, 3, 4, 4)
+        for i, u in enumerate(range(u_lo, u_hi)):
+            k, b = divmod(u, B)
+            pay[i, 0] = cond[b] * (k + 1) + z[b] + masks[b, k]
+            pay[i, 1] = cond[b] - 0.5 * k + 2.0 * z[b]
+        return pay, (3, 7)
+
+    def kmask_fuse_joint(self, cond, masks, mm, payload, where, i_lo, i_hi):
+        from localdiffusion_hallucination_amd import rng
+        assert where == (3, 7)
+        B, K = masks.shape[:2]
+        pk = payload.reshape(K, B, 2, 3, 4, 4)
+        z = torch.from_numpy(rng.randn((i_hi - i_lo, 3, 4, 4), 10, 2, self.noise_offset + i_lo * 3 * 16))
+        out = torch.zeros(i_hi - i_lo, 3, 4, 4)
+        for j, b in enumerate(range(i_lo, i_hi)):
+            for k in range(K):
+                out[j] += pk[k, b, 0] * masks[b, k] + 0.25 * pk[k, b, 1] * (1.0 - masks[b, k])
+            out[j] += z[j] + cond[b]
+        return out
+
+
+def _kmask_worker(rank, world, port, B, K, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(3)
+        cond = torch.randn(B, 3, 4, 4)
+        masks = (torch.rand(B, K, 4, 4) > 0.5).float()
+        ok = True
+        for fuse, ddim in ((True, False), (False, False), (False, True)):
+            one = _StubKmask(fuse, ddim)
+            pay, where = one.kmask_branch_units(cond, masks, None, 0, K * B)
+            if fuse:
+                want = one.kmask_fuse_joint(cond, masks, None, pay, where, 0, B)
+            else:
+                want = pay[:, 0].reshape(K, B, 3, 4, 4)
+            gd = _StubKmask(fuse, ddim)
+            got = ldist.sample_kmask_sharded(gd, cond, None, masks, (0.0, 2.0))
+            if ddim:
+                ok = ok and isinstance(got, list) and len(got) == K and all(torch.equal(g, w) for g, w in zip(got, want))
+            else:
+                ok = ok and got.shape == want.shape and torch.equal(got, want)
+            ok = ok and gd.advanced == 1 and gd.noise_offset == 0
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,K", [(2, 4), (1, 3), (3, 2), (1, 1 + 1)])
+def test_kmask_units_and_images_sharded_world2_gloo(B, K):
+    """dist.sample_kmask_sharded at world size 2: branch-patch units u = k * B + b over the ranks up to the fusion step,
+    ONE gather of (x_t, x0_hat), images over the ranks for recomposition + joint steps, ONE gather of the result -- equal
+    to the unsharded halves, with ragged unit / image shards and a rank that idles in the image phase (B = 1)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_kmask_worker, args=(r, world, port, B, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=10) for _ in range(world)) == {0: True, 1: True}
+
+
 def test_advance_call_state_mirrors_the_sampler_flags():
     """GaussianDiffusion.advance_call_state on the host (no GPU needed: it only touches the carried flags): the
     transitions of ddpm.py:1106-1117 / :780-781 for {mask_x: True, ood_AD: False} and under ood_AD."""

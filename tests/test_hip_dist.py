@@ -119,3 +119,99 @@ def test_ld_allgather_world1_through_the_c_abi():
     assert torch.equal(x, y)
     assert torch.equal(ldist.gather_patches(x, 5, comm=comm), x)
     comm.close()
+
+
+def _emulate_ranks(gd, cond, masks, world):
+    """dist.sample_kmask_sharded's arithmetic with the ranks run one after the other in this process (the collectives
+    are concatenations): units over `world` ranks, one payload, images over `world` ranks."""
+    B, K = masks.shape[:2]
+    parts, where = [], None
+    for r in range(world):
+        lo, hi = ldist.shard_bounds(K * B, world, r)
+        p, w = gd.kmask_branch_units(cond, masks, (0.0, 2.0), lo, hi)
+        where = w if where is None else where
+        assert w == where
+        parts.append(p)
+    pay = torch.cat(parts, 0)
+    _, fuse, _ = gd.kmask_flags(masks)
+    if not fuse:
+        out = pay[:, 0].reshape(K, B, *pay.shape[2:])
+    else:
+        out = torch.cat([gd.kmask_fuse_joint(cond, masks, (0.0, 2.0), pay, where, *ldist.shard_bounds(B, world, r)) for r in range(world)], 0)
+    gd.advance_call_state(masks)
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("ddim", [False, True])
+def test_kmask_units_sharded_equal_the_unsharded_loop_and_the_reference_goldens(golden, ddim):
+    """SURVEY 8e, mid-chain fusion across ranks: the K branch-patches of every image spread over 1, 2 and 3 emulated
+    ranks, ONE exchange of (x_t, x0_hat) at t = start_timestep, the joint steps by image.  K = 2 with masks
+    [m, 1 - (m >= 1)] reproduces the reference's own goldens (G6 DDPM / G7 DDIM); K = 4 equals the unsharded K-mask loop
+    (fp32; a shard's plan has another batch size, so tile variants -- not values per sample -- may differ: <= 1e-5)."""
+    if not ddim:
+        g = golden("g6_branch_fusion")
+        H, B, T, S = 32, 2, 50, None
+        cond = torch.from_numpy(rng.uniform((B, 1, H, H), 6, 1, 0.0, 2.0)).cuda()
+        mask = torch.zeros(B, 1, H, H)
+        mask[:, :, :, :H // 4] = 1.0
+        ref, kw = g[f"mri{H}_final"], dict(mode="mri")
+    else:
+        g = golden("g7_ddim")
+        mask = torch.from_numpy(g["mask"])
+        H, B, T, S = mask.shape[-1], 1, 1000, 50
+        cond = torch.from_numpy(rng.uniform((B, 1, H, H), 7, 1, 0.0, 2.0)).cuda()
+        ref, kw = g["fused_final"], dict(mode="mri")
+    masks2 = torch.cat([mask, 1.0 - (mask >= 1.0).float()], 1).cuda()
+    conf = dict(data="mri", branch_out=True, start_intermediate=True, start_timestep=2, mask_x=True)
+    for world in (1, 2, 3):
+        gd = make(kw, conf, H, T, S)
+        got = _emulate_ranks(gd, cond, masks2, world)
+        d = float(np.abs(got - ref).max())
+        print(f"K=2 over {world} emulated ranks ({'DDIM' if ddim else 'DDPM'}) vs the reference golden: max-abs {d:.3e}")
+        assert d <= 1e-3
+    # K = 4, fused and kept apart, against the unsharded loop of the same object
+    K, B, H = 4, 2, 32
+    masks = torch.zeros(B, K, H, H)
+    for k in range(K):
+        masks[:, k, :, k * (H // K):(k + 1) * (H // K)] = 1.0
+    masks = masks.cuda()
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 44, 1, 0.0, 2.0)).cuda()
+    for fuse in (True, False):
+        conf = dict(data="mri", branch_out=True, start_intermediate=fuse, start_timestep=3, mask_x=True)
+        gd = make(dict(mode="mri"), conf, H, 50 if ddim else 14, 10 if ddim else None)
+        whole = gd.sample(cond, None, batch_size=B, mask=masks, min_max_val=(0.0, 2.0))
+        whole = (torch.stack(whole) if isinstance(whole, list) else whole).cpu().numpy()
+        for world in (2, 3, 8):
+            gd.reset_call_state()
+            got = _emulate_ranks(gd, cond, masks, world)
+            assert got.shape == whole.shape
+            d = float(np.abs(got - whole).max())
+            print(f"K=4 fuse={fuse} over {world} emulated ranks vs the unsharded loop: max-abs {d:.3e}")
+            assert d <= 1e-5
+
+
+def test_kmask_sharded_world1_through_ld_allgather():
+    """dist.sample_kmask_sharded end to end at world size 1 with the C ABI's own communicator (ld_comm_* / ld_allgather,
+    RCCL through dlopen): both exchanges go through the collective; equal to the plain call, for the non-MRI data mode as
+    well (the OOD branch's prediction is its conditioning, ddpm.py:704-708: those units skip the denoiser), in the storage
+    dtype on the wire too."""
+    K, B, H, T = 3, 2, 32, 12
+    masks = torch.zeros(B, K, H, H)
+    masks[:, 0, :, :8] = 1.0
+    masks[:, 1, :, 8:20] = 1.0
+    masks[:, 2, :, 20:] = 1.0
+    masks = masks.cuda()
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 46, 1, 0.0, 2.0)).cuda()
+    with ldist.LdComm.bootstrap(world=1, rank=0) as comm:
+        for data in ("mri", "mvtecGray"):
+            conf = dict(data=data, branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True, ood_AD=True)
+            gd = make(dict(mode="mri"), conf, H, T)
+            gd.noise_source = "device"
+            want = gd.sample(cond, None, batch_size=B, mask=masks, min_max_val=(0.0, 2.0))
+            got = ldist.sample_kmask_sharded(gd, cond, None, masks, (0.0, 2.0), comm=comm)
+            assert got.shape == want.shape
+            d = float((got - want).abs().max())
+            print(f"sample_kmask_sharded ({data}) through ld_allgather vs sample(): max-abs {d:.3e}")
+            assert d <= 1e-5
+            got16 = ldist.sample_kmask_sharded(gd, cond, None, masks, (0.0, 2.0), comm=comm, gather_dtype=torch.float16)
+            assert float((got16 - want).abs().max()) <= 2e-2          # fp16 on the wire at the exchange, three joint steps behind it

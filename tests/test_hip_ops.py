@@ -73,6 +73,72 @@ def test_conv3x3_gn_film_prologue(dtype, act, groups, use_film):
     assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] * 2
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ["plain32", "one64", "two32", "pro_film", "pro_nofilm", "pro_perbatch"])
+def test_conv3x3_s32_lean_kernel(dtype, case):
+    """The lean Cout = 32 kernel of the ResBlock conv path (conv3x3_s32.hip: four workgroups per CU, GroupNorm coefficients
+    in registers, statistics as per-wave atomics): against the fp32 reference AND against the generic kernel on the same
+    inputs (routing switched through the tuning table and asserted with the launch counters); 32 and 64 input channels,
+    two concatenated sources, the GroupNorm + FiLM + SiLU prologue with a shared and a per-sample FiLM row."""
+    from localdiffusion_hallucination_amd.tuning import kernel_table
+    B, cout, H, W = 2, 32, 48, 32
+    cin = 32 if case in ("plain32", "pro_film", "pro_nofilm", "pro_perbatch") else 64
+    x = _q(hh.rand((B, cin, H, W), 80, -2.0, 3.0), dtype)
+    w, b = _q(hh.rand((cout, cin, 3, 3), 81, -0.1, 0.1), dtype), hh.rand((cout,), 82)
+    y, srcs = x, None
+    xd = hh.nhwc(x, dtype)
+    if case.startswith("pro"):
+        gamma, beta = hh.rand((cin,), 83, 0.5, 1.5), hh.rand((cin,), 84, -0.3, 0.3)
+        y = F.group_norm(x, 8, gamma, beta, eps=1e-5)
+        film = None
+        if case == "pro_film":            # the sampler's table mode: one row for the whole batch
+            film = hh.rand((1, 2 * cin), 85, -0.5, 0.5)
+            y = y * (film[:, :cin, None, None] + 1) + film[:, cin:, None, None]
+        elif case == "pro_perbatch":      # Unet.forward: a row per batch element
+            film = hh.rand((B, 2 * cin), 85, -0.5, 0.5)
+            y = y * (film[:, :cin, None, None] + 1) + film[:, cin:, None, None]
+        y = F.silu(y)
+        f_d = None if film is None else film.to(hh.DEV)
+        # the producer's statistics spread over all 16 stripes (as the convolutions' epilogues leave them)
+        wgt = torch.linspace(1.0, 2.0, cabi.STAT_STRIPES, dtype=torch.float64)
+        wgt = (wgt / wgt.sum()).to(hh.DEV)
+        sx = hh.stats_buffer(B, 8)
+        sx[:] = hh.gn_stats_ref(x, 8).to(hh.DEV)[:, None] * wgt[None, :, None, None]
+        srcs = [hh.make_src(xd, cin, gn=(sx, gamma.to(hh.DEV), beta.to(hh.DEV), 8), act=cabi.ACT_SILU,
+                            film=f_d, film_b=2 * cin if case == "pro_perbatch" else 0)]
+    elif case == "two32":
+        x2 = hh.nhwc(x[:, 32:].contiguous(), dtype)
+        srcs = [hh.make_src(xd, 32, stride=64), hh.make_src(x2, 32)]       # first source: a channel slice of a wider tensor
+    else:
+        srcs = [hh.make_src(xd, cin)]
+    ref = F.conv2d(y, w, b, padding=1)
+    wp, bd = hh.pack(w, dtype, 3), b.to(hh.DEV)
+    lib = cabi.lib()
+    keep = kernel_table(lib)
+    outs, stats = {}, {}
+    try:
+        cabi.check(lib.ld_tuning_set(b"conv_s32_min_tiles", 1), "tuning_set")
+        for name, on in (("lean", 1), ("generic", 0)):
+            cabi.check(lib.ld_tuning_set(b"conv_s32", 7 * on), "tuning_set")        # (a bit mask: every variant / none)
+            n0 = lib.ld_counter(cabi.COUNTER_CONV3X3_S32)
+            st = hh.stats_buffer(B, 8)
+            out = hh.conv3x3(srcs, wp, bd, B, H, W, cout, dtype, stats=st, groups=8)
+            torch.cuda.synchronize()
+            assert lib.ld_counter(cabi.COUNTER_CONV3X3_S32) - n0 == on, name
+            outs[name], stats[name] = hh.nchw(out), st.sum(1).cpu()
+    finally:
+        for kname, val in keep.items():
+            cabi.check(lib.ld_tuning_set(kname.encode(), val), "tuning_set")
+    tol = hh.RTOL[dtype] * (2 if case.startswith("pro") else 1)
+    assert hh.rel_err(outs["lean"], ref) < tol
+    assert hh.rel_err(stats["lean"], hh.gn_stats_ref(ref, 8)) < 1e-2
+    if not case.startswith("pro"):        # same MFMA order, same bias add, same rounding: the raw variants are bit-equal
+        assert torch.equal(outs["lean"], outs["generic"])
+    else:                                 # (the coefficient sums meet in another order: a storage ulp here and there)
+        assert hh.rel_err(outs["lean"], outs["generic"]) < hh.RTOL[dtype] / 2
+    assert hh.rel_err(stats["lean"], stats["generic"]) < 1e-5
+
+
 # ------------------------------------------------------------------------------ conv1x1
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 32, 16, 16), (1, 384, 256, 8, 8), (1, 96, 64, 14, 14),
@@ -266,6 +332,34 @@ def test_full_attention_two_key_groups(dtype, B, n_hw):
             cabi.check(lib.ld_tuning_set(kname.encode(), val), "tuning_set")
     # the two differ only in where the running maximum is taken (P is rounded to storage against it)
     assert hh.rel_err(outs["split"], outs["one"]) < hh.RTOL[dtype] / 2
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("n_hw", [(8, 8), (7, 7), (8, 16)])
+def test_full_attention_split_thresholds_never_leave_a_key_group_empty(dtype, n_hw):
+    """with attn_split_min_n lowered, a sequence that fits ONE key tile (n <= 128) must not take the two-group
+    kernel -- its second group would own no key and every query would come out NaN.  Finite and equal to the reference."""
+    from localdiffusion_hallucination_amd.tuning import kernel_table
+    hid, B = 128, 2
+    H, W = n_hw
+    n = H * W
+    qkv = _q(hh.rand((B, 3 * hid, H, W), 62, -1.5, 1.5), dtype)
+    q, k, v = [t.reshape(B, 4, 32, n).transpose(-1, -2) for t in qkv.chunk(3, dim=1)]
+    ref = ((q @ k.transpose(-1, -2)).softmax(dim=-1) @ v).transpose(-1, -2).reshape(B, hid, H, W)
+    qd = hh.nhwc(qkv, dtype)
+    lib = cabi.lib()
+    keep = kernel_table(lib)
+    try:
+        cabi.check(lib.ld_tuning_set(b"attn_split_min_n", 0), "tuning_set")
+        cabi.check(lib.ld_tuning_set(b"attn_split_max_wgs", 1 << 30), "tuning_set")
+        out = torch.empty(B, H, W, hid, dtype=hh.TDT[dtype], device=hh.DEV)
+        cabi.check(lib.ld_attention(qd.data_ptr(), out.data_ptr(), B, n, 4, 32, cabi.dtype_code(dtype), hh.st()), "attention")
+        got = hh.nchw(out)
+    finally:
+        for kname, val in keep.items():
+            cabi.check(lib.ld_tuning_set(kname.encode(), val), "tuning_set")
+    assert torch.isfinite(got).all()
+    assert hh.rel_err(got, ref) < hh.RTOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

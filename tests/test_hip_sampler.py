@@ -14,9 +14,9 @@ TOL = 1e-3
 MNIST = dict(dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist")
 
 
-def make(kw, config, H, T, S=None, objective="pred_x0", dtype="fp32"):
+def make(kw, config, H, T, S=None, objective="pred_x0", dtype="fp32", final_gain=3.0):
     net = ldh.Unet(dim=32, init_dim=32, compute_dtype=dtype, **kw)
-    net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()})
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0, final_gain=final_gain).items()})
     cfg = dict(branch_out=False, start_intermediate=False, start_timestep=2, data="mri", mask_x=False,
                mask_cond=False, ood_AD=False, ood_confidence=False, classifier=False, use_gt=False,
                use_gt_timestep=100)
@@ -52,6 +52,24 @@ def test_three_step_runs(golden):
     }
     for tag, kw in cases.items():
         check("G3 " + tag, run(make(MNIST, kw, 28, 3), cond, mask, 2), g[tag])
+
+
+def test_p_sample_is_one_step_of_the_loop():
+    """GaussianDiffusion.p_sample (ddpm.py:841-860, single-branch arm) chained over t = T-1 .. 0 with the loop's draw
+    indices reproduces every state of p_sample_loop -- in particular the draw IS added at t > 0 (round 5: the row mode of
+    ld_ddpm_step, which only p_sample uses, read t = 0 inside the kernel and silently dropped it)."""
+    H, T, B = 28, 6, 2
+    gd = make(MNIST, dict(data="mnist"), H, T)
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 71, 1, 0.0, 2.0)).cuda()
+    hist = gd.sample(cond, None, batch_size=B, min_max_val=(0.0, 2.0), return_all_timesteps=True)
+    assert tuple(hist.shape) == (B, T + 1, 1, H, H)
+    x = hist[:, 0].contiguous()
+    for i, t in enumerate(range(T - 1, -1, -1)):
+        x, x0 = gd.p_sample(x, None, (0.0, 2.0), cond, t, draw=i + 1)
+        d = float((x - hist[:, i + 1]).abs().max())
+        assert d <= 1e-5, (t, d)
+        assert float(x0.min()) >= 0.0 and float(x0.max()) <= 2.0
+    assert float((hist[:, 1] - hist[:, 0]).abs().max()) > 0.1          # (the states do move: the comparison is not vacuous)
 
 
 def test_cfg1_mnist(golden):

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_host_defaults_are_the_measured_ones():
     t = Tuning.from_env(env={})
-    assert t.describe() == dict(sub_batches=2, min_sub_batch=2, sub_resync=32, sub_resync_early=1, sub_ahead=2,
+    assert t.describe() == dict(sub_batches=2, min_sub_batch=2, sub_resync=32, sub_resync_early=1, sub_ahead=2, sub_joint_graph=False,
                                 fused_final_step=True, fused_step_begin=True, weight_split_levels=0, separate_act=True, sep_act_max_px=1024,
                                 sep_act_min_c=128, fusion_fold=True, linattn_chunk_px=None, kernel={})
     assert t.chunk_rule(4) == (512, 256, 128) and t.chunk_rule(8) == (512, 256, 128) and t.chunk_rule(32) == (1024, 256, 128)
@@ -53,8 +53,8 @@ def test_kernel_table_defaults_and_explicit_sets():
     names = [lib.ld_tuning_name(i).decode() for i in range(lib.ld_tuning_count())]
     assert lib.ld_tuning_name(lib.ld_tuning_count()) is None
     defaults = dict(c1_group=1, c1_group_max_px=32768, c1_group_min_ch=4, c1_pair_max_px=1 << 40, c1_small_min=256, conv_raw=1,
-                    conv_mt4_min_wgs=256, conv_big_min=512, conv_sk=0, conv_sk_max_wgs=256, conv_c32=1, conv_c32_min_tiles=2048,
-                    gn_frags_per_block=512, fold_split_min=32, attn_split_max_wgs=256, attn_split_min_n=2048, lead_args=1)
+                    conv_mt4_min_wgs=256, conv_big_min=512, conv_sk=0, conv_sk_max_wgs=256, conv_c32=1, conv_c32_min_tiles=2048, conv_s32=3, conv_s32_min_tiles=512,
+                    gn_frags_per_block=512, fold_split_min=32, attn_split_max_wgs=256, attn_split_min_n=2048, lead_args=1, attn_xcd_map=1)
     assert sorted(names) == sorted(defaults)
     overridden = {n for n in names if os.environ.get("LD_" + n.upper()) is not None}
     table = kernel_table(lib)

@@ -50,6 +50,11 @@ def run(B, cin, cout, H, W, dtype="bf16", prologue=False, stats=True):
 
 
 if __name__ == "__main__":
+    if os.environ.get("LD_TRACE_SHAPES"):          # "B,cin,cout,H,W,prologue;..."
+        for t in os.environ["LD_TRACE_SHAPES"].split(";"):
+            v = [int(x) for x in t.split(",")]
+            run(v[0], v[1], v[2], v[3], v[4], prologue=bool(v[5]))
+        sys.exit(0)
     run(8, 32, 32, 256, 256, stats=True)
     run(8, 32, 32, 256, 256, prologue=True)
     run(8, 64, 32, 256, 256, stats=True)
