@@ -96,10 +96,20 @@ def test_cfg2_chain_with_two_term_weights(golden, dtype):
 # ---- the end-to-end pin of the storage modes on a WELL-CONDITIONED denoiser (golden G16) ----------------
 # cfg2's shape and schedule run by the real reference on the contractive procedural net (final_conv gain 0.25: a perturbation
 # grows x1.7 in the mean over the last 100 steps and not at all over the last 10, tools/exp_contractive.py), so the distance
-# of the FINAL image is a statement about the implementation and can be bounded in max-abs.  Bounds (max-abs, mean-abs) on
-# the [0, 2] range at t = 100 and at t = 0; measured values are printed and quoted in DESIGN.md section 2.
-G16_BOUNDS = {"fp32": ((1e-4, 1e-5), (1e-4, 1e-5)), "bf16": ((4e-2, 4e-3), (6e-2, 6e-3)), "fp16": ((5e-3, 5e-4), (8e-3, 8e-4)),
-              "bf16x2": ((1.5e-2, 1e-3), (2e-2, 1.5e-3)), "fp16x2": ((2e-3, 1.5e-4), (3e-3, 2e-4))}
+# of the FINAL image is a statement about the implementation and is bounded in MAX-abs.  Bounds (max-abs, mean-abs) on the
+# [0, 2] range through t = 100 and at t <= 10, ~2x what MI355X measured (round 5, printed by the test):
+#             through t = 100          final image (t = 0)
+#   fp32      1.2e-6 / 8.6e-8          2.2e-6 / 2.0e-7     (the reference against itself, 1 thread vs 8: 1.4e-6 / 1.9e-7)
+#   bf16      2.2e-3 / 3.7e-4          9.3e-3 / 7.4e-4
+#   fp16      3.5e-4 / 5.6e-5          2.0e-3 / 1.1e-4
+#   bf16x2    6.6e-4 / 5.2e-5          1.2e-2 / 6.9e-4     (two-term weights on two levels)
+#   fp16x2    6.3e-5 / 6.6e-6          1.4e-3 / 8.7e-5
+# What the last ten steps add in every 16-bit mode is the rounding of ONE evaluation's activations: the posterior weight of
+# x0_hat goes to 1 as t -> 0, so the final image carries the denoiser output's own 16-bit error (a single forward at the
+# bench shape: 6.7e-3 of the range in bf16, 9e-4 in fp16, tests/test_hip_bench_shape.py) -- two-term WEIGHTS remove the
+# chain's accumulated part (t = 100: 6x / 9x closer) and leave that one untouched.
+G16_BOUNDS = {"fp32": ((5e-6, 5e-7), (1e-5, 1e-6)), "bf16": ((4e-3, 7e-4), (2e-2, 1.5e-3)), "fp16": ((7e-4, 1.1e-4), (4e-3, 2.2e-4)),
+              "bf16x2": ((1.3e-3, 1e-4), (2.4e-2, 1.4e-3)), "fp16x2": ((1.3e-4, 1.3e-5), (3e-3, 1.8e-4))}
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16", "bf16x2", "fp16x2"])
@@ -122,8 +132,11 @@ def test_cfg2_contractive_chain_pins_every_storage_mode(golden, mode):
     for t in (10, 0):
         assert e[t][0] <= b0[0] and e[t][1] <= b0[1], (mode, t, e[t])
     assert err(hist[:, -1], g["final"]) == e[0]
-    # the chain is contractive: what the last 100 steps add stays within a small factor of what was there at t = 100
-    assert e[0][1] <= 3.0 * max(e[100][1], 1e-7), (mode, e[100], e[0])
+    if not mode.endswith("x2"):
+        # the chain is contractive: what the last 100 steps add stays within a small factor of what was there at t = 100
+        # (gain 3, G5 / G11: x40-70).  With two-term weights the t = 100 distance is so small that the final evaluation's
+        # activation rounding dominates the end: bounded absolutely above.
+        assert e[0][1] <= 3.0 * max(e[100][1], 1e-7), (mode, e[100], e[0])
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

@@ -28,6 +28,8 @@ def family(name):
     dt = "bf16" if ("DF16b" in name or "bf16" in name or "_Accum" in name) else ("f16" if ("DF16_" in name or "_Float16" in name) else "f32")
     if "conv3x3_c32_kernel" in name:                           # persistent LDS-DMA variant (bench.py names it the same)
         return f"conv3x3_c32<{dt}>"
+    if "conv3x3_s32_kernel" in name:                           # the lean Cout = 32 kernel (conv3x3_s32.hip)
+        return f"conv3x3_s32<{dt}>"
     m = re.search(r"conv3x3_kernelI(?:f|DF16b|DF16_)Li(\d)ELi(\d)E", name) or re.search(r"conv3x3_kernel<[^,]+, (\d), (\d)", name)
     if m:
         return f"conv3x3<{dt},{m.group(1)},{m.group(2)}>"
