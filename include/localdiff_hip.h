@@ -87,7 +87,11 @@ int ld_stream_wait_event(void* stream, void* ev);
  * applies).  Names (defaults): c1_group (1), c1_group_max_px (32768), c1_group_min_ch (4), c1_pair_max_px (2^40),
  * c1_small_min (256), conv_raw (1), conv_mt4_min_wgs (256), conv_big_min (512), conv_sk (0), conv_sk_max_wgs (256),
  * conv_c32 (1), conv_c32_min_tiles (2048), gn_frags_per_block (512), fold_split_min (32), attn_split_max_wgs (256), attn_split_min_n
- * (2048), lead_args (1: gn_apply / conv1x1 launches that qualify use the kernels with preloaded leading arguments).  Values change routing, never
+ * (2048; and the two-key-group kernel is only taken when the second group owns a key: n > tile size), lead_args (1: gn_apply /
+ * conv1x1 launches that qualify use the kernels with preloaded leading arguments), conv_s32 (3: bit mask of the launches the lean
+ * Cout = 32 kernel of conv3x3_s32.hip takes -- 1 single-chunk without prologue, 2 with the GroupNorm prologue, 4 two-chunk),
+ * conv_s32_min_tiles (1024: 16 x 16 tiles per launch from which it is used), attn_xcd_map (1: ld_attention's XCD-aware workgroup
+ * order).  Values change routing, never
  * results beyond the summation order of a tile variant.  Unknown name: LD_EINVAL.  Not thread-safe against concurrent
  * launches (set it before launching).  The reference has no counterpart (its tuning is cuDNN's). */
 int ld_tuning_set(const char* name, long long value);

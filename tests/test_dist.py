@@ -315,6 +315,23 @@ def test_advance_call_state_mirrors_the_sampler_flags():
     assert gd3._mask_x_get() is True
 
 
+def test_kmask_flags_on_the_host():
+    """GaussianDiffusion.kmask_flags (what dist.sample_kmask_sharded reads before it shards anything): the flags of a K-mask
+    call as sample() would take them, without a GPU; the classifier gate is refused across ranks."""
+    import localdiffusion_hallucination_amd as ldh
+    net = ldh.Unet(dim=32, init_dim=32, dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist")
+    base = dict(branch_out=True, start_intermediate=True, start_timestep=2, data="mnist", mask_x=False, ood_AD=True,
+                ood_confidence=False, classifier=False, use_gt=False)
+    masks = torch.zeros(1, 3, 28, 28)
+    gd = ldh.GaussianDiffusion(dict(base), net, image_size=28, timesteps=10, objective="pred_x0")
+    assert gd.kmask_flags(masks) == (True, True, True)             # ood_AD arms mask_x (ddpm.py:1106-1108)
+    gd = ldh.GaussianDiffusion(dict(base, ood_AD=False, start_intermediate=False), net, image_size=28, timesteps=10, objective="pred_x0")
+    assert gd.kmask_flags(masks) == (True, False, False)
+    gd = ldh.GaussianDiffusion(dict(base, classifier=True), net, image_size=28, timesteps=10, objective="pred_x0")
+    with pytest.raises(ValueError):
+        gd.kmask_flags(masks)
+
+
 def test_recompose_has_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         ldist.recompose(torch.zeros(1, 2, 1, 4, 4), torch.zeros(2, 1, 4, 4))

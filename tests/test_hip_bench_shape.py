@@ -67,21 +67,26 @@ def _oracle_forward(sd, cfg, B):
 @pytest.mark.parametrize("B", [4, 8])
 def test_forward_16bit_at_the_bench_shape_matches_oracle(dtype, B):
     """One denoiser evaluation of B bench patches in 16-bit storage against the fp32 oracle, output and every recorded tap.
-    B = 4 is the plan of a timed sub-batch (no persistent conv: 1,024 tiles < 2,048); B = 8 is the solo leg's plan, whose
-    eight 32->32 @256^2 convolutions must have run on the persistent LDS-DMA kernel (launch counter)."""
+    B = 4 is the plan of a timed sub-batch: its eight 32->32 @256^2 convolutions run on the lean kernel (conv3x3_s32.hip,
+    round 5; no persistent conv: 1,024 tiles < 2,048), the four 64->32 ones on the generic kernel; B = 8 is the solo leg's
+    plan, whose eight 32->32 @256^2 convolutions must have run on the persistent LDS-DMA kernel (launch counters)."""
     net, sd = _net(dtype)
     x, cond, tv, y_ref, taps = _oracle_forward(sd, net.cfg, B)
-    c32 = cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32)
+    lib = cabi.lib()
+    c32, s32 = lib.ld_counter(cabi.COUNTER_CONV3X3_C32), lib.ld_counter(cabi.COUNTER_CONV3X3_S32)
     y = net(x.cuda(), cond.cuda(), tv.cuda()).cpu()
-    ran_c32 = cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32) - c32
+    ran_c32, ran_s32 = lib.ld_counter(cabi.COUNTER_CONV3X3_C32) - c32, lib.ld_counter(cabi.COUNTER_CONV3X3_S32) - s32
     plan = net.plan(B, H, H)
     fams = [(m.get("family", ""), m.get("shape", "")) for m in plan.meta.values()]
     n_c32 = sum(f.startswith("conv3x3_c32") for f, _ in fams)
+    n_s32 = sum(f.startswith("conv3x3_s32") for f, _ in fams)
     if B == 8:                                 # (+ one 32->32 @256^2 convolution of the conditioning encoder)
-        assert ran_c32 >= 8 and n_c32 == 8, (ran_c32, n_c32)
-    else:
+        assert ran_c32 >= 8 and n_c32 == 8 and n_s32 == 0, (ran_c32, n_c32, n_s32)
+    else:                                      # (the encoder's 32->32 convolution at 256^2 runs on the lean kernel too)
         assert ran_c32 == 0 and n_c32 == 0, (ran_c32, n_c32)
-        assert sum(f.startswith("conv3x3<") and s == "32->32@256x256" for f, s in fams) == 8, fams
+        assert ran_s32 >= 8 and n_s32 == 8, (ran_s32, n_s32)
+        assert sum(f.startswith("conv3x3_s32") and s == "32->32@256x256" for f, s in fams) == 8, fams
+        assert sum(f.startswith("conv3x3<") and s == "64->32@256x256" for f, s in fams) == 4, fams
     worst = ("", 0.0)
     for name, buf in plan.named.items():
         if name not in taps:
