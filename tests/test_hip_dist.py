@@ -190,6 +190,36 @@ def test_kmask_units_sharded_equal_the_unsharded_loop_and_the_reference_goldens(
             assert d <= 1e-5
 
 
+def test_kmask_units_sharded_with_the_use_gt_start():
+    """The shortened chain of ddpm.py:937-944 (x_T = q_sample(hr, use_gt_timestep), start at use_gt_timestep - 1) through the
+    two halves: units over 3 emulated ranks against the unsharded K-mask loop, for the data mode whose OOD branch skips the
+    denoiser as well (its state still steps with the shared draw)."""
+    K, B, H, T = 3, 2, 32, 40
+    masks = torch.zeros(B, K, H, H)
+    masks[:, 0, :, :8] = 1.0
+    masks[:, 1, :, 8:20] = 1.0
+    masks[:, 2, :, 20:] = 1.0
+    masks = masks.cuda()
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 47, 1, 0.0, 2.0)).cuda()
+    hr = torch.from_numpy(rng.uniform((B, 1, H, H), 48, 1, 0.0, 2.0)).cuda()
+    for data in ("mri", "mnist"):
+        conf = dict(data=data, branch_out=True, start_intermediate=True, start_timestep=3, mask_x=True, use_gt=True, use_gt_timestep=12)
+        gd = make(dict(mode="mri"), conf, H, T)
+        want = gd.sample(cond, hr, batch_size=B, mask=masks, min_max_val=(0.0, 2.0)).cpu().numpy()
+        gd.reset_call_state()
+        parts, where = [], None
+        for r in range(3):
+            lo, hi = ldist.shard_bounds(K * B, 3, r)
+            p, where = gd.kmask_branch_units(cond, masks, (0.0, 2.0), lo, hi, gt=hr)
+            parts.append(p)
+        assert where[0] == 3                                   # the exchange sits at t = start_timestep
+        pay = torch.cat(parts, 0)
+        got = torch.cat([gd.kmask_fuse_joint(cond, masks, (0.0, 2.0), pay, where, *ldist.shard_bounds(B, 3, r)) for r in range(3)], 0)
+        d = float(np.abs(got.cpu().numpy() - want).max())
+        print(f"use_gt start, {data}: units over 3 emulated ranks vs the unsharded loop: max-abs {d:.3e}")
+        assert d <= 1e-5
+
+
 def test_kmask_sharded_world1_through_ld_allgather():
     """dist.sample_kmask_sharded end to end at world size 1 with the C ABI's own communicator (ld_comm_* / ld_allgather,
     RCCL through dlopen): both exchanges go through the collective; equal to the plain call, for the non-MRI data mode as
