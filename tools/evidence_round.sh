@@ -15,7 +15,9 @@ bash tools/pmc_mfma.sh $TAG >> $OUT/${TAG}_profile_round.log 2>&1
 bash tools/pmc_mfma.sh $TAG default >> $OUT/${TAG}_profile_round.log 2>&1
 cd /tmp
 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-dtype 2> /dev/null | tail -1 > $OUT/${TAG}_bench_steps20.json
+# the complete default line exactly as the driver runs it (every leg: roofline, other dtype, G16 distance, CPU baseline)
+python3 $R/bench.py --steps 20 --warmup 5 2> /dev/null | tail -1 > $OUT/${TAG}_bench_driver.json
 python3 $R/bench.py --patches 64 --steps 60 --no-cpu-baseline --no-other-dtype 2> /dev/null | tail -1 > $OUT/${TAG}_p64_bench.json
 python3 $R/bench.py --dtype fp16 --weight-split-levels 2 --no-cpu-baseline --no-other-dtype --no-roofline 2> /dev/null | tail -1 > $OUT/${TAG}_fp16x2_bench.json
-for f in bench s1_bench fp16_bench bench_steps20 p64_bench cfg5_bench fp16x2_bench; do python3 -c "
+for f in bench s1_bench fp16_bench bench_steps20 bench_driver p64_bench cfg5_bench fp16x2_bench; do python3 -c "
 import json,sys; d=json.load(open('$OUT/${TAG}_$f.json')); print('%-16s' % '$f', d['value'], d['unit'], d['ms_per_step'], 'ms/step', d.get('roofline',{}).get('frac'))"; done
