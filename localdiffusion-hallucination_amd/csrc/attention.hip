@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256 * KS) void attention_mfma_kernel(const T* __res
     float r0[4] = {o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv};
     float r1[4] = {o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
     const uint4 w16 = pair_frag16<T>(r0, r1);
-    if (qi < n) *reinterpret_cast<uint4*>(op + pair_frag16_off(kg)) = w16;
+    if (qi < n) store16_out(op + pair_frag16_off(kg), w16);
   }
 }
 

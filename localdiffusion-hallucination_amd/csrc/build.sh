@@ -2,6 +2,7 @@
 # Build liblocaldiff_hip.so for gfx950 (cross-compiles without a GPU).
 #   ./build.sh                   incremental: recompile the sources that are newer than their objects
 #   ./build.sh --clean           remove build/ and the library first (what __graft_entry__.build() does by default)
+#   ./build.sh --plain-stores    the A/B build of finding 98: plain instead of write-through (sc1) output stores
 #   ./build.sh --debug-variants  also instantiate the LD_CONV_DEBUG ablation / trace kernels (-DLD_DEBUG_VARIANTS);
 #                                the flag is recorded in build/.flags, so switching it rebuilds everything
 set -e
@@ -15,6 +16,7 @@ for arg in "$@"; do
   case "$arg" in
     --clean) CLEAN=1 ;;
     --debug-variants) FLAGS="$FLAGS -DLD_DEBUG_VARIANTS" ;;
+    --plain-stores) FLAGS="$FLAGS -DLD_STORE_WT=0" ;;      # A/B build: plain instead of write-through output stores (finding 98)
     *) echo "build.sh: unknown option $arg" >&2; exit 2 ;;
   esac
 done

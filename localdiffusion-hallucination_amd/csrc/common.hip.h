@@ -281,6 +281,29 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// ---------------------------------------------------------------- output stores that do not stay dirty in L2
+// The eight L2s are not coherent with each other, so the release at the end of a kernel writes every dirty line back before
+// the next kernel of the stream may start: a launch that leaves its plain-stored output in L2 pays for that write-back at its
+// boundary (MI355X_MICROARCH.md, price list "boundary": + B / 6 TB/s behind B dirty bytes; fence table: a release is ~1.7 us
+// clean and ~6.5 us behind freshly dirtied lines).  An `sc1` store is written THROUGH as it is issued -- the write-back
+// overlaps the kernel instead of trailing it -- and leaves no line behind; the consumer is the NEXT kernel, on any XCD, and
+// would read through the fabric anyway.  Measured (finding 98): 32->32 @256^2 alone 11.1 -> 9.6 us (x 4 patches, with
+// statistics), 20.9 -> 16.4 (x 8).  Every 16-byte output store of the activations goes through here (LD_STORE_WT=0: plain
+// stores, `build.sh --plain-stores`, the A/B build).  The asm store is invisible to hipcc's s_waitcnt bookkeeping (nothing later
+// in a kernel depends on its output) and ends in `s_nop 1`: the next instruction must not overwrite its data registers before
+// the store has read them (cdna_hip_programming.md 5.7 item 1).
+#ifndef LD_STORE_WT
+#define LD_STORE_WT 1
+#endif
+__device__ __forceinline__ void store16_out(void* p, const uint4& v) {
+#if LD_STORE_WT
+  const u32x4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#else
+  *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+
 // ---------------------------------------------------------------- kernel-argument layout
 // Byte offset, in the kernel-argument segment, of the argument that follows leading arguments of types Lead... and has
 // alignment `align` (each argument sits at its natural alignment, in order): where a kernel finds its trailing by-value

@@ -401,7 +401,7 @@ __device__ __forceinline__ void conv1x1_body(const Conv1Dev& head, Conv1KernargP
 #pragma unroll
       for (int m = 0; m < MT; m += 2) {
         const uint4 w16 = pair_frag16<T>(v[m], v[m + 1]);
-        if (valid) *reinterpret_cast<uint4*>(reinterpret_cast<char*>(opix + m * 16) + pair_frag16_off(kq)) = w16;
+        if (valid) store16_out(reinterpret_cast<char*>(opix + m * 16) + pair_frag16_off(kq), w16);
       }
     } else if (valid) {
 #pragma unroll

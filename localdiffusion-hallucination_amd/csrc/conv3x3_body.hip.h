@@ -429,7 +429,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
         if constexpr (MS == 2) {
           const uint4 w16 = pair_frag16<T>(v[0], v[1]);      // all lanes: the exchange is unconditional
           const unsigned off = lane_off - kq * 4 * (unsigned)sizeof(T) + j * row_off + m * 16 * (unsigned)sizeof(T) + pair_frag16_off(kq);
-          if (valid && !(DBG & 8)) *reinterpret_cast<uint4*>(outb + off) = w16;
+          if (valid && !(DBG & 8)) store16_out(outb + off, w16);
         } else {
           const unsigned off = lane_off + j * row_off + m * 16 * (unsigned)sizeof(T);
           if (valid && !(DBG & 8)) store4<T>(reinterpret_cast<T*>(outb + off), v[0]);

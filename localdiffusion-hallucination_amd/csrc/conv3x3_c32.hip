@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64 * NWAVE) void conv3x3_c32_kernel(C32Dev a) {
             }
             T* pix = out + (size_t)(((b * H + gy) * W + gx) * 32 + m * 16);
             if constexpr (MS == 2)      // ONE 16-byte store per lane for the pair of m-tiles: a wave writes 1 KiB contiguous
-              *reinterpret_cast<uint4*>(reinterpret_cast<char*>(pix) + pair_frag16_off(kq)) = pair_frag16<T>(v[0], v[1]);
+              store16_out(reinterpret_cast<char*>(pix) + pair_frag16_off(kq), pair_frag16<T>(v[0], v[1]));
             else
               store4<T>(pix + kq * 4, v[0]);
 #pragma unroll

@@ -223,7 +223,7 @@ void conv3x3_s32_kernel(const void* data0, const void* wts, int hw, int ld0, int
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[m][r] = acc[m][j][r] + bias[m][r];
-    *reinterpret_cast<uint4*>(outp + lane_off + j * row_off) = pair_frag16<T>(v[0], v[1]);
+    store16_out(outp + lane_off + j * row_off, pair_frag16<T>(v[0], v[1]));
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       // (the generic kernel's order: per channel over the rows, then the four channels of the fragment)

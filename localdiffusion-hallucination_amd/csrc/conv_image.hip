@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_stem_mfma_kernel(const float* __rest
           r4[m][0] = acc[m][0] + bv[m].x; r4[m][1] = acc[m][1] + bv[m].y; r4[m][2] = acc[m][2] + bv[m].z; r4[m][3] = acc[m][3] + bv[m].w;
         }
         const uint4 w16 = pair_frag16<T>(r4[0], r4[1]);
-        if (in) *reinterpret_cast<uint4*>(op + pair_frag16_off(kq)) = w16;
+        if (in) store16_out(op + pair_frag16_off(kq), w16);
       }
     }
   }

@@ -103,7 +103,7 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& head, const int bx, c
         for (int e = 0; e < E; ++e) v[e] = fmaxf(v[e], u[e]);
       }
     }
-    *reinterpret_cast<uint4*>(out + (size_t)opix * C + c) = pack16<T>(v);
+    store16_out(out + (size_t)opix * C + c, pack16<T>(v));
   };
   if (256 % fpp == 0) {
     const int c = (tid % fpp) * E, ppb = 256 / fpp;    // pixels per block-iteration
@@ -134,8 +134,8 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& head, const int bx, c
         float v0[E], v1[E];
         finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, ra0, rb0, v0);
         finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, ra1, rb1, v1);
-        *reinterpret_cast<uint4*>(out + (size_t)opix * C + c) = pack16<T>(v0);
-        *reinterpret_cast<uint4*>(out + (size_t)(opix + step) * C + c) = pack16<T>(v1);
+        store16_out(out + (size_t)opix * C + c, pack16<T>(v0));
+        store16_out(out + (size_t)(opix + step) * C + c, pack16<T>(v1));
       } else {
         one(opix, c, ca, sa, cb, sb);
         one(opix + step, c, ca, sa, cb, sb);
@@ -145,7 +145,7 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& head, const int bx, c
       if (!POOL && first) {                            // a single pixel, already here
         float v0[E];
         finish_pixel<T, HAS_B>(g, ca, sa, cb, sb, make_uint4(pa0[0], pa0[1], pa0[2], pa0[3]), make_uint4(pb0[0], pb0[1], pb0[2], pb0[3]), v0);
-        *reinterpret_cast<uint4*>(out + (size_t)opix * C + c) = pack16<T>(v0);
+        store16_out(out + (size_t)opix * C + c, pack16<T>(v0));
       } else {
         one(opix, c, ca, sa, cb, sb);
       }

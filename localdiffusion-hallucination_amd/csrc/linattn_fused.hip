@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void linout_kernel(LINOUT_PARAMS) {
           r4[mm][2] = y[mq][2] * inv * gv.z + xr[2]; r4[mm][3] = y[mq][3] * inv * gv.w + xr[3];
         }
         const uint4 w16 = pair_frag16<T>(r4[0], r4[1]);
-        if (valid) *reinterpret_cast<uint4*>(opix + m2 * 16 * sizeof(T) + pair_frag16_off(kq)) = w16;
+        if (valid) store16_out(opix + m2 * 16 * sizeof(T) + pair_frag16_off(kq), w16);
       }
     }
   }
