@@ -16,7 +16,8 @@ for arg in "$@"; do
   case "$arg" in
     --clean) CLEAN=1 ;;
     --debug-variants) FLAGS="$FLAGS -DLD_DEBUG_VARIANTS" ;;
-    --plain-stores) FLAGS="$FLAGS -DLD_STORE_WT=0" ;;      # A/B build: plain instead of write-through output stores (finding 98)
+    --plain-stores) FLAGS="$FLAGS -DLD_STORE_WT=0" ;;
+    --wt-level=*) FLAGS="$FLAGS -DLD_STORE_WT=${arg#--wt-level=}" ;;   # experiments: 0 plain, 1 the 16-byte activation stores, 2 + the narrow ones      # A/B build: plain instead of write-through output stores (finding 98)
     *) echo "build.sh: unknown option $arg" >&2; exit 2 ;;
   esac
 done

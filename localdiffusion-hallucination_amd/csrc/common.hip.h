@@ -303,6 +303,27 @@ __device__ __forceinline__ void store16_out(void* p, const uint4& v) {
   *reinterpret_cast<uint4*>(p) = v;
 #endif
 }
+// The same for the narrow stores of small outputs (kvctx's partial sums, ctxfold's folded weights, the final step's NCHW
+// images): a relaxed agent-scope atomic store IS a `global_store_dword / _short ... sc1`.  Narrow write-through stores cost
+// ~6-12x a 16-byte one per byte (each 64-byte segment is its own fabric write), so this level is only worth it where the
+// bytes are few and what matters is that the kernel ends with clean L2s (LD_STORE_WT >= 2).  MEASURED AND NOT KEPT: with the
+// narrow stores written through as well the step is 1.263 -> 1.281 ms (+1.4 %, three alternating pairs, `build.sh
+// --wt-level=2`): level 1 stays the default and these compile to plain stores.
+__device__ __forceinline__ void store_f32_out(float* p, float v) {
+#if LD_STORE_WT >= 2
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+template <typename T> __device__ __forceinline__ void store_elem_out(T* p, T v) {
+#if LD_STORE_WT >= 2
+  if constexpr (sizeof(T) == 2) __hip_atomic_store(reinterpret_cast<unsigned short*>(p), __builtin_bit_cast(unsigned short, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
 
 // ---------------------------------------------------------------- kernel-argument layout
 // Byte offset, in the kernel-argument segment, of the argument that follows leading arguments of types Lead... and has
@@ -328,8 +349,8 @@ struct StepBeginDev {
 __device__ __forceinline__ void step_begin_work(const StepBeginDev& s, long e, long ne, int* s_t) {
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
   const long stride = ne * blockDim.x;
-  for (long i = e * blockDim.x + threadIdx.x; i < s.na; i += stride) s.a[i] = z;
-  for (long i = e * blockDim.x + threadIdx.x; i < s.nb; i += stride) s.b[i] = z;
+  for (long i = e * blockDim.x + threadIdx.x; i < s.na; i += stride) store16_out(&s.a[i], z);     // (write-through: finding 98)
+  for (long i = e * blockDim.x + threadIdx.x; i < s.nb; i += stride) store16_out(&s.b[i], z);
   if (e == 0) {
     if (threadIdx.x == 0) {
       int tn = s.t ? *s.t : 0;
@@ -348,7 +369,10 @@ __device__ __forceinline__ void step_begin_work(const StepBeginDev& s, long e, l
       __syncthreads();
       const float4* src = reinterpret_cast<const float4*>(s.film_rows + (size_t)*s_t * s.row_floats);
       float4* dst = reinterpret_cast<float4*>(s.film_cur);
-      for (int i = threadIdx.x; i < s.row_floats / 4; i += blockDim.x) dst[i] = src[i];
+      for (int i = threadIdx.x; i < s.row_floats / 4; i += blockDim.x) {
+        const float4 v = src[i];
+        store16_out(&dst[i], make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)));
+      }
     }
   }
 }

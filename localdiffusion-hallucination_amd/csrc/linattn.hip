@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ ctx
     if (perm) {   // chained-MFMA operand order (linattn_fused.hip): ci = 32s + 16(e>>2) + 4kq + (e&3), bf16 only
       ch = ci >> 5; kq = (ci >> 2) & 3; e = ((ci >> 4) & 1) * 4 + (ci & 3);
     }
-    dst[((((size_t)ch * mt_total + mt) * 4 + kq) * 16 + ii) * E + e] = from_f<T>(m);
+    store_elem_out<T>(&dst[((((size_t)ch * mt_total + mt) * 4 + kq) * 16 + ii) * E + e], from_f<T>(m));
   }
 }
 
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void ctxfold_kernel(const float* __restrict__ 
     const int mt = co >> 4, ii = co & 15;
     int ch = ci / CK, kq = (ci % CK) / E, e = ci % E;
     if (perm) { ch = ci >> 5; kq = (ci >> 2) & 3; e = ((ci >> 4) & 1) * 4 + (ci & 3); }
-    dst[((((size_t)ch * mt_total + mt) * 4 + kq) * 16 + ii) * E + e] = from_f<T>(m);
+    store_elem_out<T>(&dst[((((size_t)ch * mt_total + mt) * 4 + kq) * 16 + ii) * E + e], from_f<T>(m));
   }
 }
 

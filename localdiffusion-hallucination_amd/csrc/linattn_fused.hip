@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KVCTX_PARAMS) {
   }
   float* dst = a.ctx_part + (((size_t)b * a.heads + h) * a.nchunks + ck) * CTX_STRIDE;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) dst[(dt * 16 + kq * 4 + r) * 32 + et * 16 + li] = cacc[r];
+  for (int r = 0; r < 4; ++r) store_f32_out(&dst[(dt * 16 + kq * 4 + r) * 32 + et * 16 + li], cacc[r]);
   // Z: lanes -> waves -> block, fixed order (deterministic)
   __syncthreads();
   float* s_z = reinterpret_cast<float*>(s_p);           // [4][32]
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KVCTX_PARAMS) {
     }
   __syncthreads();
   if (tid < 32) {
-    dst[1024 + tid] = s_z[tid] + s_z[32 + tid] + s_z[64 + tid] + s_z[96 + tid];
-    dst[1056 + tid] = fmaxf(fmaxf(s_m[tid], s_m[32 + tid]), fmaxf(s_m[64 + tid], s_m[96 + tid]));
+    store_f32_out(&dst[1024 + tid], s_z[tid] + s_z[32 + tid] + s_z[64 + tid] + s_z[96 + tid]);
+    store_f32_out(&dst[1056 + tid], fmaxf(fmaxf(s_m[tid], s_m[32 + tid]), fmaxf(s_m[64 + tid], s_m[96 + tid])));
   }
 }
 
@@ -399,15 +399,15 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KVCTX_PARAMS) {
 #pragma unroll
     for (int et = 0; et < 2; ++et)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(dt * 16 + kq * 4 + r) * 32 + et * 16 + li] = cacc[dt][et][r];
+      for (int r = 0; r < 4; ++r) store_f32_out(&dst[(dt * 16 + kq * 4 + r) * 32 + et * 16 + li], cacc[dt][et][r]);
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float z = wave16_sum(zs[m][r]);
       if (li == 0) {
-        dst[1024 + 16 * m + 4 * kq + r] = z;
-        dst[1056 + 16 * m + 4 * kq + r] = mloc[m][r];
+        store_f32_out(&dst[1024 + 16 * m + 4 * kq + r], z);
+        store_f32_out(&dst[1056 + 16 * m + 4 * kq + r], mloc[m][r]);
       }
     }
 }

@@ -333,7 +333,7 @@ __global__ void final_step_kernel(const T* __restrict__ x, const float* __restri
     for (int o = 0; o < Cout; ++o) {
       const size_t idx = ((size_t)b * Cout + o) * HW + p;
       const float mo = keep ? acc[o] + bias[o] : lo;
-      model_out[idx] = mo;
+      store_f32_out(&model_out[idx], mo);
       const float xi = x_t[idx];
       const float x0 = clampf(to_x0(xi, mo, row, obj), lo, hi);
       const float mean = c1 * x0 + c2 * xi;
@@ -344,8 +344,8 @@ __global__ void final_step_kernel(const T* __restrict__ x, const float* __restri
         const float u2 = (float)(unsigned)((h >> 16) & 0xFFFFFFu) * 5.9604644775390625e-8f;
         r = mean + sg * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
       }
-      x_t[idx] = r;
-      if (x0o) x0o[idx] = x0;
+      store_f32_out(&x_t[idx], r);
+      if (x0o) store_f32_out(&x0o[idx], x0);
     }
   }
 }

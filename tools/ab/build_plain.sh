@@ -7,6 +7,6 @@ TMP=/tmp/ld_plain_build
 mkdir -p $TMP/localdiffusion-hallucination_amd/csrc $TMP/include
 cp $ROOT/localdiffusion-hallucination_amd/csrc/*.hip $ROOT/localdiffusion-hallucination_amd/csrc/*.h $ROOT/localdiffusion-hallucination_amd/csrc/build.sh $TMP/localdiffusion-hallucination_amd/csrc/
 cp $ROOT/include/*.h $TMP/include/
-(cd $TMP/localdiffusion-hallucination_amd/csrc && bash build.sh --plain-stores)
-cp $TMP/localdiffusion-hallucination_amd/csrc/liblocaldiff_hip.so $ROOT/tools/ab/libplain.so
-echo "built $ROOT/tools/ab/libplain.so"
+(cd $TMP/localdiffusion-hallucination_amd/csrc && bash build.sh ${1:---plain-stores})
+cp $TMP/localdiffusion-hallucination_amd/csrc/liblocaldiff_hip.so $ROOT/tools/ab/${2:-libplain.so}
+echo "built $ROOT/tools/ab/${2:-libplain.so}"
