@@ -86,7 +86,7 @@ int ld_stream_wait_event(void* stream, void* ev);
  * table is first used, and explicit control through ld_tuning_set (what localdiffusion_hallucination_amd.tuning.Tuning
  * applies).  Names (defaults): c1_group (1), c1_group_max_px (32768), c1_group_min_ch (4), c1_pair_max_px (2^40),
  * c1_small_min (256), conv_raw (1), conv_mt4_min_wgs (256), conv_big_min (512), conv_sk (0), conv_sk_max_wgs (256),
- * conv_c32 (1), conv_c32_min_tiles (2048), gn_frags_per_block (512), fold_split_min (32), attn_split_max_wgs (256), attn_split_min_n
+ * conv_c32 (0: the persistent LDS-DMA kernel is retired from the default routing, finding 99), conv_c32_min_tiles (2048), gn_frags_per_block (512), fold_split_min (32), attn_split_max_wgs (256), attn_split_min_n
  * (2048; and the two-key-group kernel is only taken when the second group owns a key: n > tile size), lead_args (1: gn_apply /
  * conv1x1 launches that qualify use the kernels with preloaded leading arguments), conv_s32 (3: bit mask of the launches the lean
  * Cout = 32 kernel of conv3x3_s32.hip takes -- 1 single-chunk without prologue, 2 with the GroupNorm prologue, 4 two-chunk),

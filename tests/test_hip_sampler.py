@@ -558,13 +558,13 @@ def test_cfg3_shape_sub_batches_and_batch_independence():
     assert float(np.abs(same - same[:1]).max()) == 0.0, "identical patches in one batch must give identical outputs"
 
 
-def test_cfg4_per_gpu_share_64_patches_runs_the_persistent_conv():
+def test_cfg4_per_gpu_share_64_patches_and_its_large_launches():
     """BASELINE.json configs[3]'s per-GPU share at full size: 64 patches of 3x256x256 (8 images x 8 band masks), bf16,
     as the bench's `--patches 64` runs them -- two concurrent sub-batches of 32, whose 32->32 @256^2 convolutions are
-    8,192-tile launches of the PERSISTENT LDS-DMA kernel (conv3x3_c32.hip), a launch mix the cfg3 timed region never
-    sees.  Size-independent properties: two sub-batches of 32 == one batch of 64 within the bf16 bound; the first
-    sub-batch == a plain batch of its 32 patches bit for bit; a replay is bitwise equal; and the launch counters show
-    that the persistent kernel ran."""
+    8,192-tile launches (rounds 2-4: of the persistent LDS-DMA kernel; since round 5 of the lean kernel, conv3x3_s32.hip), a
+    launch mix the cfg3 timed region never sees.  Size-independent properties: two sub-batches of 32 == one batch of 64
+    within the bf16 bound; the first sub-batch == a plain batch of its 32 patches bit for bit; a replay is bitwise equal; and
+    the launch counters show which kernel ran."""
     from localdiffusion_hallucination_amd import _cabi as cabi
     H, B, T = 256, 64, 6
     net = ldh.Unet(dim=32, init_dim=32, channels=3, out_dim=3, mode="mvtec", compute_dtype="bf16")
@@ -582,19 +582,21 @@ def test_cfg4_per_gpu_share_64_patches_runs_the_persistent_conv():
     imgs = torch.from_numpy(rng.uniform((B // K, 3, H, H), 64, 1, 0.0, 2.0))
     cond = torch.stack([imgs[i] * (masks[k] if k == 0 else torch.clip(masks[k], 0.95, 1.0))
                         for i in range(B // K) for k in range(K)])
-    c32_before = cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32)
+    # (the large-launch kernel of the C = 32 stages: the lean kernel since round 5 -- with write-through output stores it beats
+    #  the persistent LDS-DMA kernel at 8, 32 and 64 patches per launch, finding 99)
+    s32_before = cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_S32)
     gd.sub_batches = 1
     single = run(gd, cond, None, B)
-    assert cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32) > c32_before, "one batch of 64 did not use the persistent conv"
+    assert cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_S32) > s32_before, "one batch of 64 did not use the lean C = 32 kernel"
     gd.sub_batches, gd.min_sub_batch = 2, 4
-    c32_before = cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32)
+    s32_before = cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_S32)
     split = run(gd, cond, None, B)
     sub = gd._subs[(id(net.plan(B, H, H, table_T=T)), 2)]
     assert sub.b == 32 and len(sub.plans) == 2
-    assert cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_C32) > c32_before, "the 32-patch sub-batches did not use the persistent conv"
+    assert cabi.lib().ld_counter(cabi.COUNTER_CONV3X3_S32) > s32_before, "the 32-patch sub-batches did not use the lean C = 32 kernel"
     fams = [(m.get("family", ""), m.get("shape", "")) for m in sub.plans[0].meta.values()]
     # the eight 32->32 @256^2 convolutions (at 32 patches per launch the four 32->32 @128^2 ones qualify as well)
-    assert sum(f.startswith("conv3x3_c32") and s == "32->32@256x256" for f, s in fams) == 8, fams
+    assert sum(f.startswith("conv3x3_s32") and s == "32->32@256x256" for f, s in fams) == 8, fams
 
     def close(tag, x, y):
         d = np.abs(x - y)
