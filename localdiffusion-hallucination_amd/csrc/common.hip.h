@@ -158,8 +158,9 @@ template <> __device__ __forceinline__ uint4 pack16<f16>(const float* v) {
 
 // 4 consecutive output channels (one accumulator fragment) -> 8 or 16 bytes
 template <typename T> __device__ __forceinline__ void store4(T* p, const float* v);
+__device__ __forceinline__ void store16_out(void* p, const uint4& v);       // (below: write-through output stores)
 template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
-  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  store16_out(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
 }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));

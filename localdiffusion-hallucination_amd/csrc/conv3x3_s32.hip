@@ -18,6 +18,9 @@
 //   * the statistics of the result leave as fp64 atomics straight from each wave (16-lane DPP sums, lanes px == 0 add
 //     their (m-tile, kq) entry -- one group each at 4 channels per group): no LDS, no barrier, and a wave that has
 //     issued its atomics is finished.
+//   * the output leaves by write-through stores (store16_out, common.hip.h; finding 98): 32->32 @256^2 x 4 patches alone
+//     9.3 / 9.6 / 13.6 us (plain / statistics / prologue) = 0.50 / 0.48 / 0.34 of 8 TB/s, x 8 patches 13.4 / 15.2 / 23.5 (0.63 /
+//     0.55 / 0.36) -- which also retired the persistent LDS-DMA kernel (conv3x3_c32.hip) from the default routing (finding 99).
 // Routing: ld_conv3x3_s32_try (below); everything it does not take falls through to the generic kernel.
 #include "common.hip.h"
 
