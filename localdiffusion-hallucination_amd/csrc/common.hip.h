@@ -439,6 +439,7 @@ static inline SrcDev to_dev(const ld_src& s) {
 // after_issue: called once every request of the head has left and before the first wait -- a caller whose remaining
 // kernel arguments are read late (finding 84) requests them there, under the statistics' round trip.
 struct GnNoHook { __device__ __forceinline__ void operator()() const {} };
+__device__ __forceinline__ double row_group_sum_d(double v, int n);       // (below)
 template <bool PRECISE = true, typename F = GnNoHook>
 __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, long npix, float* coef,
                                               double* red, int tid, int nthreads, F after_issue = F()) {
@@ -459,28 +460,40 @@ __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, 
     g0 = S.gamma[tid]; b0 = S.beta[tid];
     f0 = fp[tid]; f1 = fp[(film ? C : 0) + tid];
   }
-  double st1[LD_STAT_STRIPES], st2[LD_STAT_STRIPES];
-  if (tid < G) {
-    const double* p = S.stats + (size_t)b * LD_STAT_STRIPES * G * 2 + 2 * tid;
+  // Stripe sums: 16 lanes per group (thread g * 16 + s takes stripes s, s + 16, ... of group g: LD_STAT_STRIPES / 16 pairs
+  // of doubles each), the 16 partial sums meet by DPP inside the 16-lane row.  (Until round 5: G threads x 2 * 16 loads and a
+  // sequential fp64 chain; with 64 stripes that would be 128 loads per thread.)
+  constexpr int SPL = LD_STAT_STRIPES / 16;
+  static_assert(LD_STAT_STRIPES % 16 == 0, "stripes are reduced 16 lanes at a time");
+  double st1[SPL], st2[SPL];
+  const int sg = tid >> 4, sl = tid & 15;
+  const bool lead = tid < 16 * G;                        // (whole 16-lane rows: the DPP row sums need every lane of a row;
+                                                         //  16 * G <= nthreads: G <= 16 at 256 threads, checked on the host)
+  if (lead) {
+    const double* p = S.stats + ((size_t)b * LD_STAT_STRIPES + sl) * G * 2 + 2 * sg;
 #pragma unroll
-    for (int s = 0; s < LD_STAT_STRIPES; ++s) { st1[s] = p[(size_t)s * G * 2]; st2[s] = p[(size_t)s * G * 2 + 1]; }
+    for (int k = 0; k < SPL; ++k) { st1[k] = p[(size_t)k * 16 * G * 2]; st2[k] = p[(size_t)k * 16 * G * 2 + 1]; }
     __builtin_amdgcn_sched_barrier(0);
   }
   after_issue();
   // (opaque from here on: hipcc otherwise computes `f0 + 1` right behind its load, in front of the statistics requests)
   asm volatile("" : "+v"(g0), "+v"(b0), "+v"(f0), "+v"(f1));
-  if (tid < G) {
-    // sum the stripes in fp64, then ONE double divide/sqrt per group (not per channel)
+  if (lead) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int s = 0; s < LD_STAT_STRIPES; ++s) { s1 += st1[s]; s2 += st2[s]; }
+    for (int k = 0; k < SPL; ++k) { s1 += st1[k]; s2 += st2[k]; }
+    s1 = row_group_sum_d(s1, 16);
+    s2 = row_group_sum_d(s2, 16);
+    // ONE double divide/sqrt per group (not per channel)
     const double inv_n = PRECISE ? 1.0 / ((double)npix * gs) : (double)__builtin_amdgcn_rcpf((float)npix * (float)gs);
     const double mean = s1 * inv_n;
     double var = s2 * inv_n - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const float rstd = PRECISE ? (float)(1.0 / sqrt(var + 1e-5)) : __builtin_amdgcn_rsqf((float)(var + 1e-5));
-    gstat[tid] = (float)mean;
-    gstat[G + tid] = rstd;
+    if (sl == 0) {
+      gstat[sg] = (float)mean;
+      gstat[G + sg] = rstd;
+    }
   }
   __syncthreads();
   for (int c = tid; c < C; c += nthreads) {

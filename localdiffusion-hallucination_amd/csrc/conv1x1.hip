@@ -621,6 +621,7 @@ extern "C" int ld_conv1x1(const ld_conv1x1_args* p, void* stream) {
   a.kmax = (p->epilogue == LD_EPI_QKV_LINEAR) ? p->kmax_out : nullptr;
   if (p->epilogue == LD_EPI_GN_TAIL) {
     const ld_src& t = p->gn_tail;
+    LD_REQUIRE(t.gn_groups <= 16, "ld_conv1x1: gn_tail groups %d > 16 (the stripe reduction uses 16 lanes per group)", t.gn_groups);
     LD_REQUIRE(t.data && t.gn_stats && t.gn_gamma && t.gn_beta && t.gn_groups > 0 && t.C == p->Cout &&
                t.C % t.gn_groups == 0 && (t.pix_stride == 0 || t.pix_stride == t.C) && !t.film,
                "ld_conv1x1: GN_TAIL operand incomplete");

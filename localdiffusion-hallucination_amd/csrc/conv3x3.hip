@@ -175,6 +175,7 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
     LD_REQUIRE(S.C > 0 && S.C % 32 == 0, "ld_conv3x3: src[%d].C=%d must be a multiple of 32", s, S.C);
     if (S.upsample) LD_REQUIRE(p->H % 2 == 0 && p->W % 2 == 0, "ld_conv3x3: upsample needs even H,W");
     if (S.gn_stats) {
+      LD_REQUIRE(S.gn_groups <= 16, "ld_conv3x3: src[%d] gn_groups %d > 16 (the stripe reduction uses 16 lanes per group)", s, S.gn_groups);
       LD_REQUIRE(S.gn_gamma && S.gn_beta && S.gn_groups > 0 && S.C % S.gn_groups == 0,
                  "ld_conv3x3: src[%d] GroupNorm prologue incomplete", s);
     }

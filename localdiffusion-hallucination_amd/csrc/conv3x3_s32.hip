@@ -113,13 +113,22 @@ void conv3x3_s32_kernel(const void* data0, const void* wts, int hw, int ld0, int
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.beta + c), b1 = *reinterpret_cast<const f32x4*>(a.beta + c + 4);
     const f32x4 fs0 = *reinterpret_cast<const f32x4*>(fp + c), fs1 = *reinterpret_cast<const f32x4*>(fp + c + 4);
     const f32x4 fh0 = *reinterpret_cast<const f32x4*>(fp + (a.film ? 32 : 0) + c), fh1 = *reinterpret_cast<const f32x4*>(fp + (a.film ? 32 : 0) + c + 4);
-    // statistics: [B, 16 stripes, 8 groups, 2] fp64; lane (px = stripe, kq) takes groups 2kq, 2kq + 1 of its stripe
-    const double* sp = a.stats + (((size_t)b * LD_STAT_STRIPES + px) * 8 + 2 * kq) * 2;
+    // statistics: [B, stripes, 8 groups, 2] fp64; lane (px, kq) takes groups 2kq, 2kq + 1 of stripes px, px + 16, ...
+    constexpr int SPL = LD_STAT_STRIPES / 16;
     typedef __attribute__((ext_vector_type(2))) double f64x2;
-    const f64x2 q0 = *reinterpret_cast<const f64x2*>(sp), q1 = *reinterpret_cast<const f64x2*>(sp + 2);
+    f64x2 q0[SPL], q1[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+      const double* sp = a.stats + (((size_t)b * LD_STAT_STRIPES + k * 16 + px) * 8 + 2 * kq) * 2;
+      q0[k] = *reinterpret_cast<const f64x2*>(sp);
+      q1[k] = *reinterpret_cast<const f64x2*>(sp + 2);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    double s1[2] = {row_group_sum_d(q0[0], 16), row_group_sum_d(q1[0], 16)};
-    double s2[2] = {row_group_sum_d(q0[1], 16), row_group_sum_d(q1[1], 16)};
+    f64x2 t0 = q0[0], t1 = q1[0];
+#pragma unroll
+    for (int k = 1; k < SPL; ++k) { t0 += q0[k]; t1 += q1[k]; }
+    double s1[2] = {row_group_sum_d(t0[0], 16), row_group_sum_d(t1[0], 16)};
+    double s2[2] = {row_group_sum_d(t0[1], 16), row_group_sum_d(t1[1], 16)};
     float mean[2], rstd[2];
     const double inv_n = (double)__builtin_amdgcn_rcpf((float)((long)H * W) * 4.0f);      // as build_gn_coef (16-bit storage)
 #pragma unroll

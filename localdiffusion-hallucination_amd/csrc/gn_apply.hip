@@ -48,6 +48,7 @@ int run(const GnDev& g, hipStream_t st) {
 extern "C" int ld_gn_apply(const ld_gn_apply_args* p, void* stream) {
   LD_REQUIRE(p && p->a.data && p->out, "ld_gn_apply: null pointer");
   LD_REQUIRE(p->a.gn_stats && p->a.gn_gamma && p->a.gn_beta && p->a.gn_groups > 0, "ld_gn_apply: operand a needs GroupNorm data");
+  LD_REQUIRE(p->a.gn_groups <= 16 && (!p->b.gn_stats || p->b.gn_groups <= 16), "ld_gn_apply: more than 16 groups (the stripe reduction uses 16 lanes per group)");
   LD_REQUIRE(p->a.C % 32 == 0 && p->a.C % p->a.gn_groups == 0, "ld_gn_apply: C=%d groups=%d", p->a.C, p->a.gn_groups);
   LD_REQUIRE(p->a.pix_stride == 0 || p->a.pix_stride == p->a.C, "ld_gn_apply: operands must be dense");
   LD_REQUIRE(!p->pool || (p->H % 2 == 0 && p->W % 2 == 0), "ld_gn_apply: pool needs even H,W");
