@@ -297,7 +297,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 #define LD_STORE_WT 1
 #endif
 __device__ __forceinline__ void store16_out(void* p, const uint4& v) {
-#if LD_STORE_WT
+#if LD_STORE_WT == 3        // experiments (finding 98): other cache-policy bits on the same store
+  const u32x4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#elif LD_STORE_WT == 4
+  const u32x4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#elif LD_STORE_WT == 5
+  const u32x4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+#elif LD_STORE_WT
   const u32x4 d = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
 #else
