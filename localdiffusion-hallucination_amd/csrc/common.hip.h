@@ -292,21 +292,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // statistics), 20.9 -> 16.4 (x 8).  Every 16-byte output store of the activations goes through here (LD_STORE_WT=0: plain
 // stores, `build.sh --plain-stores`, the A/B build).  The asm store is invisible to hipcc's s_waitcnt bookkeeping (nothing later
 // in a kernel depends on its output) and ends in `s_nop 1`: the next instruction must not overwrite its data registers before
-// the store has read them (cdna_hip_programming.md 5.7 item 1).
+// the store has read them (cdna_hip_programming.md 5.7 item 1).  Other policy bits on the same store, in the sampler (three
+// alternating runs, sc1 = 1.244 ms): `sc0 sc1` 1.242 (the same), `sc1 nt` 1.298 (+4.4 %), `nt` alone 1.311 (+5.3 %: worse than
+// plain stores, although one kernel alone on the chip ran as fast with `nt` as with `sc1`).
 #ifndef LD_STORE_WT
 #define LD_STORE_WT 1
 #endif
 __device__ __forceinline__ void store16_out(void* p, const uint4& v) {
-#if LD_STORE_WT == 3        // experiments (finding 98): other cache-policy bits on the same store
-  const u32x4 d = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-#elif LD_STORE_WT == 4
-  const u32x4 d = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-#elif LD_STORE_WT == 5
-  const u32x4 d = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-#elif LD_STORE_WT
+#if LD_STORE_WT
   const u32x4 d = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
 #else
