@@ -328,6 +328,19 @@ template <typename T> __device__ __forceinline__ void store_elem_out(T* p, T v) 
 #endif
 }
 
+// ---------------------------------------------------------------- activation loads (experiment switch, finding 101)
+// LD_LOAD_NT = 1: the read-once activation tiles of the convolutions are requested with the non-temporal policy.
+#ifndef LD_LOAD_NT
+#define LD_LOAD_NT 0
+#endif
+__device__ __forceinline__ u32x4 load16_act(const void* p) {
+#if LD_LOAD_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#else
+  return *reinterpret_cast<const u32x4*>(p);
+#endif
+}
+
 // ---------------------------------------------------------------- kernel-argument layout
 // Byte offset, in the kernel-argument segment, of the argument that follows leading arguments of types Lead... and has
 // alignment `align` (each argument sits at its natural alignment, in order): where a kernel finds its trailing by-value

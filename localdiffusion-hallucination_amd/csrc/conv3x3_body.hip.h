@@ -156,7 +156,10 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         hx[it] = make_uint4(0u, 0u, 0u, 0u);
-        if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const uint4*>(sp + (FIRST ? hoffb0[it] : (si ? hoffb1[it] : hoffb0[it])));
+        if ((hvalid >> it) & 1u) {
+          const u32x4 v = load16_act(sp + (FIRST ? hoffb0[it] : (si ? hoffb1[it] : hoffb0[it])));
+          hx[it] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
       }
     }
   };

@@ -87,7 +87,7 @@ void conv3x3_s32_kernel(const void* data0, const void* wts, int hw, int ld0, int
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       hx[it] = u32x4{0u, 0u, 0u, 0u};
-      if ((hvalid >> it) & 1u) hx[it] = *reinterpret_cast<const u32x4*>(sp + (size_t)hoff[it] * ldb);
+      if ((hvalid >> it) & 1u) hx[it] = load16_act(sp + (size_t)hoff[it] * ldb);
     }
   };
   issue_w(0);
