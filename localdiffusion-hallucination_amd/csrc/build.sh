@@ -17,6 +17,7 @@ for arg in "$@"; do
     --clean) CLEAN=1 ;;
     --debug-variants) FLAGS="$FLAGS -DLD_DEBUG_VARIANTS" ;;
     --plain-stores) FLAGS="$FLAGS -DLD_STORE_WT=0" ;;
+    --tile-xcd) FLAGS="$FLAGS -DLD_TILE_XCD=1" ;;            # experiment: rectangular tile regions per XCD in the 3x3 convolutions
     --load-nt) FLAGS="$FLAGS -DLD_LOAD_NT=1" ;;              # experiment: non-temporal activation loads in the 3x3 convolutions
     --wt-level=*) FLAGS="$FLAGS -DLD_STORE_WT=${arg#--wt-level=}" ;;   # experiments: 0 plain, 1 the 16-byte activation stores, 2 + the narrow ones      # A/B build: plain instead of write-through output stores (finding 98)
     *) echo "build.sh: unknown option $arg" >&2; exit 2 ;;

@@ -341,6 +341,25 @@ __device__ __forceinline__ u32x4 load16_act(const void* p) {
 #endif
 }
 
+// ---------------------------------------------------------------- tile -> XCD placement (experiment switch, finding 102)
+// Workgroups are dealt round-robin over the 8 XCDs (id % 8: observed, speed only).  With tiles numbered row by row, the
+// horizontal neighbours of a tile run on other XCDs and the halo columns they share are fetched through the fabric twice.
+// LD_TILE_XCD = 1: XCD x owns one of 2 x 4 rectangular regions of the tile grid, so that only region borders do.
+#ifndef LD_TILE_XCD
+#define LD_TILE_XCD 0
+#endif
+__device__ __forceinline__ void tile_of(int id, int tiles_x, int tiles_y, int& ty, int& tx) {
+  ty = id / tiles_x;
+  tx = id - ty * tiles_x;
+#if LD_TILE_XCD
+  if ((tiles_x & 1) == 0 && (tiles_y & 3) == 0) {
+    const int rw = tiles_x >> 1, rh = tiles_y >> 2, x = id & 7, s = id >> 3;
+    ty = (x >> 1) * rh + s / rw;
+    tx = (x & 1) * rw + s % rw;
+  }
+#endif
+}
+
 // ---------------------------------------------------------------- kernel-argument layout
 // Byte offset, in the kernel-argument segment, of the argument that follows leading arguments of types Lead... and has
 // alignment `align` (each argument sits at its natural alignment, in order): where a kernel finds its trailing by-value

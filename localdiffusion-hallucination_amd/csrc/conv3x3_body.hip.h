@@ -77,7 +77,9 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
   if ((DBG & 128) && threadIdx.x == 0 && bx == 0 && by == 0 && bz == 0)
     g_conv_span[(a.dbg >> 8) & 1023][0] = __builtin_amdgcn_s_memrealtime();
   const int b = bz, m0 = by * MT;
-  const int ty0 = (bx / a.tiles_x) * TR, tx0 = (bx % a.tiles_x) * TC;
+  int ty_, tx_;
+  tile_of(bx, a.tiles_x, gdx / a.tiles_x, ty_, tx_);
+  const int ty0 = ty_ * TR, tx0 = tx_ * TC;
   const int H = a.H, W = a.W;
   const int nch0 = a.s[0].C / CK;
   const int ws = a.wsplit;

@@ -57,7 +57,9 @@ void conv3x3_s32_kernel(const void* data0, const void* wts, int hw, int ld0, int
   const int H = hw & 0xffff, W = hw >> 16;
   const int tiles_x = W >> 4;
   const int bx = blockIdx.x, b = blockIdx.z;
-  const int ty0 = (bx / tiles_x) * TR, tx0 = (bx % tiles_x) * TC;
+  int ty_, tx_;
+  tile_of(bx, tiles_x, H >> 4, ty_, tx_);
+  const int ty0 = ty_ * TR, tx0 = tx_ * TC;
 
   // ---- the tile's requests: weights (no per-lane geometry: they leave first), then the halo fragments
   unsigned hvalid = 0, hoff[ITER];
