@@ -66,6 +66,7 @@ struct LdTuning {
   long long conv_raw, conv_mt4_min_wgs, conv_big_min, conv_sk, conv_sk_max_wgs;
   long long conv_c32, conv_c32_min_tiles;
   long long conv_s32, conv_s32_min_tiles;
+  long long conv_big4_min;
   long long gn_frags_per_block, fold_split_min, attn_split_max_wgs, attn_split_min_n, lead_args, attn_xcd_map;
 };
 const LdTuning& ld_tuning();

@@ -105,6 +105,9 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
   // drops to one wave per SIMD and measured slower (64->64@128^2: 23.3 vs 19.7 us)
   const long big_min = tn.conv_big_min;
   bool big = blocks16 >= big_min && a.H >= 16 && !mt4;
+  // 64 channels x 16 rows (<4,4>, two workgroups per CU): 0.375 KB of LDS fragment reads per MFMA instead of <4,2>'s 0.667 --
+  // the throughput regime (dozens of patches per launch), where the LDS pipe and not a dependent chain is the bound
+  if (mt4 && a.H >= 16 && blocks16 >= tn.conv_big4_min) big = true;
   if (force_mt == 2) mt4 = false;
   if (force_mt == 4 && (a.Cout % 64) == 0) mt4 = true;
   if (force_nw == 2) big = false;

@@ -263,6 +263,42 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
   // 38 % of wave cycles were s_waitcnt stalls with the read-then-use order).
   auto compute = [&]() {
     if (DBG & 4) return;
+    if constexpr (MT * NW >= 16) {
+      // 64 channels x 16 rows: m-tile outer inside a tap column, so only the 3 weight fragments of ONE m-tile (and the
+      // next one's, in flight) are live instead of 3*MT per column -- 24 registers instead of 96, which is what lets two
+      // of these workgroups share a CU.  Per (m, row) the accumulation order (dx, then dy) is the one of the loop below.
+      uint4 A[2][3], Bq[2][NW + 2];
+      auto load_b = [&](int dx, int set) {
+#pragma unroll
+        for (int rr = 0; rr < NW + 2; ++rr)
+          Bq[set][rr] = *reinterpret_cast<const uint4*>(s_x + kq * PLANE + (((wv * NW + rr) * HC + dx + px) * 16));
+      };
+      auto load_a = [&](int dx, int m, int set) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+          A[set][dy] = *reinterpret_cast<const uint4*>(s_w + ((dy * 3 + dx) * MT + m) * 1024 + lane * 16);
+      };
+      load_b(0, 0);
+      load_a(0, 0, 0);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        if (dx + 1 < 3) load_b(dx + 1, (dx + 1) & 1);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int idx = dx * MT + m;
+          if (idx + 1 < 3 * MT) load_a((idx + 1) / MT, (idx + 1) % MT, (idx + 1) & 1);
+#pragma unroll
+          for (int rr = 0; rr < NW + 2; ++rr) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+              const int j = rr - dy;
+              if (j >= 0 && j < NW) mma16<T>(acc[m][j], A[idx & 1][dy], Bq[dx & 1][rr]);
+            }
+          }
+        }
+      }
+      return;
+    }
     uint4 A[2][3][MT], Bq[2][NW + 2];
     auto load_frags = [&](int dx, int set) {
 #pragma unroll

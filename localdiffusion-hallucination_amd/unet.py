@@ -450,7 +450,9 @@ class _Plan:
         cin = sum(s.C for s in srcs)
         npx = self.B * h * w
         mt4 = cout % 64 == 0 and ((w + 15) // 16) * ((h + 7) // 8) * (cout // 64) * self.B >= 256
-        big = ((w + 15) // 16) * ((h + 15) // 16) * (cout // (64 if mt4 else 32)) * self.B >= 512 and h >= 16 and not mt4
+        blocks16 = ((w + 15) // 16) * ((h + 15) // 16) * (cout // (64 if mt4 else 32)) * self.B
+        big = blocks16 >= 512 and h >= 16 and not mt4
+        big = big or (mt4 and h >= 16 and blocks16 >= self._kt("conv_big4_min"))    # mirrors conv3x3.hip:dispatch
         dname = {cabi.LD_F32: "f32", cabi.LD_BF16: "bf16", cabi.LD_F16: "f16"}[self.dt]
         fam = f"conv3x3<{dname},{4 if mt4 else 2},{4 if big else 2}>"
         ck = 16 if self.dt == cabi.LD_F32 else 32

@@ -139,6 +139,51 @@ def test_conv3x3_s32_lean_kernel(dtype, case):
     assert hh.rel_err(stats["lean"], stats["generic"]) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["plain", "pro", "ragged", "two_src"])
+def test_conv3x3_big64_tile_equals_the_small_tile(dtype, case):
+    """The 64-channel x 16-row tile of the throughput regime (`<4,4>`, routing entry conv_big4_min): the same accumulation
+    order per output element as the 64 x 8-row tile, so the outputs are bit-equal; statistics meet in another order."""
+    from localdiffusion_hallucination_amd.tuning import kernel_table
+    B, cin, cout = 2, 64, 128
+    H, W = (40, 24) if case == "ragged" else (32, 48)
+    x = _q(hh.rand((B, cin, H, W), 90, -2.0, 3.0), dtype)
+    w, b = _q(hh.rand((cout, cin, 3, 3), 91, -0.1, 0.1), dtype), hh.rand((cout,), 92)
+    y, xd = x, hh.nhwc(x, dtype)
+    if case == "pro":
+        gamma, beta = hh.rand((cin,), 93, 0.5, 1.5), hh.rand((cin,), 94, -0.3, 0.3)
+        film = hh.rand((1, 2 * cin), 95, -0.5, 0.5)
+        y = F.group_norm(x, 8, gamma, beta, eps=1e-5)
+        y = F.silu(y * (film[:, :cin, None, None] + 1) + film[:, cin:, None, None])
+        sx = hh.stats_buffer(B, 8)
+        sx[:, 0] = hh.gn_stats_ref(x, 8).to(hh.DEV)
+        srcs = [hh.make_src(xd, cin, gn=(sx, gamma.to(hh.DEV), beta.to(hh.DEV), 8), act=cabi.ACT_SILU, film=film.to(hh.DEV))]
+    elif case == "two_src":
+        srcs = [hh.make_src(xd, 32, stride=64), hh.make_src(hh.nhwc(x[:, 32:].contiguous(), dtype), 32)]
+    else:
+        srcs = [hh.make_src(xd, cin)]
+    ref = F.conv2d(y, w, b, padding=1)
+    wp, bd = hh.pack(w, dtype, 3), b.to(hh.DEV)
+    lib = cabi.lib()
+    keep = kernel_table(lib)
+    outs, stats = {}, {}
+    try:
+        cabi.check(lib.ld_tuning_set(b"conv_mt4_min_wgs", 1), "tuning_set")
+        for name, big_min in (("rows16", 1), ("rows8", 1 << 40)):
+            cabi.check(lib.ld_tuning_set(b"conv_big4_min", big_min), "tuning_set")
+            st = hh.stats_buffer(B, 8)
+            out = hh.conv3x3(srcs, wp, bd, B, H, W, cout, dtype, stats=st, groups=8)
+            torch.cuda.synchronize()
+            outs[name], stats[name] = hh.nchw(out), st.sum(1).cpu()
+    finally:
+        for kname, val in keep.items():
+            cabi.check(lib.ld_tuning_set(kname.encode(), val), "tuning_set")
+    assert hh.rel_err(outs["rows16"], ref) < hh.RTOL[dtype] * (2 if case == "pro" else 1)
+    assert hh.rel_err(stats["rows16"], hh.gn_stats_ref(ref, 8)) < 1e-2
+    assert torch.equal(outs["rows16"], outs["rows8"])
+    assert hh.rel_err(stats["rows16"], stats["rows8"]) < 1e-5
+
+
 # ------------------------------------------------------------------------------ conv1x1
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 32, 16, 16), (1, 384, 256, 8, 8), (1, 96, 64, 14, 14),
