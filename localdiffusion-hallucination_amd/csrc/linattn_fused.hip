@@ -206,10 +206,15 @@ __global__ __launch_bounds__(256) void kvctx_kernel(KVCTX_PARAMS) {
 // ------------------------------------------------------------------------------------------------
 // kvctx, wave-per-head schedule (heads == 4): one workgroup = (batch, pixel chunk); the x tile is staged
 // and RMS-normalised ONCE for all heads, and wave h computes k_h, v_h, P_h and the whole 32x32 context of
-// head h privately: its P/V rows go to a wave-private LDS strip and come back through transposed reads, so
-// the inner loop has no workgroup barrier at all (one per x tile), and the per-channel max of pass 0 is an
-// in-wave DPP reduction.  Emits the same partials as kvctx_kernel.
-constexpr int SROW = 32;                  // pixels per wave-private P/V strip (= one MFMA K-step)
+// head h privately.  The projection is issued TRANSPOSED -- pixels as the M side, W as the N side (the same two
+// fragments, operands swapped) -- so an accumulator lane (li, kq) holds output channel li of pixels 4 kq + r: for the
+// context product ctx[d][e] = sum_n P[n][d] V[n][e], whose contraction runs over PIXELS, the k accumulators of two
+// 16-pixel groups ARE lane (d, kq)'s eight K-slots of the A operand and the v accumulators lane (e, kq)'s of the B
+// operand (any pixel order serves a sum, as long as both operands use the same one).  P and V never touch LDS: no
+// wave-private strip, no transposed reads, no LDS round trip between the softmax and the context MFMAs (round 5; the
+// strip version spent two exposed round trips per 32 pixels).  Per-pixel factors (1 / rms) come as one broadcast
+// 16-byte LDS read per group, per-channel ones (shift, Z, max) are one value per lane.  Emits the same partials as
+// kvctx_kernel.
 
 // SINGLE (caller-supplied shift): the max sweep, its registers and its code are compiled out.
 // WS = 1: two-term weights (ld_pack_conv_weight_terms): 2 * NCH weight chunks, chunk v multiplies x chunk v >> 1.
@@ -221,7 +226,6 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KVCTX_PARAMS) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_x = smem;                                     // [NCH][4][KTN][16 B]
   float* s_rinv = reinterpret_cast<float*>(s_x + NCH * 4 * PLANE);           // [KTN]
-  char* s_pv = reinterpret_cast<char*>(s_rinv + KTN);   // [4 waves][2 (P,V)][SROW][96 B]
   const int ck = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, kq = lane >> 4;
   const int h = wv;
@@ -236,20 +240,15 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KVCTX_PARAMS) {
   // (Z_d = sum_n P_nd stays an fp32 sum of the UNROUNDED weights: taking it from the matrix pipe -- a B tile of ones in
   //  the context product -- was measured in round 4: no step time, and the fp16 context moved from 4e-3 to 6e-3 of its
   //  range against the oracle)
-  float cmax[2][4], mloc[2][4], zs[2][4];
+  float cmax[2], mloc[2], zs[2];                         // k-channel 16 m + li of this lane: running max, shift, Z
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { cmax[m][r] = -INFINITY; mloc[m][r] = 0.f; zs[m][r] = 0.f; }
+  for (int m = 0; m < 2; ++m) { cmax[m] = -INFINITY; mloc[m] = 0.f; zs[m] = 0.f; }
   f32x4 cacc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) cacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int tq = (lane >> 2) & 3, tp = lane & 3;
   const T* xb = reinterpret_cast<const T*>(a.x) + (size_t)b * n * C;
-  char* my_p = s_pv + (wv * 2 + 0) * SROW * PROW;
-  char* my_v = s_pv + (wv * 2 + 1) * SROW * PROW;
 
   uint4 xr[NCH][4];
   auto issue = [&](int p0) {
@@ -269,16 +268,12 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KVCTX_PARAMS) {
   constexpr int first_pass = SINGLE ? 1 : 0;
   if (SINGLE) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mloc[m][r] = a.kshift[h * 32 + 16 * m + 4 * kq + r];
+    for (int m = 0; m < 2; ++m) mloc[m] = a.kshift[h * 32 + 16 * m + li];
   }
   constexpr float LOG2E = 1.4426950408889634f;
-  float m2[2][4];                                        // shift * log2(e): P = exp2(k*log2e - m2), one FMA + v_exp
+  float m2[2];                                           // shift * log2(e): P = exp2(k*log2e - m2), one FMA + v_exp
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) m2[m][r] = mloc[m][r] * LOG2E - DT<T>::pshift;   // P stored as P * 2^pshift (fp16 range)
+  for (int m = 0; m < 2; ++m) m2[m] = mloc[m] * LOG2E - DT<T>::pshift;   // P stored as P * 2^pshift (fp16 range)
   for (int pass = first_pass; pass < 2; ++pass) {
     for (int p0 = lo; p0 < hi; p0 += KTN) {
       __syncthreads();                                   // every wave is done with the previous x tile
@@ -314,87 +309,78 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KVCTX_PARAMS) {
           f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
 #pragma unroll
           for (int c = 0; c < NCW; ++c) {
-            const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + ((c >> WS) * 4 + kq) * PLANE + qq * 16);
-            mma16<T>(k0, A[0][c], Bf);
-            mma16<T>(k1, A[1][c], Bf);
+            const uint4 Xf = *reinterpret_cast<const uint4*>(s_x + ((c >> WS) * 4 + kq) * PLANE + qq * 16);
+            mma16<T>(k0, Xf, A[0][c]);                   // (pixels x channels: lane = channel li, registers = pixels 4 kq + r)
+            mma16<T>(k1, Xf, A[1][c]);
           }
-          if (p0 + qq < hi) {
-            const float rinv = s_rinv[qq];
+          const float4 rv = *reinterpret_cast<const float4*>(s_rinv + g * 16 + 4 * kq);
+          const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              cmax[0][r] = fmaxf(cmax[0][r], k0[r] * rinv);
-              cmax[1][r] = fmaxf(cmax[1][r], k1[r] * rinv);
+          for (int r = 0; r < 4; ++r) {
+            if (p0 + g * 16 + 4 * kq + r < hi) {
+              cmax[0] = fmaxf(cmax[0], k0[r] * rr[r]);
+              cmax[1] = fmaxf(cmax[1], k1[r] * rr[r]);
             }
           }
         }
       } else {
         for (int g2 = 0; g2 < (ngrp + 1) / 2; ++g2) {     // 32 pixels = one context K-step
           // groups that lie entirely inside the chunk (all of them at the model's sizes) skip the per-element
-          // validity selects (24 v_cndmask of ~200 VALU instructions per group)
+          // validity selects
+          uint4 Pf[2], Vf[2];
           auto softmax_part = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
+            unsigned pk[2][4], vk[2][4];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-              const int qq = (g2 * 2 + half) * 16 + li;
-              const bool valid = FULL || (p0 + qq) < hi;
+              const int g16 = (g2 * 2 + half) * 16;
               f32x4 acc[4];
 #pragma unroll
               for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
               for (int c = 0; c < NCW; ++c) {
-                const uint4 Bf = *reinterpret_cast<const uint4*>(s_x + ((c >> WS) * 4 + kq) * PLANE + qq * 16);
+                const uint4 Xf = *reinterpret_cast<const uint4*>(s_x + ((c >> WS) * 4 + kq) * PLANE + (g16 + li) * 16);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) mma16<T>(acc[m], A[m][c], Bf);
+                for (int m = 0; m < 4; ++m) mma16<T>(acc[m], Xf, A[m][c]);
               }
-              const float rinv = s_rinv[qq], rinv2 = rinv * LOG2E;
-              const int row = half * 16 + li;
+              const float4 rv = *reinterpret_cast<const float4*>(s_rinv + g16 + 4 * kq);
+              const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
               for (int m = 0; m < 2; ++m) {
                 float pv[4], vv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  pv[r] = valid ? __builtin_amdgcn_exp2f(fmaf(acc[m][r], rinv2, -m2[m][r])) : 0.f;
-                  vv[r] = valid ? acc[2 + m][r] * rinv : 0.f;
-                  zs[m][r] += pv[r];
+                  const bool valid = FULL || (p0 + g16 + 4 * kq + r) < hi;
+                  pv[r] = valid ? __builtin_amdgcn_exp2f(fmaf(acc[m][r], rr[r] * LOG2E, -m2[m])) : 0.f;
+                  vv[r] = valid ? acc[2 + m][r] * rr[r] : 0.f;
+                  zs[m] += pv[r];
                 }
-                *reinterpret_cast<uint2*>(my_p + row * PROW + (16 * m + 4 * kq) * 2) =
-                    make_uint2(pack2<T>(pv[0], pv[1]), pack2<T>(pv[2], pv[3]));
-                *reinterpret_cast<uint2*>(my_v + row * PROW + (16 * m + 4 * kq) * 2) =
-                    make_uint2(pack2<T>(vv[0], vv[1]), pack2<T>(vv[2], vv[3]));
+                pk[m][half * 2 + 0] = pack2<T>(pv[0], pv[1]); pk[m][half * 2 + 1] = pack2<T>(pv[2], pv[3]);
+                vk[m][half * 2 + 0] = pack2<T>(vv[0], vv[1]); vk[m][half * 2 + 1] = pack2<T>(vv[2], vv[3]);
               }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+              Pf[m] = make_uint4(pk[m][0], pk[m][1], pk[m][2], pk[m][3]);
+              Vf[m] = make_uint4(vk[m][0], vk[m][1], vk[m][2], vk[m][3]);
             }
           };
           if (p0 + (g2 * 2 + 2) * 16 <= hi) softmax_part(std::true_type{});
           else softmax_part(std::false_type{});
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: own writes visible to own reads
-          const int row = kq * 4 + tq;
-          uint4 Af[2], Bf2[2];
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const char* pa = my_p + row * PROW + t * 32 + tp * 8;
-            const char* pb = my_v + row * PROW + t * 32 + tp * 8;
-            const uint2 a1 = tr8(pa), a2 = tr8(pa + 16 * PROW);
-            const uint2 b1 = tr8(pb), b2 = tr8(pb + 16 * PROW);
-            Af[t] = make_uint4(a1.x, a1.y, a2.x, a2.y);
-            Bf2[t] = make_uint4(b1.x, b1.y, b2.x, b2.y);
-          }
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int et = 0; et < 2; ++et) mma16<T>(cacc[dt][et], Af[dt], Bf2[et]);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the strip is rewritten
+            for (int et = 0; et < 2; ++et) mma16<T>(cacc[dt][et], Pf[dt], Vf[et]);
         }
       }
     }
     if (!SINGLE && pass == 0) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { mloc[m][r] = wave16_max(cmax[m][r]); m2[m][r] = mloc[m][r] * LOG2E - DT<T>::pshift; }
+      for (int m = 0; m < 2; ++m) { mloc[m] = kq4_max(cmax[m]); m2[m] = mloc[m] * LOG2E - DT<T>::pshift; }
     }
   }
   float* dst = a.ctx_part + (((size_t)b * a.heads + h) * a.nchunks + ck) * CTX_STRIDE;
-  // (measured and not kept, finding 98: the context as 16-byte write-through stores, transposed through the wave's LDS strip --
+  // (measured and not kept, finding 98: the context as 16-byte write-through stores, transposed through LDS --
   //  1.3283 -> 1.3374 ms, +0.7 %: the extra LDS round trip at the tail costs more than the 8.9 MB of dirty lines it avoids)
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -403,15 +389,13 @@ __global__ __launch_bounds__(256) void kvctx_wph_kernel(KVCTX_PARAMS) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) store_f32_out(&dst[(dt * 16 + kq * 4 + r) * 32 + et * 16 + li], cacc[dt][et][r]);
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float z = wave16_sum(zs[m][r]);
-      if (li == 0) {
-        store_f32_out(&dst[1024 + 16 * m + 4 * kq + r], z);
-        store_f32_out(&dst[1056 + 16 * m + 4 * kq + r], mloc[m][r]);
-      }
+  for (int m = 0; m < 2; ++m) {
+    const float z = kq4_sum(zs[m]);
+    if (kq == 0) {
+      store_f32_out(&dst[1024 + 16 * m + li], z);
+      store_f32_out(&dst[1056 + 16 * m + li], mloc[m]);
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -617,7 +601,7 @@ int kvctx_launch(const KvCtxArgs& a, int B, hipStream_t st) {
   constexpr int no_wph = 0;
 #endif
   if (heads == 4 && (!no_wph || kshift)) {               // wave-per-head schedule
-    const size_t lds2 = (size_t)nch * 4 * KTN * 16 + KTN * sizeof(float) + 4 * 2 * SROW * PROW;
+    const size_t lds2 = (size_t)nch * 4 * KTN * 16 + KTN * sizeof(float);
     dim3 grid2(nchunks, B);
     if (a.wsplit) {                                        // two-term weights: the full- and half-resolution blocks
       LD_REQUIRE(nch <= 2, "ld_linattn_kvctx: two-term weights are built for C = 32 / 64 (got %d)", a.C);
