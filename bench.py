@@ -686,6 +686,7 @@ def main():
         gc.collect()
         gc.disable()
         sync_all()
+        _tl = [] if os.environ.get("LD_BENCH_TIMELINE") else None
         t0 = time.perf_counter()
         t_start = T_STEPS - 1 - warmup
         done, new_sample, parent_encoded = 0, True, False
@@ -700,7 +701,11 @@ def main():
             elif not gd._will_sub_batch(jp, chunk) and not parent_encoded:
                 jp.run_cond(st)
                 parent_encoded = True
+            if _tl is not None:
+                _tl.append(("encode enqueued", time.perf_counter() - t0))
             draw = gd.run_joint_steps(jp, t_start, chunk, lo, hi, z, draw)
+            if _tl is not None:
+                _tl.append((f"{chunk} steps enqueued", time.perf_counter() - t0))
             done += chunk
             t_start -= chunk
             new_sample = t_start < 0
@@ -712,9 +717,14 @@ def main():
             dist.all_gather_into_tensor(gathered, xl.contiguous())
             xl = gathered[rank * P:(rank + 1) * P]
         cabi.check(lib.ld_recompose(xl.contiguous().data_ptr(), mk.data_ptr(), img.data_ptr(), 1, P, 3, H * H, st), "recompose")
+        if _tl is not None:
+            _tl.append(("recompose enqueued", time.perf_counter() - t0))
         sync_all()
         elapsed = time.perf_counter() - t0
         gc.enable()
+        if _tl is not None:                                         # LD_BENCH_TIMELINE=1: host clock inside the timed region (stderr)
+            _tl.append(("synchronised", elapsed))
+            print("timed region, host clock [ms]: " + ", ".join(f"{k} {1e3 * v:.3f}" for k, v in _tl), file=sys.stderr)
         if world > 1:
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
