@@ -397,6 +397,13 @@ class _Plan:
             self._track.append(t)
         return t
 
+    def _tracked(self, t):
+        """A per-evaluation scratch tensor of the main trunk that is not an activation (context partials, folded matrices):
+        placed in the pool like the buffers of ``buf``."""
+        if self._track is not None:
+            self._track.append(t)
+        return t
+
     def _pool_buffers(self):
         """Sampler plans: the activations of the main trunk share ONE pool, placed by liveness (first / last launch that
         touches a buffer), instead of one allocation per layer -- a 4-patch plan cycles through ~0.65 GB of distinct
@@ -725,8 +732,8 @@ class _Plan:
         if heads == 4 and self.tn.linattn_chunk_px is None:
             while B * nchunks < 512 and nchunks < 512 and n // (2 * nchunks) >= 256:
                 nchunks *= 2
-        ctx = torch.empty(int(lib.ld_linattn_ctx_part_floats(B, heads, 32, nchunks)), dtype=torch.float32, device=self.dev)
-        wfold = torch.empty(B, c * hid, dtype=self.tdt, device=self.dev)
+        ctx = self._tracked(torch.empty(int(lib.ld_linattn_ctx_part_floats(B, heads, 32, nchunks)), dtype=torch.float32, device=self.dev))
+        wfold = self._tracked(torch.empty(B, c * hid, dtype=self.tdt, device=self.dev))
         wout = f[p + ".to_out.0.weight"].reshape(c, hid).contiguous()
         wq, wkv = self.P["wq"][p], self.P["wkv"][p]
         kshift = self.P["kshift"].get(p) if heads == 4 else None
