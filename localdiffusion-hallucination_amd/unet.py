@@ -510,7 +510,8 @@ class _Plan:
             if last[k] < n_ops:
                 pooled.add(id(t))
         self.named = {k: v for k, v in self.named.items() if id(v) not in pooled}
-        self.pool_stats = dict(buffers=len(bufs), bytes_unshared=sum(size), bytes_pool=top)
+        peak = max(sum(size[k] for k in range(len(bufs)) if first[k] <= i <= last[k]) for i in range(n_ops))
+        self.pool_stats = dict(buffers=len(bufs), bytes_unshared=sum(size), bytes_pool=top, bytes_peak_live=peak)
 
     def slot(self):
         s = self._slot_cursor
