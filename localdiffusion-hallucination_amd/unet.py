@@ -411,7 +411,7 @@ class _Plan:
         address is seen again.  The launch list is analysed as it stands: ctypes argument blocks are scanned for pointers
         into the tracked buffers (and patched), raw launches are closures over the tensors themselves (``data_ptr()`` at call
         time), so re-pointing the tensor objects at the pool moves both.  Buffers reachable from plan attributes (``final``,
-        the conditioning features) keep an unbounded lifetime; ``named`` taps of pooled buffers are dropped."""
+        the conditioning features) stay live to the end of the evaluation; ``named`` taps of pooled buffers are dropped."""
         import bisect
         bufs = self._track or []
         if not bufs:
@@ -476,13 +476,13 @@ class _Plan:
                     if k is not None:
                         touch(k, i)
         n_ops = len(self.ops_main)
-        for name, v in self.__dict__.items():              # reachable from outside the launch list: never shared
-            if name in ("_track", "keep", "named"):
-                continue
+        for name, v in self.__dict__.items():              # reachable from outside the launch list (``final``: the sampler's own
+            if name in ("_track", "keep", "named"):         # last launch reads it AFTER the list): live from its first launch to
+                continue                                    # the end of the evaluation, dead again while the next one starts
             for t in tensors(v):
                 k = owner(t.data_ptr()) if t.is_cuda else None
                 if k is not None:
-                    first[k], last[k] = -1, n_ops
+                    first[k], last[k] = first.get(k, -1), n_ops
         for k in range(len(bufs)):                           # (a buffer no launch touches: keep it apart)
             if k not in first:
                 first[k], last[k] = -1, n_ops
