@@ -278,7 +278,7 @@ class Unet(nn.Module):
         #  not silently keep plans built under the old one -- ADVICE r4)
         tn = self.tuning
         key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels,
-               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse)
+               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse, tn.recompute_stem)
         if key not in self._plans:
             self._plans[key] = _Plan(self, B, H, W, table_T)
         return self._plans[key]
@@ -916,7 +916,19 @@ class _Plan:
                 x = self.conv3(ops, [self.src(x, c)], p + ".3", cin, h, w)
             self.named[p + ".3"] = x
             c = cin
-        x = self.resnet_block(ops, "final_res_block", lambda x=x, c=c: [self.src(x, c), self.src(r, cfg.init_dim)],
+        if self.tn.recompute_stem and self._track is not None and self.dt != cabi.LD_F32 and cfg.init_dim == 32:
+            # the final block concatenates init_conv's output, which would otherwise stay live for the whole evaluation
+            # (one of six 16 MB tensors at the peak of a 4-patch plan): evaluate init_conv again here instead
+            r2 = self.buf(H, W, cfg.init_dim)
+            wstem2 = self.P["stem"]
+            self._raw(ops, lambda st, r2=r2: cabi.check(lib.ld_conv_stem(
+                self.x_in.data_ptr(), wstem2.data_ptr(), bi.data_ptr(), r2.data_ptr(), B, cfg.channels, H, W, self.dt, st),
+                "init_conv (again)"), "conv_image7x7",
+                nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W)
+            r_cat = r2                                   # (``r`` itself stays bound: the first launch's closures write it)
+        else:
+            r_cat = r
+        x = self.resnet_block(ops, "final_res_block", lambda x=x, c=c, r_cat=r_cat: [self.src(x, c), self.src(r_cat, cfg.init_dim)],
                               c + cfg.init_dim, cfg.dim, h, w)
         wf = f["final_conv.weight"].reshape(cfg.out_dim, cfg.dim).contiguous()
         bf = f["final_conv.bias"]
