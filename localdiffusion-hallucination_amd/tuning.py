@@ -34,6 +34,7 @@ class Tuning:
     fusion_fold: bool = True             # conv_fusion's conditioning halves evaluated once per sample (16-bit storage)
     linattn_chunk_px: Optional[Tuple[int, int, int]] = None   # kvctx chunk pixels for n >= 65536 / n >= 16384 / smaller (None: by batch)
     graph_prewarm: bool = True           # a captured graph is launched once where it is captured (the first launch completes its set-up)
+    pool_by_size: bool = True            # pool placement: largest buffers first (False: by first use; 9 % more pool at the bench shape)
     recompute_stem: bool = False         # pooled plans: init_conv evaluated a second time for the final block's concat instead of kept live
     buffer_reuse: bool = True            # sampler plans (table mode): activations share ONE pool by liveness instead of a buffer per layer
     # ---- the library's launch-routing table (ld_tuning_set): name -> value, applied when the library is loaded
@@ -49,6 +50,7 @@ class Tuning:
         "LD_NO_SEPARATE_ACT": ("separate_act", lambda v: False),
         "LD_NO_FUSION_FOLD": ("fusion_fold", lambda v: False),
         "LD_NO_GRAPH_PREWARM": ("graph_prewarm", lambda v: False),
+        "LD_POOL_BY_START": ("pool_by_size", lambda v: False),
         "LD_RECOMPUTE_STEM": ("recompute_stem", lambda v: v not in ("0", "")),
         "LD_BUFFER_REUSE": ("buffer_reuse", lambda v: v not in ("0", "")), "LD_NO_BUFFER_REUSE": ("buffer_reuse", lambda v: False),
         "LD_LINATTN_CHUNK_PX": ("linattn_chunk_px", lambda v: tuple(int(x) for x in (v.split(",") * 3)[:3])),

@@ -278,7 +278,7 @@ class Unet(nn.Module):
         #  not silently keep plans built under the old one -- ADVICE r4)
         tn = self.tuning
         key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels,
-               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse, tn.recompute_stem)
+               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse, tn.recompute_stem, tn.pool_by_size)
         if key not in self._plans:
             self._plans[key] = _Plan(self, B, H, W, table_T)
         return self._plans[key]
@@ -487,17 +487,20 @@ class _Plan:
             if k not in first:
                 first[k], last[k] = -1, n_ops
         size = [(r[1] - r[0] + 255) // 256 * 256 for r in rng]
-        offset, live, top = {}, [], 0                        # live: (offset, size, last)
-        for k in sorted(range(len(bufs)), key=lambda k: (first[k], -size[k])):
-            live = [a for a in live if a[2] >= first[k]]     # closed intervals: an op's inputs and outputs never alias
-            live.sort()
+        # placement: the largest buffers first, each at the lowest offset free of every placed buffer whose (closed) interval
+        # meets its own -- an op's inputs and outputs never alias.  (By start time the pool was 9 % above the peak live set,
+        # by size it is within a few per cent; at 8 patches per GPU the working set sits on the edge of the cache, finding 108.)
+        offset, placed, top = {}, [], 0                      # placed: (offset, size, first, last)
+        by_size = self.tn.pool_by_size
+        for k in sorted(range(len(bufs)), key=lambda k: (-size[k], first[k]) if by_size else (first[k], -size[k])):
+            busy = sorted((o, sz) for o, sz, f0, l0 in placed if f0 <= last[k] and first[k] <= l0)
             pos = 0
-            for off, sz, _ in live:
+            for off, sz in busy:
                 if off - pos >= size[k]:
                     break
                 pos = max(pos, off + sz)
             offset[k] = pos
-            live.append((pos, size[k], last[k]))
+            placed.append((pos, size[k], first[k], last[k]))
             top = max(top, pos + size[k])
         self._pool = torch.empty(top, dtype=torch.uint8, device=self.dev)
         base = self._pool.data_ptr()
