@@ -733,6 +733,9 @@ def main():
         return elapsed, jp, z
 
     elapsed, jp, z = measure(a.steps, a.warmup)
+    for _rep in range(int(os.environ.get("LD_BENCH_REPEAT", "1")) - 1):     # diagnosis only: the line reports the FIRST measurement
+        e_again, _, _ = measure(a.steps, a.warmup)
+        print(f"measurement {_rep + 2}: {1e3 * e_again / a.steps:.4f} ms per step (first: {1e3 * elapsed / a.steps:.4f})", file=sys.stderr)
 
     value = world * P * a.steps / (T_STEPS * elapsed)
     out = {
