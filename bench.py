@@ -674,17 +674,19 @@ def main():
         gd._noise(x_T, 0)
         jp.x_in.copy_(x_T)
         z = torch.empty_like(x_T)
-        # warm-up (untimed): encoder + W steps
-        gd.encode_cond(jp, warmup)
-        draw = gd.run_joint_steps(jp, T_STEPS - 1, warmup, lo, hi, z, 1)
         # inputs of the per-sample exchange are resident before the timed region starts (the masks are an input of the path;
         # uploading them inside it was 2 MB of pageable host-to-device copy per measurement: ~0.4 ms, 1.5 % of a 20-step run)
         img = torch.empty(1, 3, H, H, device=dev)
         mk = masks.reshape(P, H * H).to(dev)
         gathered = torch.empty(world * P, 3, H, H, device=dev) if world > 1 else None
-        # (the host paces a 27 ms timed region of the default run two steps ahead of the GPU: a collector pause in it is a GPU bubble)
+        # (the host paces a 27 ms timed region of the default run two steps ahead of the GPU: a collector pause in it is a GPU bubble.
+        #  Collected HERE, in front of the warm-up: tens of milliseconds of an idle GPU between the warm-up and the timed region
+        #  would start the region on a chip that has dropped its clocks)
         gc.collect()
         gc.disable()
+        # warm-up (untimed): encoder + W steps, then straight into the timed region
+        gd.encode_cond(jp, warmup)
+        draw = gd.run_joint_steps(jp, T_STEPS - 1, warmup, lo, hi, z, 1)
         sync_all()
         _tl = [] if os.environ.get("LD_BENCH_TIMELINE") else None
         t0 = time.perf_counter()
