@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import _cabi as cabi
+from .pool import peak_live, place_intervals
 from .tuning import Tuning
 from .weights import UnetConfig, unet_param_shapes
 
@@ -487,21 +488,11 @@ class _Plan:
             if k not in first:
                 first[k], last[k] = -1, n_ops
         size = [(r[1] - r[0] + 255) // 256 * 256 for r in rng]
-        # placement: the largest buffers first, each at the lowest offset free of every placed buffer whose (closed) interval
-        # meets its own -- an op's inputs and outputs never alias.  (By start time the pool was 9 % above the peak live set,
-        # by size it is within a few per cent; at 8 patches per GPU the working set sits on the edge of the cache, finding 108.)
-        offset, placed, top = {}, [], 0                      # placed: (offset, size, first, last)
-        by_size = self.tn.pool_by_size
-        for k in sorted(range(len(bufs)), key=lambda k: (-size[k], first[k]) if by_size else (first[k], -size[k])):
-            busy = sorted((o, sz) for o, sz, f0, l0 in placed if f0 <= last[k] and first[k] <= l0)
-            pos = 0
-            for off, sz in busy:
-                if off - pos >= size[k]:
-                    break
-                pos = max(pos, off + sz)
-            offset[k] = pos
-            placed.append((pos, size[k], first[k], last[k]))
-            top = max(top, pos + size[k])
+        # placement (pool.py): largest buffers first, each at the lowest offset free of every placed buffer whose closed interval
+        # meets its own -- the pool then equals the peak live set (by first use it was 9 % above it; at 8 patches per GPU the
+        # working set sits on the edge of the cache, finding 108)
+        idx = list(range(len(bufs)))
+        offset, top = place_intervals(size, [first[k] for k in idx], [last[k] for k in idx], self.tn.pool_by_size)
         self._pool = torch.empty(top, dtype=torch.uint8, device=self.dev)
         base = self._pool.data_ptr()
         for obj, name, k, delta in patches:
@@ -513,7 +504,7 @@ class _Plan:
             if last[k] < n_ops:
                 pooled.add(id(t))
         self.named = {k: v for k, v in self.named.items() if id(v) not in pooled}
-        peak = max(sum(size[k] for k in range(len(bufs)) if first[k] <= i <= last[k]) for i in range(n_ops))
+        peak = peak_live(size, [first[k] for k in idx], [last[k] for k in idx])
         self.pool_stats = dict(buffers=len(bufs), bytes_unshared=sum(size), bytes_pool=top, bytes_peak_live=peak)
 
     def slot(self):
