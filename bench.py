@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg5"],
                     help="cfg3 (default, the headline metric) | cfg5: BASELINE configs[4] as stated -- one 1x512x512 image per GPU, "
                          "DDIM 50 of 1000 steps, OOD/IND branches with a circular mask, fusion at times[-4]; reports images/s")
+    ap.add_argument("--images", type=int, default=None,
+                    help="cfg5 only: images in the whole job (default: one per GPU, image-sharded).  Fewer images than ranks: the "
+                         "branch-patch units of every image are spread over the ranks (dist.sample_kmask_sharded)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the short cfg4-share (64 patches per GPU) and cfg5 legs of the default line")
     ap.add_argument("--weight-split-levels", type=int, default=None,
                     help="two-term (hi + lo) convolution weights on the first N resolution levels (accuracy mode, DESIGN section 2); "
                          "the default line is measured with 0 and reports the cost of 2 in `two_term_weights`")
@@ -277,28 +281,33 @@ def cpu_baseline(cfg, sd, H, patches, seconds_budget=12.0):
     # the whole workload: one worker process per patch, each on its own physical cores (spread over the whole box: eight
     # workers packed onto one socket's first 64 CPUs ran 4.6x slower each than one alone)
     cores = len(physical_cpus())
-    threads = max(1, min(32, cores // max(1, patches)))
+    # at most one worker per 8 physical cores (--patches 64 used to start 64 torch processes); the figure is the
+    # BOX's rate -- the sum of the workers' rates, each worker stepping one patch -- whatever the batch size, so it compares
+    # across patch counts; `single_patch` below is the one-patch latency figure every round has reported
+    workers = max(1, min(patches, cores // 8))
+    threads = max(1, min(32, cores // workers))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(H), str(i * threads), str(threads),
                                str(seconds_budget)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-             for i in range(patches)]
+             for i in range(workers)]
     rates, steps = [], []
+    deadline = time.monotonic() + 8 * seconds_budget + 180        # ONE deadline for the whole pool (first import of torch on a fresh box: ~2 min)
     for pr in procs:
         try:
-            out, _ = pr.communicate(timeout=40 * seconds_budget + 300)
+            out, _ = pr.communicate(timeout=max(1.0, deadline - time.monotonic()))
             d = json.loads(out.strip().splitlines()[-1])
             rates.append(1.0 / (T_STEPS * d["s_per_step"]))
             steps.append(d["steps"])
         except Exception:                                       # a worker that died or hung is reported, not hidden
             pr.kill()
-    if len(rates) != patches:
+    if len(rates) != workers:
         return dict(single, kind="port", host_logical_cpus=os.cpu_count(), host_cpu=cpu_model(),
-                    sample=single["sample"] + f"; whole-box leg failed ({len(rates)} of {patches} workers answered)")
+                    sample=single["sample"] + f"; whole-box leg failed ({len(rates)} of {workers} workers answered)")
     ms = 1e3 / (T_STEPS * (sum(rates) / len(rates)))
-    return dict(value=sum(rates), unit="patches/s", cores=threads * patches, kind="port",
+    return dict(value=sum(rates), unit="patches/s", cores=threads * workers, kind="port",
                 host_logical_cpus=os.cpu_count(), host_usable_cpus=usable, host_cpu=cpu_model(), single_patch=single,
-                sample=f"the batch's {patches} patches ({cfg.channels}x{H}x{H}, fp32, oracle/unet_ref.py) stepped concurrently by {patches} "
+                sample=f"{workers} patches ({cfg.channels}x{H}x{H}, fp32, oracle/unet_ref.py) stepped concurrently by {workers} "
                        f"worker processes x {threads} threads, each pinned to its own physical cores ({cores} on the box): {min(steps)}-{max(steps)} consecutive reverse "
-                       f"steps per worker in ~{seconds_budget:.0f} s, mean {ms:.1f} ms/step per patch, extrapolated to T={T_STEPS}")
+                       f"steps per worker in ~{seconds_budget:.0f} s, mean {ms:.1f} ms/step per patch, extrapolated to T={T_STEPS}; value = the sum of the workers' rates")
 
 
 def lowp_pin(dtype, dev):
@@ -361,12 +370,20 @@ def _price(row, peak_tf):
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac}, gbs, tfs
 
 
-def _pmc_traffic(name, solo):
+def _pmc_traffic(name, solo, tag=None):
     """HBM bytes per launch of family ``name`` from the newest committed rocprofv3 --pmc passes of the SAME regime
     (profiles/*_pmc_traffic.json: the default two-sub-batch regime; *_s1_pmc_traffic.json: one batch on one stream).
     Not live: counters need their own profiler passes (tools/profile_round.sh)."""
-    files = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")
-             and f.endswith("_s1_pmc_traffic.json") == solo]
+    # tag: the workload the passes were collected on (None: cfg3, the headline; "cfg5" / "p64": profiles/*_<tag>_pmc_traffic.json)
+    def ok(f):
+        if not f.endswith("_pmc_traffic.json"):
+            return False
+        stem = f[:-len("_pmc_traffic.json")]
+        is_solo = stem.endswith("_s1")
+        stem = stem[:-3] if is_solo else stem
+        ftag = next((t for t in ("cfg5", "p64") if stem.endswith("_" + t)), None)
+        return is_solo == solo and ftag == tag
+    files = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if ok(f)]
     for cand in sorted(files, reverse=True):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", cand))).get(name, {}).get("hbm_bytes_per_launch")
@@ -377,12 +394,12 @@ def _pmc_traffic(name, solo):
     return None, None
 
 
-def _leg_block(table, per_op, plan, regime, peak_tf, H, solo, conv_sel=None):
+def _leg_block(table, per_op, plan, regime, peak_tf, H, solo, conv_sel=None, traffic_tag=None):
     """One regime's roofline block: the dominant family priced per launch + the table it is recomputed from."""
     name = next(iter(table))                                 # the family with the most time per step
     roof, gbs, tfs = _price(table[name], peak_tf)
     step_ms = sum(r["ms_per_step"] for r in table.values())
-    traffic, src = _pmc_traffic(name, solo)
+    traffic, src = _pmc_traffic(name, solo, traffic_tag)
     roof.update({"kernel": name, "regime": regime, "launch_batch": int(plan.x_in.shape[0]), "traffic": traffic,
                  "traffic_source": src, "avg_launch_us": table[name]["avg_us"], "bytes_per_launch": table[name]["bytes_per_launch"],
                  "flops_per_launch": table[name]["flops_per_launch"], "launches_per_step": table[name]["launches_per_step"],
@@ -455,7 +472,7 @@ def cabi_mod():
     return _cabi
 
 
-def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5):
+def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5, traffic_tag=None):
     """Per-launch timing (hipExtLaunchKernelGGL start/stop events on the launch stream = rocprofv3's kernel
     durations) of a few reverse steps.  The block describes the regime the TIMED region runs in:
       timed -- the batch as concurrent sub-batches on two streams (replayed step graphs); sub-batch 0 is stepped
@@ -498,12 +515,12 @@ def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5):
 
     B_ = int(jp.x_in.shape[0])
     t1, ops1, plan1 = legs["solo"]
-    solo = _leg_block(t1, ops1, plan1, f"solo: one batch of {B_} on one stream, every launch alone on the chip", peak_tf, H, True, conv_sel)
+    solo = _leg_block(t1, ops1, plan1, f"solo: one batch of {B_} on one stream, every launch alone on the chip", peak_tf, H, True, conv_sel, traffic_tag)
     if "in_situ" in legs:
         t2, ops2, plan2 = legs["in_situ"]
         b2 = int(plan2.x_in.shape[0])
         roof = _leg_block(t2, ops2, plan2, f"timed: {gd.sub_batches} concurrent sub-batches of {b2} (replayed step graphs); "
-                          f"sub-batch 0's launches timed while the other sub-batch shares the chip", peak_tf, H, False, conv_sel)
+                          f"sub-batch 0's launches timed while the other sub-batch shares the chip", peak_tf, H, False, conv_sel, traffic_tag)
         roof["concurrent_streams"] = gd.sub_batches
         sub = gd._subs.get((id(jp), gd.sub_batches))
         if sub is not None:
@@ -518,15 +535,20 @@ def roofline_leg(gd, jp, tp_value, dtype, H, lo, hi, z, nsteps=5):
     return roof
 
 
-def bench_cfg5(a, rank, world, dev, dist):
+def cfg5_run(dtype, steps, rank, world, dev, dist, images=None, want_roofline=True):
     """BASELINE.json configs[4] as stated: 1-channel 512x512, T=1000 strided to S=50 DDIM steps (eta 0), OOD / IND
     branches with a circular OOD mask (radius 64 at the centre), fusion at times[-4], fp16 unless --dtype says
-    otherwise; one image per GPU (images shard across ranks with no traffic until the final gather).  A "step" is one
-    DDIM step of the image (both branches before the fusion time, one after); `value` = images/s of whole samples."""
+    otherwise.  A "step" is one DDIM step of an image (both branches before the fusion time, one after); `value` =
+    images/s of whole samples.  Returns the JSON object of the line (every rank computes it, rank 0 prints it).
+
+    ``images`` None (default): one image per GPU -- images shard across ranks with no traffic until the final gather
+    (weak scaling).  ``images`` < world: the job's images are FEWER than the ranks, so whole images cannot fill the node;
+    the K = 2 branch-patches of every image are spread instead (dist.sample_kmask_sharded: units over ranks -> ONE
+    all-gather of [x_t, x0_hat] at the fusion step -> images over ranks -> one final gather; SURVEY 8e "If K*B < G")."""
     import localdiffusion_hallucination_amd as ldh
     from localdiffusion_hallucination_amd import rng, weights
+    from localdiffusion_hallucination_amd import dist as ldist
     H, T, S = 512, T_STEPS, 50
-    dtype = a.dtype
     net = ldh.Unet(dim=32, init_dim=32, mode="mri", compute_dtype=dtype)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(net.cfg, 0).items()})
     net = net.to(dev)
@@ -535,23 +557,34 @@ def bench_cfg5(a, rank, world, dev, dist):
     gd = ldh.GaussianDiffusion(config, net, image_size=H, timesteps=T, objective="pred_x0", beta_schedule="sigmoid",
                                sampling_timesteps=S).to(dev)
     gd.noise_source = "device"
-    gd.noise_offset = rank * H * H
+    unit_sharded = images is not None and images < world
+    n_img = images if unit_sharded else 1
+    gd.noise_offset = 0 if unit_sharded else rank * H * H
     yy, xx = np.mgrid[0:H, 0:H]
     mask = torch.from_numpy((((yy - H / 2) ** 2 + (xx - H / 2) ** 2) <= 64 ** 2).astype(np.float32))[None, None].to(dev)
-    cond = torch.from_numpy(rng.uniform((1, 1, H, H), 200 + rank, 1, 0.0, 2.0)).to(dev)
+    if unit_sharded:                # the job's images, identical on every rank; masks in the K-mask form [B, 2, H, W] = [m, 1 - (m >= 1)]
+        cond = torch.cat([torch.from_numpy(rng.uniform((1, 1, H, H), 200 + i, 1, 0.0, 2.0)) for i in range(n_img)], 0).to(dev)
+        mask = torch.cat([mask, 1.0 - (mask >= 1).float()], 1).expand(n_img, 2, H, H).contiguous()
+    else:
+        cond = torch.from_numpy(rng.uniform((1, 1, H, H), 200 + rank, 1, 0.0, 2.0)).to(dev)
+
+    def one_sample():
+        if unit_sharded:
+            return ldist.sample_kmask_sharded(gd, cond, None, mask, (0.0, 2.0))
+        return gd.sample(cond, None, batch_size=1, mask=mask, min_max_val=(0.0, 2.0))
 
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
-    samples = max(1, (a.steps + S - 1) // S)
-    out_img = gd.sample(cond, None, batch_size=1, mask=mask, min_max_val=(0.0, 2.0))          # warm-up sample (plans, packing)
+    samples = max(1, (steps + S - 1) // S)
+    out_img = one_sample()          # warm-up sample (plans, packing)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(samples):
-        out_img = gd.sample(cond, None, batch_size=1, mask=mask, min_max_val=(0.0, 2.0))
-    if world > 1:
+        out_img = one_sample()
+    if world > 1 and not unit_sharded:
         gathered = torch.empty(world, 1, H, H, device=dev)
         dist.all_gather_into_tensor(gathered, out_img.contiguous())
     sync_all()
@@ -561,8 +594,10 @@ def bench_cfg5(a, rank, world, dev, dist):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(out_img).all() and float(out_img.min()) >= 0.0 and float(out_img.max()) <= 2.0
+    if rank == 0 and os.environ.get("LD_BENCH_DUMP"):         # tests: the finished image(s) of the last timed sample
+        np.save(os.environ["LD_BENCH_DUMP"], (gathered if (world > 1 and not unit_sharded) else out_img).cpu().numpy())
     roof = None
-    if rank == 0 and not a.no_roofline:
+    if rank == 0 and want_roofline and not unit_sharded:
         # per-launch table of the branch phase (47 of the 50 pairs): branch 0 timed launch by launch while branch 1's
         # replayed graph shares the chip (the timed regime), and alone on the chip (`solo`)
         from localdiffusion_hallucination_amd.diffusion import _DdimBranches
@@ -576,7 +611,7 @@ def bench_cfg5(a, rank, world, dev, dist):
                 regime = ("timed: the OOD and the IND branch of one 1x512x512 image as two concurrent sub-batches (replayed step graphs); "
                           "branch 0's launches timed while branch 1 shares the chip") if not alone else \
                          "solo: one branch of one image on one stream, every launch alone on the chip"
-                blocks[leg] = _leg_block(table, per_op, db.plans[0], regime, peak_tf, H, alone)
+                blocks[leg] = _leg_block(table, per_op, db.plans[0], regime, peak_tf, H, alone, traffic_tag="cfg5")
                 if os.environ.get("LD_BENCH_OPS"):
                     with open(os.environ["LD_BENCH_OPS"], "a" if leg == "solo" else "w") as f:
                         f.write(f"# {leg}\n")
@@ -584,20 +619,46 @@ def bench_cfg5(a, rank, world, dev, dist):
                             f.write(f"{i:4d} {m.get('family', '?'):22s} {m.get('what', '?'):38s} {m.get('shape', ''):20s} {us:9.1f} us\n")
             roof = blocks["timed"]
             roof["solo"] = blocks["solo"]
+    n_job = n_img if unit_sharded else world
+    return {
+        "metric": "images/sec (cfg5: 512^2, DDIM 50 of 1000, branch + fusion)", "value": n_job * samples / elapsed, "unit": "images/s",
+        "n_gpus": world, "steps": samples * S, "warmup": S, "ms_per_step": 1e3 * elapsed / (samples * S),
+        "higher_is_better": True, "scaling": "strong" if unit_sharded else "weak", "vs_baseline": None, "dtype": dtype,
+        "data": "synthetic (portable-RNG conditioning image and x_T, procedural random-init weights)",
+        "config": {"workload": "cfg5: one 1x512x512 image per GPU, 4-stage dim-32 conditional UNet, T=1000 / DDIM S=50 (eta 0), "
+                               "OOD + IND branches (circular mask r=64), fusion at times[-4], full attention over 4096 tokens",
+                   "images_per_gpu": 1 if not unit_sharded else None, "images_in_job": n_job, "sampling_timesteps": S,
+                   "parallelism": (f"branch-patch units of {n_img} image(s) over {world} ranks: one all-gather of [x_t, x0_hat] at the fusion step, "
+                                   f"images over ranks, one final gather (dist.sample_kmask_sharded)" if unit_sharded
+                                   else f"image-sharded x{world}, one all-gather per sample")
+                                  + (" [LD_BENCH_SHARE_GPU: ranks share one GPU over gloo -- functional test, not a measurement]"
+                                     if os.environ.get("LD_BENCH_SHARE_GPU") == "1" else ""),
+                   "denoiser_evaluations_per_image": 2 * (S - 3) + 3},
+        **({"roofline": roof} if roof is not None else {})}
+
+
+def bench_cfg5(a, rank, world, dev, dist):
+    out = cfg5_run(a.dtype, a.steps, rank, world, dev, dist, images=a.images, want_roofline=not a.no_roofline)
     if rank == 0:
-        print(json.dumps({
-            "metric": "images/sec (cfg5: 512^2, DDIM 50 of 1000, branch + fusion)", "value": world * samples / elapsed, "unit": "images/s",
-            "n_gpus": world, "steps": samples * S, "warmup": S, "ms_per_step": 1e3 * elapsed / (samples * S),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
-            "data": "synthetic (portable-RNG conditioning image and x_T, procedural random-init weights)",
-            "config": {"workload": "cfg5: one 1x512x512 image per GPU, 4-stage dim-32 conditional UNet, T=1000 / DDIM S=50 (eta 0), "
-                                   "OOD + IND branches (circular mask r=64), fusion at times[-4], full attention over 4096 tokens",
-                       "images_per_gpu": 1, "sampling_timesteps": S, "parallelism": f"image-sharded x{world}, one all-gather per sample",
-                       "denoiser_evaluations_per_image": 2 * (S - 3) + 3},
-            **({"roofline": roof} if roof is not None else {})}))
+        print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _compact_leg(line):
+    """A whole bench line -> the short form the default line carries for the other BASELINE configs: throughput, step time
+    and the dominant kernel family with its roofline fraction (no per-family table)."""
+    keep = {k: line[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype") if k in line}
+    r = line.get("roofline")
+    if r:
+        keep["dominant"] = {k: r.get(k) for k in ("kernel", "bound", "frac", "achieved", "unit", "avg_launch_us", "launches_per_step",
+                                                  "share_of_step", "traffic", "traffic_source", "bytes_per_launch", "flops_per_launch")}
+        if "path_frac" in r:
+            keep["path_frac"] = r["path_frac"]
+        if "resblock_conv_path" in r:
+            keep["resblock_conv_path"] = {k: v for k, v in r["resblock_conv_path"].items() if k in ("hbm_frac", "chip_hbm_frac", "ms_per_step")}
+    return keep
 
 
 def main():
@@ -654,11 +715,17 @@ def main():
     gd.sub_cu_mask = os.environ.get("LD_BENCH_CU_MASK") or None      # experiments: "xcd" = each sub-batch stream owns four XCDs
     gd.use_graph = a.graph == 1          # HIP-graph replay of the reverse step (measured: no gain, the step is GPU-bound)
 
-    masks = band_masks(P, H)
     cond_img = torch.from_numpy(rng.uniform((1, 3, H, H), 100 + rank, 1, 0.0, 2.0))
-    conds = patch_conditions(cond_img, masks).to(dev)
     lib, st = cabi.lib(), torch.cuda.current_stream().cuda_stream
     lo, hi = 0.0, 2.0
+    inputs = {}
+
+    def workload(Pn):
+        """band masks + per-patch conditioning of ``Pn`` local patches (built once per patch count)"""
+        if Pn not in inputs:
+            m = band_masks(Pn, H)
+            inputs[Pn] = (m, patch_conditions(cond_img, m).to(dev))
+        return inputs[Pn]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -666,64 +733,67 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def measure(steps, warmup):
-        """W untimed + K timed reverse steps in the model's current storage dtype -> (seconds, plan, z)."""
-        jp = net.plan(P, H, H, table_T=T_STEPS)
+    def measure(steps, warmup, Pn=P):
+        """W untimed + K timed reverse steps of ``Pn`` local patches in the model's current storage dtype -> (seconds, plan, z)."""
+        masks, conds = workload(Pn)
+        jp = net.plan(Pn, H, H, table_T=T_STEPS)
         jp.cond_in.copy_(conds)
-        x_T = torch.empty(P, 3, H, H, device=dev)
+        x_T = torch.empty(Pn, 3, H, H, device=dev)
         gd._noise(x_T, 0)
         jp.x_in.copy_(x_T)
         z = torch.empty_like(x_T)
         # inputs of the per-sample exchange are resident before the timed region starts (the masks are an input of the path;
         # uploading them inside it was 2 MB of pageable host-to-device copy per measurement: ~0.4 ms, 1.5 % of a 20-step run)
         img = torch.empty(1, 3, H, H, device=dev)
-        mk = masks.reshape(P, H * H).to(dev)
-        gathered = torch.empty(world * P, 3, H, H, device=dev) if world > 1 else None
+        mk = masks.reshape(Pn, H * H).to(dev)
+        gathered = torch.empty(world * Pn, 3, H, H, device=dev) if world > 1 else None
         # (the host paces a 27 ms timed region of the default run two steps ahead of the GPU: a collector pause in it is a GPU bubble.
         #  Collected HERE, in front of the warm-up: tens of milliseconds of an idle GPU between the warm-up and the timed region
         #  would start the region on a chip that has dropped its clocks)
         gc.collect()
         gc.disable()
-        # warm-up (untimed): encoder + W steps, then straight into the timed region
-        gd.encode_cond(jp, warmup)
-        draw = gd.run_joint_steps(jp, T_STEPS - 1, warmup, lo, hi, z, 1)
-        sync_all()
-        _tl = [] if os.environ.get("LD_BENCH_TIMELINE") else None
-        t0 = time.perf_counter()
-        t_start = T_STEPS - 1 - warmup
-        done, new_sample, parent_encoded = 0, True, False
-        while done < steps:                                         # wrap to a new sample after T steps
-            chunk = min(steps - done, t_start + 1)
-            # the conditioning encoder runs once per SAMPLE, inside the timed region.  Whether a chunk's steps run as
-            # sub-batches is decided per chunk (run_joint_steps: >= 4 steps): a short chunk at a wrap runs on the
-            # parent plan, whose features must then have been encoded as well.
-            if new_sample:
-                gd.encode_cond(jp, chunk)
-                parent_encoded = not gd._will_sub_batch(jp, chunk)
-            elif not gd._will_sub_batch(jp, chunk) and not parent_encoded:
-                jp.run_cond(st)
-                parent_encoded = True
+        try:                                                            # (an exception in the region must not leave the collector off)
+            # warm-up (untimed): encoder + W steps, then straight into the timed region
+            gd.encode_cond(jp, warmup)
+            draw = gd.run_joint_steps(jp, T_STEPS - 1, warmup, lo, hi, z, 1)
+            sync_all()
+            _tl = [] if os.environ.get("LD_BENCH_TIMELINE") else None
+            t0 = time.perf_counter()
+            t_start = T_STEPS - 1 - warmup
+            done, new_sample, parent_encoded = 0, True, False
+            while done < steps:                                         # wrap to a new sample after T steps
+                chunk = min(steps - done, t_start + 1)
+                # the conditioning encoder runs once per SAMPLE, inside the timed region.  Whether a chunk's steps run as
+                # sub-batches is decided per chunk (run_joint_steps: >= 4 steps): a short chunk at a wrap runs on the
+                # parent plan, whose features must then have been encoded as well.
+                if new_sample:
+                    gd.encode_cond(jp, chunk)
+                    parent_encoded = not gd._will_sub_batch(jp, chunk)
+                elif not gd._will_sub_batch(jp, chunk) and not parent_encoded:
+                    jp.run_cond(st)
+                    parent_encoded = True
+                if _tl is not None:
+                    _tl.append(("encode enqueued", time.perf_counter() - t0))
+                draw = gd.run_joint_steps(jp, t_start, chunk, lo, hi, z, draw)
+                if _tl is not None:
+                    _tl.append((f"{chunk} steps enqueued", time.perf_counter() - t0))
+                done += chunk
+                t_start -= chunk
+                new_sample = t_start < 0
+                if new_sample:
+                    t_start = T_STEPS - 1
+            # per-sample exchange: all-gather the local patches and recompose by the masks
+            xl = jp.x_in
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, xl.contiguous())
+                xl = gathered[rank * Pn:(rank + 1) * Pn]
+            cabi.check(lib.ld_recompose(xl.contiguous().data_ptr(), mk.data_ptr(), img.data_ptr(), 1, Pn, 3, H * H, st), "recompose")
             if _tl is not None:
-                _tl.append(("encode enqueued", time.perf_counter() - t0))
-            draw = gd.run_joint_steps(jp, t_start, chunk, lo, hi, z, draw)
-            if _tl is not None:
-                _tl.append((f"{chunk} steps enqueued", time.perf_counter() - t0))
-            done += chunk
-            t_start -= chunk
-            new_sample = t_start < 0
-            if new_sample:
-                t_start = T_STEPS - 1
-        # per-sample exchange: all-gather the local patches and recompose by the masks
-        xl = jp.x_in
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, xl.contiguous())
-            xl = gathered[rank * P:(rank + 1) * P]
-        cabi.check(lib.ld_recompose(xl.contiguous().data_ptr(), mk.data_ptr(), img.data_ptr(), 1, P, 3, H * H, st), "recompose")
-        if _tl is not None:
-            _tl.append(("recompose enqueued", time.perf_counter() - t0))
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        gc.enable()
+                _tl.append(("recompose enqueued", time.perf_counter() - t0))
+            sync_all()
+            elapsed = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if _tl is not None:                                         # LD_BENCH_TIMELINE=1: host clock inside the timed region (stderr)
             _tl.append(("synchronised", elapsed))
             print("timed region, host clock [ms]: " + ", ".join(f"{k} {1e3 * v:.3f}" for k, v in _tl), file=sys.stderr)
@@ -786,6 +856,22 @@ def main():
         pin = lowp_pin(a.dtype, dev)                               # the storage dtype's end-to-end distance (golden G16)
         if pin is not None:
             out["dtype_end_to_end"] = pin
+    if rank == 0 and world == 1 and not a.no_legs and not a.no_other_dtype and a.dtype in ("bf16", "fp16") and P == 8 and H == 256:
+        # The other BASELINE configs' throughput where the driver sees it, AFTER the headline measurement and
+        # its per-launch legs: short runs, compact blocks (the whole lines: `--patches 64`, `--workload cfg5`).
+        #   cfg4_share -- configs[3]'s share of one GPU: 64 local patches per GPU (two sub-batches of 32), 20 timed steps;
+        #   cfg5       -- configs[4] as stated on one GPU: 1x512x512, fp16, DDIM 50 of 1000, OOD + IND branches, fusion: three samples.
+        k64 = 20
+        e64, jp64, z64 = measure(k64, 5, Pn=64)
+        v64 = 64 * k64 / (T_STEPS * e64)
+        leg = {"metric": out["metric"], "value": v64, "unit": "patches/s", "steps": k64, "ms_per_step": 1e3 * e64 / k64, "dtype": a.dtype,
+               "patches_per_gpu": 64}
+        if not a.no_roofline:
+            leg["roofline"] = roofline_leg(gd, jp64, tp_value=v64, dtype=a.dtype, H=H, lo=lo, hi=hi, z=z64, nsteps=2, traffic_tag="p64")
+        out["cfg4_share"] = dict(_compact_leg(leg), patches_per_gpu=64,
+                                 workload="cfg4's per-GPU share: 64 local patches of 3x256x256 per GPU as two concurrent sub-batches of 32")
+        del jp64, z64                                          # (the 64-patch plans stay cached in the model: 2 GB of 288)
+        out["cfg5"] = _compact_leg(cfg5_run("fp16", 150, 0, 1, dev, None, want_roofline=not a.no_roofline))
     if rank == 0 and world == 1 and not a.no_cpu_baseline:        # contract: CPU baseline on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(net.cfg, sd, H, P)
     if rank == 0:

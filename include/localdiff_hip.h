@@ -12,8 +12,12 @@
  *   - plain pointers and sizes only; all pointers are DEVICE pointers unless marked "host".
  *   - every launch function takes the HIP stream to enqueue on (void*, a hipStream_t) and returns
  *     0 on success or a negative LD_E* code; ld_last_error() gives a thread-local message.
- *   - no allocation, no synchronisation, no global mutable state inside launch functions, so they
- *     may be captured into a HIP graph (ld_graph_*).
+ *   - no allocation and no synchronisation inside launch functions, so they may be captured into a HIP graph
+ *     (ld_graph_*).  The library's only process-wide mutable state is what this header documents further down: the
+ *     launch-routing table (ld_tuning_set / ld_tuning_get: read by the launch functions, written only by an explicit
+ *     call or once from the environment), the launch-routing counters (ld_counter: diagnostics, relaxed atomics), the
+ *     per-(kernel, device) LDS-limit cache and an open timing session (ld_timing_*); none of it changes what a launch
+ *     computes, only which kernel variant computes it.
  *   - internal activations are NHWC (channels-last) in the storage dtype (LD_F32, LD_BF16 or LD_F16),
  *     accumulation is always fp32 (the 16-bit types run v_mfma_f32_16x16x32_bf16 / _f16 at the same rate; fp16
  *     keeps 10 mantissa bits against bf16's 7, at a range of 6e-8 .. 65504); tensors that cross the reference's API (x_t, cond, mask, model
@@ -35,6 +39,7 @@ extern "C" {
 #define LD_OK 0
 #define LD_EINVAL (-1)   /* bad argument / unsupported shape */
 #define LD_EHIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
+#define LD_ETIMEOUT (-3) /* a deadline passed (ld_comm_init_timeout and the calls on the communicator it made) */
 
 #define LD_F32 0
 #define LD_BF16 1
@@ -383,8 +388,10 @@ int ld_step_begin_film(void* zero_a, size_t bytes_a, void* zero_b, size_t bytes_
 
 /* p_sample, single branch (ddpm.py:631-666, 739-761, 817-838, 857-858):
  *   x0 = clamp(to_x0(model_out)), x_prev = c1*x0 + c2*x_t + (t>0 ? sigma*z : 0).
- * x0_out may be NULL.  noise may be NULL when t == 0 is guaranteed.  `t_ptr` NULL = row mode: `sched` points at the step's
- * own row of the table and the draw is added iff `noise` is non-NULL (pass NULL at t == 0). */
+ * x0_out may be NULL.  `noise` may be NULL: then no draw is added, in either mode (round 6: table mode used to dereference it
+ * at t > 0).  Table mode (`t_ptr` non-NULL) adds sigma*z iff *t_ptr > 0 and `noise` is non-NULL.  Row mode (`t_ptr` NULL:
+ * `sched` points at the step's own row, the kernel does not know t) adds it iff `noise` is non-NULL -- the CALLER carries
+ * the reference's `t > 0` test (ddpm.py:857): pass NULL at t == 0, or the last step gets noise the reference does not add. */
 int ld_ddpm_step(const float* x_t, const float* model_out, const float* noise, float* x_prev,
                  float* x0_out, const float* sched, const int32_t* t_ptr, float lo, float hi,
                  int objective, int64_t n, void* stream);
@@ -471,6 +478,11 @@ int ld_recompose(const float* patches /*[B,K,C,HW]*/, const float* masks /*[K,HW
  * in torch.distributed (same RCCL); dist.gather_patches uses these entry points when asked to. */
 int ld_comm_unique_id(void* id_out_128 /* host, 128 bytes */);
 int ld_comm_init(void** comm_out, const void* id_128 /* host */, int world, int rank);
+/* The same with a deadline: the communicator comes up non-blocking (ncclCommInitRankConfig + ncclCommGetAsyncError polled
+ * against timeout_s); if it is not up in time -- a peer that never arrives, a stale unique id -- it is aborted
+ * (ncclCommAbort) and the call returns LD_ETIMEOUT instead of hanging.  timeout_s <= 0 = ld_comm_init (blocking).
+ * ld_allgather / ld_comm_destroy on such a communicator poll with the same deadline where RCCL answers ncclInProgress. */
+int ld_comm_init_timeout(void** comm_out, const void* id_128 /* host */, int world, int rank, double timeout_s);
 int ld_allgather(const void* send, void* recv, size_t bytes_per_rank, void* comm, void* stream);
 int ld_comm_destroy(void* comm);
 

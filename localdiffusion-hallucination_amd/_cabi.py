@@ -133,6 +133,7 @@ _SIGS = {
     "ld_recompose": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_comm_unique_id": (C.c_int, [vp]),
     "ld_comm_init": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
+    "ld_comm_init_timeout": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_double]),
     "ld_allgather": (C.c_int, [vp, vp, C.c_size_t, vp, vp]),
     "ld_comm_destroy": (C.c_int, [vp]),
 }
@@ -164,9 +165,14 @@ def lib():
     return l
 
 
+LD_ETIMEOUT = -3
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = lib().ld_last_error().decode("utf-8", "replace")
+        if rc == LD_ETIMEOUT:
+            raise TimeoutError(f"localdiff_hip {what} timed out: {msg}")
         raise RuntimeError(f"localdiff_hip {what} failed (rc={rc}): {msg}")
 
 

@@ -59,7 +59,8 @@ __global__ void ddpm_step_kernel(const float* x, const float* mo, const float* z
   // the draw is added at t > 0 (ddpm.py:857).  Row mode (t_ptr null: `sched` IS the step's row, the kernel does not know t):
   // the caller says it with the noise pointer -- null at t = 0.  (Round 5: row mode used to read t = 0 and dropped the draw at
   // every step; GaussianDiffusion.p_sample, the one caller, had no test that drew noise.)
-  const bool draw = t_ptr ? t > 0 : z != nullptr;
+  // Both modes are null-safe (round 6): a table-mode call at t > 0 without a noise buffer adds no draw instead of faulting.
+  const bool draw = (t_ptr ? t > 0 : true) && z != nullptr;
   GRID_STRIDE(i, n) {
     const float xi = x[i];
     const float x0 = clampf(to_x0(xi, mo[i], row, obj), lo, hi);
@@ -73,7 +74,7 @@ __global__ void posterior_step_kernel(const float* x, const float* x0, const flo
   const int t = t_ptr ? *t_ptr : 0;
   const float* row = sched + (size_t)t * LD_SCHED_COLS;
   const float c1 = row[LD_SCHED_COEF1], c2 = row[LD_SCHED_COEF2], sg = row[LD_SCHED_SIGMA];
-  const bool draw = t_ptr ? t > 0 : z != nullptr;          // (row mode: as in ddpm_step_kernel)
+  const bool draw = (t_ptr ? t > 0 : true) && z != nullptr;          // (as in ddpm_step_kernel: null-safe in both modes)
   GRID_STRIDE(i, n) {
     const float mean = c1 * x0[i] + c2 * x[i];
     xp[i] = draw ? mean + sg * z[i] : mean;

@@ -44,13 +44,16 @@ class LdComm:
     0 has to reach every rank through SOME channel; ``bootstrap`` uses the torch process group when there is one (a
     byte-tensor broadcast) or a file path otherwise."""
 
-    def __init__(self, world, rank, unique_id):
+    def __init__(self, world, rank, unique_id, timeout_s=120.0):
+        """``timeout_s`` > 0: the communicator comes up non-blocking and is polled against the deadline
+        (``ld_comm_init_timeout``); a peer that never arrives or a stale unique id raises ``TimeoutError`` (the half-built
+        communicator is aborted) instead of hanging in ``ncclCommInitRank``.  ``timeout_s`` = 0: the blocking call."""
         import ctypes as C
         from . import _cabi as cabi
         self.world, self.rank = world, rank
         self._comm = C.c_void_p()
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
-        cabi.check(cabi.lib().ld_comm_init(C.byref(self._comm), buf, world, rank), "comm_init")
+        cabi.check(cabi.lib().ld_comm_init_timeout(C.byref(self._comm), buf, world, rank, float(timeout_s or 0.0)), "comm_init")
 
     @staticmethod
     def make_unique_id():
@@ -77,10 +80,14 @@ class LdComm:
         """Collective: every rank calls it.  With a torch process group the id travels by broadcast; otherwise rank 0
         writes ``id_file`` and the others poll for it.  ``run_id`` (any string all ranks of THIS run agree on and no
         other run shares: a job id, ``TORCHELASTIC_RUN_ID``) becomes part of the file name; without one the name falls
-        back to ``MASTER_PORT``, which torchrun reuses from run to run -- so rank 0 removes the file again as soon as the
-        communicator is up (``ncclCommInitRank`` is collective: when it returns on rank 0 every rank has read the id),
-        and a file can only be left behind by a run that died inside the rendezvous.  After such a crash pass a fresh
-        ``run_id`` or ``id_file``: a stale id makes ``ncclCommInitRank`` hang, and ``timeout_s`` only bounds the polling."""
+        back to ``MASTER_PORT``, which torchrun reuses from run to run -- so rank 0 removes a pre-existing file before it
+        writes its own and removes its own again as soon as the communicator is up (the init is collective: when it
+        returns on rank 0 every rank has read the id); a file can only be left behind by a run that died inside the
+        rendezvous.  ``timeout_s`` bounds BOTH waits (round 6): the polling for the file and the communicator's own
+        bring-up (``ld_comm_init_timeout``: non-blocking init polled against the deadline, aborted on expiry), so a
+        non-zero rank that read such a stale id gets ``TimeoutError`` instead of hanging.  The per-process sequence number
+        that keeps successive bootstraps apart advances only when a bootstrap SUCCEEDS: a rank that timed out and retries
+        uses the same file name as rank 0 (which never times out on its own file)."""
         import os
         import time
         if dist.is_available() and dist.is_initialized():
@@ -90,10 +97,10 @@ class LdComm:
             if rank == 0:
                 t.copy_(torch.frombuffer(bytearray(cls.make_unique_id()), dtype=torch.uint8))
             dist.broadcast(t, 0)
-            return cls(world, rank, bytes(t.cpu().numpy().tobytes()))
+            return cls(world, rank, bytes(t.cpu().numpy().tobytes()), timeout_s)
         assert world is not None and rank is not None and (id_file is not None or world == 1)
         if world == 1:
-            return cls(1, 0, cls.make_unique_id())
+            return cls(1, 0, cls.make_unique_id(), timeout_s)
         if run_id is None:
             from .tuning import rendezvous_run_id
             run_id = rendezvous_run_id()
@@ -101,9 +108,13 @@ class LdComm:
             id_file = f"{id_file}.{run_id}"
         # a sequence number per bootstrap of this process (identical on all ranks: bootstrap is collective): a fast rank
         # entering the NEXT bootstrap can no longer find the previous one's file before rank 0 has unlinked it
-        cls._bootstraps = getattr(cls, "_bootstraps", 0) + 1
-        id_file = f"{id_file}.{cls._bootstraps}"
+        seq = getattr(cls, "_bootstraps", 0) + 1           # advanced below, once the communicator is up
+        id_file = f"{id_file}.{seq}"
         if rank == 0:
+            try:
+                os.unlink(id_file)                         # a file of this name can only be a crashed run's: never hand its id out
+            except OSError:
+                pass
             with open(id_file + ".tmp", "wb") as f:
                 f.write(cls.make_unique_id())
             os.replace(id_file + ".tmp", id_file)
@@ -112,7 +123,9 @@ class LdComm:
             if time.monotonic() - t0 > timeout_s:
                 raise TimeoutError(f"LdComm.bootstrap: rank {rank} saw no {id_file} within {timeout_s} s")
             time.sleep(0.01)
-        comm = cls(world, rank, open(id_file, "rb").read())
+        left = max(timeout_s - (time.monotonic() - t0), 1.0) if timeout_s else 0.0
+        comm = cls(world, rank, open(id_file, "rb").read(), left)
+        cls._bootstraps = seq
         if rank == 0:
             try:
                 os.unlink(id_file)

@@ -335,3 +335,98 @@ def test_kmask_flags_on_the_host():
 def test_recompose_has_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         ldist.recompose(torch.zeros(1, 2, 1, 4, 4), torch.zeros(2, 1, 4, 4))
+
+
+# ---------------------------------------------------------------- the communicator's deadline (round 6)
+_FAKE_RCCL = r"""
+/* A stand-in for librccl.so, test infrastructure only: ld_comm_init_timeout's polling logic runs against it on a box with no
+ * GPU.  FAKE_RCCL_MODE=hang: the communicator never comes up (a missing peer / a stale unique id); =slow: it comes up after
+ * FAKE_RCCL_POLLS polls.  Every call is appended to FAKE_RCCL_LOG. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+typedef struct { char internal[128]; } ncclUniqueId;
+static int polls = 0;
+static void note(const char* s) { const char* p = getenv("FAKE_RCCL_LOG"); if (p) { FILE* f = fopen(p, "a"); if (f) { fprintf(f, "%s\n", s); fclose(f); } } }
+static int hang(void) { const char* m = getenv("FAKE_RCCL_MODE"); return m && !strcmp(m, "hang"); }
+int ncclGetUniqueId(ncclUniqueId* id) { memset(id, 7, sizeof(*id)); note("unique_id"); return 0; }
+int ncclCommInitRank(void** c, int n, ncclUniqueId id, int r) { (void)n; (void)id; (void)r; *c = (void*)0x1000; note("init_blocking"); return 0; }
+int ncclCommInitRankConfig(void** c, int n, ncclUniqueId id, int r, void* cfg) {
+  (void)n; (void)r; (void)id;
+  *c = (void*)0x1000; polls = 0;
+  note(((int*)cfg)[4] == 0 ? "init_config blocking=0" : "init_config blocking!=0");     /* ncclConfig_t: size_t, magic, version, blocking */
+  return 7;                                                                               /* ncclInProgress */
+}
+int ncclCommGetAsyncError(void* c, int* st) {
+  (void)c; ++polls;
+  const char* n = getenv("FAKE_RCCL_POLLS");
+  *st = (!hang() && polls > (n ? atoi(n) : 3)) ? 0 : 7;
+  return 0;
+}
+int ncclCommAbort(void* c) { (void)c; note("abort"); return 0; }
+int ncclCommFinalize(void* c) { (void)c; note("finalize"); return 0; }
+int ncclCommDestroy(void* c) { (void)c; note("destroy"); return 0; }
+int ncclAllGather(const void* s, void* r, size_t n, int dt, void* c, void* st) { (void)s; (void)r; (void)n; (void)dt; (void)c; (void)st; note("allgather"); return 0; }
+const char* ncclGetErrorString(int rc) { (void)rc; return "fake"; }
+"""
+
+_DEADLINE_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+from localdiffusion_hallucination_amd import dist as ldist
+mode, id_file = sys.argv[2], sys.argv[3]
+if mode == "hang":
+    # a run that died inside the rendezvous left its id behind; rank 1 of the NEXT run finds it and its peers never come
+    with open(id_file + ".run.1", "wb") as f:
+        f.write(b"\x01" * 128)
+    t0 = time.monotonic()
+    try:
+        ldist.LdComm.bootstrap(world=2, rank=1, id_file=id_file, run_id="run", timeout_s=1.5)
+    except TimeoutError as e:
+        dt = time.monotonic() - t0
+        assert dt < 6.0, dt
+        assert getattr(ldist.LdComm, "_bootstraps", 0) == 0            # a failed bootstrap does not advance the sequence number
+        print("TIMEOUT", round(dt, 2), e)
+    else:
+        raise SystemExit("no TimeoutError")
+else:
+    with open(id_file + ".run.1", "wb") as f:                            # stale: rank 0 must replace it, never hand it out
+        f.write(b"\x01" * 128)
+    comm = ldist.LdComm.bootstrap(world=2, rank=0, id_file=id_file, run_id="run", timeout_s=5.0)
+    assert ldist.LdComm._bootstraps == 1 and not os.path.exists(id_file + ".run.1")
+    comm.close()
+    print("UP")
+"""
+
+
+def _fake_rccl(tmp_path):
+    import subprocess
+    src = tmp_path / "fake_rccl.c"
+    src.write_text(_FAKE_RCCL)
+    so = tmp_path / "libfake_rccl.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-o", str(so), str(src)], check=True)
+    return so
+
+
+@pytest.mark.parametrize("mode", ["hang", "slow"])
+def test_comm_bootstrap_deadline_against_a_fake_rccl(tmp_path, mode):
+    """A stale rendezvous file / a peer that never arrives is a TimeoutError within the deadline (and an aborted
+    communicator), not a hang in ncclCommInitRank; a communicator that needs a few polls comes up, advances the bootstrap
+    sequence number and is finalised + destroyed on close().  The RCCL entry points are a gcc-built stub reached through
+    LD_RCCL_PATH: the polling logic of ld_comm_init_timeout (csrc/collective.hip) needs no GPU."""
+    import subprocess
+    import sys
+    so = _fake_rccl(tmp_path)
+    log = tmp_path / "calls.log"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LD_RCCL_PATH=str(so), FAKE_RCCL_MODE=mode, FAKE_RCCL_LOG=str(log), FAKE_RCCL_POLLS="5")
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    r = subprocess.run([sys.executable, "-c", _DEADLINE_SCRIPT, root, mode, str(tmp_path / "id")], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    calls = log.read_text().split("\n")
+    assert "init_config blocking=0" in calls and "init_blocking" not in calls
+    if mode == "hang":
+        assert "TIMEOUT" in r.stdout and "abort" in calls and "destroy" not in calls
+    else:
+        assert "UP" in r.stdout and "abort" not in calls and calls.index("finalize") < calls.index("destroy")

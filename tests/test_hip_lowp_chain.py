@@ -97,19 +97,23 @@ def test_cfg2_chain_with_two_term_weights(golden, dtype):
 # cfg2's shape and schedule run by the real reference on the contractive procedural net (final_conv gain 0.25: a perturbation
 # grows x1.7 in the mean over the last 100 steps and not at all over the last 10, tools/exp_contractive.py), so the distance
 # of the FINAL image is a statement about the implementation and is bounded in MAX-abs.  Bounds (max-abs, mean-abs) on the
-# [0, 2] range through t = 100 and at t <= 10, ~2x what MI355X measured (round 5, printed by the test):
+# [0, 2] range through t = 100 and at t <= 10.  Round 6: the 16-bit bounds sit at 1.3x what MI355X measures
+# (they were ~2x: a summation-order change that doubled the distance would have passed silently; finding 105 had moved the bf16
+# final image from 9.3e-3 to 1.1e-2 inside the old bound) -- the next such change is a conscious decision.  The values repeat to
+# every printed digit from run to run and box to box (fp64 statistics, fixed summation orders); fp32 keeps 2x because its distance
+# is a few ulps of the image (quantised in steps of 1.2e-7).  Measured (printed by the test):
 #             through t = 100          final image (t = 0)
 #   fp32      1.2e-6 / 8.6e-8          2.2e-6 / 2.0e-7     (the reference against itself, 1 thread vs 8: 1.4e-6 / 1.9e-7)
-#   bf16      2.2e-3 / 3.7e-4          9.3e-3 / 7.4e-4
-#   fp16      3.5e-4 / 5.6e-5          2.0e-3 / 1.1e-4
-#   bf16x2    6.6e-4 / 5.2e-5          1.2e-2 / 6.9e-4     (two-term weights on two levels)
-#   fp16x2    6.3e-5 / 6.6e-6          1.4e-3 / 8.7e-5
+#   bf16      2.3e-3 / 3.7e-4          1.1e-2 / 7.4e-4
+#   fp16      3.8e-4 / 5.6e-5          2.1e-3 / 1.1e-4
+#   bf16x2    4.6e-4 / 5.1e-5          9.8e-3 / 6.9e-4     (two-term weights on two levels)
+#   fp16x2    5.2e-5 / 6.6e-6          1.4e-3 / 8.7e-5
 # What the last ten steps add in every 16-bit mode is the rounding of ONE evaluation's activations: the posterior weight of
 # x0_hat goes to 1 as t -> 0, so the final image carries the denoiser output's own 16-bit error (a single forward at the
 # bench shape: 6.7e-3 of the range in bf16, 9e-4 in fp16, tests/test_hip_bench_shape.py) -- two-term WEIGHTS remove the
-# chain's accumulated part (t = 100: 6x / 9x closer) and leave that one untouched.
-G16_BOUNDS = {"fp32": ((5e-6, 5e-7), (1e-5, 1e-6)), "bf16": ((4e-3, 7e-4), (2e-2, 1.5e-3)), "fp16": ((7e-4, 1.1e-4), (4e-3, 2.2e-4)),
-              "bf16x2": ((1.3e-3, 1e-4), (2.4e-2, 1.4e-3)), "fp16x2": ((1.3e-4, 1.3e-5), (3e-3, 1.8e-4))}
+# chain's accumulated part (t = 100: 5x / 7x closer) and leave that one untouched.
+G16_BOUNDS = {"fp32": ((2.4e-6, 1.8e-7), (4.5e-6, 4e-7)), "bf16": ((2.95e-3, 4.9e-4), (1.5e-2, 9.6e-4)), "fp16": ((4.9e-4, 7.3e-5), (2.7e-3, 1.4e-4)),
+              "bf16x2": ((6.0e-4, 6.7e-5), (1.3e-2, 9.0e-4)), "fp16x2": ((6.8e-5, 8.5e-6), (1.76e-3, 1.13e-4))}
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "fp16", "bf16x2", "fp16x2"])
