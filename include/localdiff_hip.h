@@ -68,6 +68,8 @@ int ld_graph_launch(void* graph_exec, void* stream);
 int ld_graph_destroy(void* graph_exec);
 /* hipMemsetAsync(ptr, 0, bytes) on the stream (statistics arenas are zeroed once per forward) */
 int ld_memset_zero(void* ptr, size_t bytes, void* stream);
+/* hipMemsetAsync(ptr, value & 0xff, bytes): the activation pool's verify mode poisons dead buffers with 0xFF (NaN in every storage type) */
+int ld_memset_bytes(void* ptr, int value, size_t bytes, void* stream);
 /* event timing on the stream the kernels run on (bench.py's roofline leg) */
 /* Per-launch timing session: between begin and end every kernel launched by this library (from the calling
  * process, any stream) carries its own start/stop events; ld_timing_count() = launches so far, ld_timing_end fills

@@ -63,6 +63,7 @@ _SIGS = {
     "ld_graph_launch": (C.c_int, [vp, vp]),
     "ld_graph_destroy": (C.c_int, [vp]),
     "ld_memset_zero": (C.c_int, [vp, C.c_size_t, vp]),
+    "ld_memset_bytes": (C.c_int, [vp, C.c_int, C.c_size_t, vp]),
     "ld_event_create": (C.c_int, [C.POINTER(vp)]),
     "ld_event_record": (C.c_int, [vp, vp]),
     "ld_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),

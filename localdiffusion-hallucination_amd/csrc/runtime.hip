@@ -134,6 +134,12 @@ extern "C" int ld_memset_zero(void* ptr, size_t bytes, void* stream) {
   return LD_OK;
 }
 
+extern "C" int ld_memset_bytes(void* ptr, int value, size_t bytes, void* stream) {
+  LD_REQUIRE(ptr || bytes == 0, "ld_memset_bytes: null");
+  if (bytes) LD_HIP(hipMemsetAsync(ptr, value & 0xff, bytes, reinterpret_cast<hipStream_t>(stream)));
+  return LD_OK;
+}
+
 extern "C" int ld_stream_wait_event(void* stream, void* ev) {
   LD_REQUIRE(ev, "ld_stream_wait_event: null event");
   LD_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(ev), 0));

@@ -37,6 +37,7 @@ class Tuning:
     pool_by_size: bool = True            # pool placement: largest buffers first (False: by first use; 9 % more pool at the bench shape)
     recompute_stem: bool = False         # pooled plans: init_conv evaluated a second time for the final block's concat instead of kept live
     buffer_reuse: bool = True            # sampler plans (table mode): activations share ONE pool by liveness instead of a buffer per layer
+    pool_verify: bool = False            # debugging: every pooled buffer is overwritten with 0xFF bytes (NaNs) right behind the launch of its last DECLARED use
     # ---- the library's launch-routing table (ld_tuning_set): name -> value, applied when the library is loaded
     kernel: Dict[str, int] = field(default_factory=dict)
 
@@ -53,6 +54,7 @@ class Tuning:
         "LD_POOL_BY_START": ("pool_by_size", lambda v: False),
         "LD_RECOMPUTE_STEM": ("recompute_stem", lambda v: v not in ("0", "")),
         "LD_BUFFER_REUSE": ("buffer_reuse", lambda v: v not in ("0", "")), "LD_NO_BUFFER_REUSE": ("buffer_reuse", lambda v: False),
+        "LD_POOL_VERIFY": ("pool_verify", lambda v: v not in ("0", "")),
         "LD_LINATTN_CHUNK_PX": ("linattn_chunk_px", lambda v: tuple(int(x) for x in (v.split(",") * 3)[:3])),
     }
 

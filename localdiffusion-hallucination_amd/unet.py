@@ -22,7 +22,7 @@ import torch
 from torch import nn
 
 from . import _cabi as cabi
-from .pool import peak_live, place_intervals
+from .pool import check_declared, intervals_from_declared, peak_live, place_intervals
 from .tuning import Tuning
 from .weights import UnetConfig, unet_param_shapes
 
@@ -279,7 +279,7 @@ class Unet(nn.Module):
         #  not silently keep plans built under the old one -- ADVICE r4)
         tn = self.tuning
         key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels,
-               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse, tn.recompute_stem, tn.pool_by_size)
+               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse, tn.recompute_stem, tn.pool_by_size, tn.pool_verify)
         if key not in self._plans:
             self._plans[key] = _Plan(self, B, H, W, table_T)
         return self._plans[key]
@@ -323,6 +323,8 @@ class _Plan:
         self._track = None                         # buffers of the main trunk, while buffer_reuse collects them
         self.named = {}                            # oracle tap name -> NHWC buffer (parity tests)
         self.meta = {}                             # index in ops_main -> {what, family, bytes, flops}
+        self.decl = {}                             # index in ops_main -> (tensors read, tensors written): what the launch DECLARES (pool liveness)
+        self.live_out = []                         # tensors of the main trunk something reads AFTER the launch list (the sampler's fused final step)
         self.ops_time, self.ops_cond, self.ops_main = [], [], []
         self.nslot = 0
         self.stats = torch.zeros(160, B, cabi.STAT_STRIPES, 16, 2, dtype=torch.float64, device=self.dev)
@@ -409,10 +411,17 @@ class _Plan:
         """Sampler plans: the activations of the main trunk share ONE pool, placed by liveness (first / last launch that
         touches a buffer), instead of one allocation per layer -- a 4-patch plan cycles through ~0.65 GB of distinct
         addresses per evaluation otherwise, 2.5x the Infinity Cache, and every output line is written back to HBM before its
-        address is seen again.  The launch list is analysed as it stands: ctypes argument blocks are scanned for pointers
-        into the tracked buffers (and patched), raw launches are closures over the tensors themselves (``data_ptr()`` at call
-        time), so re-pointing the tensor objects at the pool moves both.  Buffers reachable from plan attributes (``final``,
-        the conditioning features) stay live to the end of the evaluation; ``named`` taps of pooled buffers are dropped."""
+        address is seen again.
+
+        Liveness is DECLARED (round 6): every launch of ``ops_main`` carries the tensors it reads and writes (``self.decl``,
+        filled by the builders), tensors read after the list are in ``self.live_out``.  The launch list is still analysed as
+        it stands -- ctypes argument blocks scanned for pointers into the tracked buffers, raw launches for the tensors
+        their closures capture -- because that is what PATCHES the pointers and re-points the tensors; the scan is also
+        the cross-check of the declarations (pool.check_declared: a buffer a launch touches without declaring it, or
+        declares without a patchable reference, raises).  After patching everything is scanned again, plain integers
+        included: nothing may still point into an old allocation.  ``named`` taps of pooled buffers are dropped.
+        ``Tuning.pool_verify`` (LD_POOL_VERIFY=1): every buffer is overwritten with 0xFF bytes (NaN in every storage type)
+        right behind the launch of its last declared use, so an undeclared later read shows in the samples."""
         import bisect
         bufs = self._track or []
         if not bufs:
@@ -420,6 +429,7 @@ class _Plan:
         rng = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in bufs]
         order = sorted(range(len(bufs)), key=lambda k: rng[k][0])
         starts = [rng[k][0] for k in order]
+        n_ops = len(self.ops_main)
 
         def owner(ptr):
             j = bisect.bisect_right(starts, ptr) - 1
@@ -427,27 +437,21 @@ class _Plan:
                 return order[j]
             return None
 
-        first, last, patches = {}, {}, []
-
-        def touch(k, i):
-            first.setdefault(k, i)
-            last[k] = max(last.get(k, i), i)
-
-        def scan(obj, i):
+        def scan_struct(obj, hit):
+            """every c_void_p field of a ctypes block (nested structs / arrays included) that points into a tracked buffer"""
             if isinstance(obj, C.Array):
                 for e in obj:
                     if isinstance(e, (C.Structure, C.Array)):
-                        scan(e, i)
+                        scan_struct(e, hit)
                 return
             for name, typ in obj._fields_:
                 v = getattr(obj, name)
                 if isinstance(v, (C.Structure, C.Array)):
-                    scan(v, i)
+                    scan_struct(v, hit)
                 elif typ is cabi.vp and v:
                     k = owner(v)
                     if k is not None:
-                        touch(k, i)
-                        patches.append((obj, name, k, v - rng[k][0]))
+                        hit(obj, name, k, v - rng[k][0])
 
         def tensors(v, depth=0):
             if isinstance(v, torch.Tensor):
@@ -459,40 +463,55 @@ class _Plan:
                 for e in v.values():
                     yield from tensors(e, depth + 1)
 
-        for i, op in enumerate(self.ops_main):
+        def held(op):
+            """what a launch closure holds: default arguments and closure cells"""
             for d in (getattr(op, "__defaults__", None) or ()):
-                if hasattr(d, "_obj"):
-                    scan(d._obj, i)
-                for t in tensors(d):
-                    k = owner(t.data_ptr()) if t.is_cuda else None
-                    if k is not None:
-                        touch(k, i)
+                yield d
             for cell in (getattr(op, "__closure__", None) or ()):
                 try:
-                    v = cell.cell_contents
+                    yield cell.cell_contents
                 except ValueError:
                     continue
+
+        # ---- the reflection scan: per launch, the tracked buffers it references in a PATCHABLE form
+        scanned, patches = [set() for _ in range(n_ops)], []
+        for i, op in enumerate(self.ops_main):
+            def hit(obj, name, k, delta, i=i):
+                scanned[i].add(k)
+                patches.append((obj, name, k, delta))
+            for v in held(op):
+                if hasattr(v, "_obj"):                       # C.byref(args) of a _call launch
+                    scan_struct(v._obj, hit)
                 for t in tensors(v):
                     k = owner(t.data_ptr()) if t.is_cuda else None
                     if k is not None:
-                        touch(k, i)
-        n_ops = len(self.ops_main)
-        for name, v in self.__dict__.items():              # reachable from outside the launch list (``final``: the sampler's own
-            if name in ("_track", "keep", "named"):         # last launch reads it AFTER the list): live from its first launch to
-                continue                                    # the end of the evaluation, dead again while the next one starts
+                        scanned[i].add(k)
+        # ---- the declarations, and their agreement with the scan
+        def declared_set(ts):
+            out = set()
+            for t in ts:
+                k = owner(t.data_ptr()) if (t is not None and t.is_cuda) else None
+                if k is not None:
+                    out.add(k)
+            return out
+        declared = [declared_set(self.decl.get(i, ((), ()))[0]) | declared_set(self.decl.get(i, ((), ()))[1]) for i in range(n_ops)]
+        op_names = [self.meta.get(i, {}).get("what", "?") for i in range(n_ops)]
+        buf_names = [f"#{k} {tuple(t.shape)}" for k, t in enumerate(bufs)]
+        check_declared(declared, scanned, op_names, buf_names)
+        live_out = declared_set(self.live_out)
+        for name, v in self.__dict__.items():              # cross-check: a tracked buffer reachable from a plan attribute is read
+            if name in ("_track", "keep", "named", "decl", "live_out"):     # by something outside the launch list: it must be declared
+                continue
             for t in tensors(v):
                 k = owner(t.data_ptr()) if t.is_cuda else None
-                if k is not None:
-                    first[k], last[k] = first.get(k, -1), n_ops
-        for k in range(len(bufs)):                           # (a buffer no launch touches: keep it apart)
-            if k not in first:
-                first[k], last[k] = -1, n_ops
+                if k is not None and k not in live_out:
+                    raise RuntimeError(f"pool: plan attribute {name!r} reaches pooled buffer {buf_names[k]} that is not in live_out")
+        first, last = intervals_from_declared(declared, len(bufs), live_out)
         size = [(r[1] - r[0] + 255) // 256 * 256 for r in rng]
         # placement (pool.py): largest buffers first, each at the lowest offset free of every placed buffer whose closed interval
         # meets its own -- the pool then equals the peak live set (by first use it was 9 % above it; at 8 patches per GPU the
         # working set sits on the edge of the cache, finding 108)
-        idx = list(range(len(bufs)))
-        offset, top = place_intervals(size, [first[k] for k in idx], [last[k] for k in idx], self.tn.pool_by_size)
+        offset, top = place_intervals(size, first, last, self.tn.pool_by_size)
         self._pool = torch.empty(top, dtype=torch.uint8, device=self.dev)
         base = self._pool.data_ptr()
         for obj, name, k, delta in patches:
@@ -503,9 +522,43 @@ class _Plan:
             assert t.data_ptr() == base + offset[k]
             if last[k] < n_ops:
                 pooled.add(id(t))
+        # ---- after patching: NOTHING a launch holds may still point into an old allocation -- pointer fields, tensors, and plain
+        # integers (a data_ptr() taken at build time would have been missed by the scan above and is caught here)
+        def stale(v):
+            return isinstance(v, int) and not isinstance(v, bool) and owner(v) is not None
+        cur = [0]
+
+        def still(obj, name, k, delta):
+            raise RuntimeError(f"pool: launch {cur[0]} ({op_names[cur[0]]}) field {name} still points into the old allocation of {buf_names[k]}")
+        for i, op in enumerate(self.ops_main):
+            cur[0] = i
+            for v in held(op):
+                if hasattr(v, "_obj"):
+                    scan_struct(v._obj, still)
+                vals = list(v) if isinstance(v, (tuple, list)) else (list(v.values()) if isinstance(v, dict) else [v])
+                for e in vals:
+                    if stale(e):
+                        raise RuntimeError(f"pool: launch {i} ({op_names[i]}) holds the old address of {buf_names[owner(e)]} as a plain integer")
+                for t in tensors(v):
+                    if t.is_cuda and owner(t.data_ptr()) is not None:
+                        raise RuntimeError(f"pool: launch {i} ({op_names[i]}) holds a tensor that was not re-pointed at the pool")
         self.named = {k: v for k, v in self.named.items() if id(v) not in pooled}
-        peak = peak_live(size, [first[k] for k in idx], [last[k] for k in idx])
+        peak = peak_live(size, first, last)
         self.pool_stats = dict(buffers=len(bufs), bytes_unshared=sum(size), bytes_pool=top, bytes_peak_live=peak)
+        self.pool_intervals = [(first[k], last[k], offset[k], size[k]) for k in range(len(bufs))]
+        if self.tn.pool_verify:
+            dying = {}
+            for k in range(len(bufs)):
+                if 0 <= last[k] < n_ops:
+                    dying.setdefault(last[k], []).append((base + offset[k], size[k]))
+            lib = self.lib
+            for i, regions in dying.items():
+                def poisoned(st, op=self.ops_main[i], regions=tuple(regions)):
+                    op(st)
+                    for ptr, nbytes in regions:
+                        cabi.check(lib.ld_memset_bytes(ptr, 0xFF, nbytes, st), "pool verify")
+                self.ops_main[i] = poisoned
+            self.pool_stats["verify_poisoned_buffers"] = sum(len(r) for r in dying.values())
 
     def slot(self):
         s = self._slot_cursor
@@ -533,19 +586,24 @@ class _Plan:
             s.film_tstride = 0
             s.film_bstride = 2 * c
         self.keep.append(t)
+        s._tensor = t                                  # (python-side only: the builders declare it as read; lost when the struct is copied)
         return s
 
-    def _call(self, ops, fn, args, what, meta=None):
+    def _call(self, ops, fn, args, what, meta=None, reads=(), writes=()):
+        """``reads`` / ``writes``: the tensors this launch reads and writes (the pool's liveness comes from these declarations;
+        the reflection scan of ``args`` cross-checks them and patches the pointers: _pool_buffers)."""
         self.keep.append(args)
         ref = C.byref(args)
         ops.append(lambda st, fn=fn, ref=ref, what=what: cabi.check(fn(ref, st), what))
         if ops is self.ops_main:
             self.meta[len(ops) - 1] = dict(what=what, **(meta or {}))
+            self.decl[len(ops) - 1] = ([t for t in reads if t is not None], [t for t in writes if t is not None])
 
-    def _raw(self, ops, fn, what, nbytes=0, flops=0):
+    def _raw(self, ops, fn, what, nbytes=0, flops=0, reads=(), writes=()):
         ops.append(fn)
         if ops is self.ops_main:
             self.meta[len(ops) - 1] = dict(what=what, family=what, bytes=nbytes, flops=flops)
+            self.decl[len(ops) - 1] = ([t for t in reads if t is not None], [t for t in writes if t is not None])
 
     def conv3(self, ops, srcs, wname, cout, h, w, stats=None, groups=8, weight=None, bias=None, addend=None):
         a = cabi.Conv3x3Args()
@@ -588,7 +646,8 @@ class _Plan:
         in_el = sum(s.C * (npx // 4 if s.upsample else npx) for s in srcs)
         self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname,
                    dict(family=fam, bytes=(in_el + npx * cout + 9 * cin * cout) * self.esize + 4 * cout,
-                        flops=2 * 9 * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"))
+                        flops=2 * 9 * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"),
+                   reads=[s._tensor for s in srcs] + [addend], writes=[out])
         return out
 
     def conv1(self, ops, srcs, weight, cout, h, w, bias=None, epi=cabi.EPI_PLAIN, unshuffle=0, rms_in=0,
@@ -613,7 +672,8 @@ class _Plan:
         npx = self.B * h * w
         el = npx * cin + npx * cout + cin * cout * (self.B if bstride else 1) + (npx * cout if (residual is not None or gn_tail is not None) else 0)
         self._call(ops, self.lib.ld_conv1x1, a, what,
-                   dict(family="conv1x1", bytes=el * self.esize, flops=2 * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"))
+                   dict(family="conv1x1", bytes=el * self.esize, flops=2 * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"),
+                   reads=[s._tensor for s in srcs] + [residual, gn_tail._tensor if gn_tail is not None else None], writes=[out])
         return out
 
     def gn_apply(self, ops, a_src, b_src, h, w, c, final_act=cabi.ACT_NONE, pool=0):
@@ -627,7 +687,8 @@ class _Plan:
         g.B, g.H, g.W, g.t_ptr, g.dtype = self.B, h, w, self.t_ptr(), self.dt
         nel = self.B * h * w * c
         self._call(ops, self.lib.ld_gn_apply, g, "gn_apply",
-                   dict(family="gn_apply", bytes=(nel * (2 if b_src is not None else 1) + nel // (4 if pool else 1)) * self.esize, flops=0))
+                   dict(family="gn_apply", bytes=(nel * (2 if b_src is not None else 1) + nel // (4 if pool else 1)) * self.esize, flops=0),
+                   reads=[a_src._tensor, b_src._tensor if b_src is not None else None], writes=[out])
         return out
 
     # ------------------------------------------------------------------ time embedding / FiLM
@@ -742,15 +803,16 @@ class _Plan:
         terms = self.P.get("attn_terms", {}).get(p, 1)
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_kvctx_terms(x.data_ptr(), wkv.data_ptr(), ksp, ctx.data_ptr(), B, n, c,
                                                                         heads, 32, nchunks, dt, terms, st), "linattn_kvctx"),
-                  "linattn_kvctx", nbytes=npx * c * es, flops=2 * npx * c * 2 * hid * (1 if kshift is not None else 2) + 2 * npx * hid * 32)
+                  "linattn_kvctx", nbytes=npx * c * es, flops=2 * npx * c * 2 * hid * (1 if kshift is not None else 2) + 2 * npx * hid * 32,
+                  reads=[x], writes=[ctx])
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctxfold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold.data_ptr(), B, c,
                                                                     heads, 32, 1, dt, st), "linattn_ctxfold"),
-                  "linattn_ctxfold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
+                  "linattn_ctxfold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32, reads=[ctx], writes=[wfold])
         scale = cfg.attn_dim_head ** -0.5
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_out_terms(x.data_ptr(), wq.data_ptr(), qsp, wfold.data_ptr(), bias.data_ptr(),
                                                                       g2.data_ptr(), out.data_ptr(), B, n, c, scale, dt, terms, st),
                                              "linattn_out"),
-                  "linattn_out", nbytes=2 * npx * c * es, flops=2 * npx * hid * c * 2)
+                  "linattn_out", nbytes=2 * npx * c * es, flops=2 * npx * hid * c * 2, reads=[x, wfold], writes=[out])
         return out
 
     def linear_attention(self, ops, p, x, c, h, w):
@@ -773,10 +835,10 @@ class _Plan:
         es = self.esize
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctx(qkv.data_ptr(), kmax.data_ptr(), ctx.data_ptr(),
                                                                 B, n, heads, 32, nchunks, dt, st), "linattn_ctx"),
-                  "linattn_ctx", nbytes=2 * B * n * hid * es, flops=2 * B * n * hid * 32)
+                  "linattn_ctx", nbytes=2 * B * n * hid * es, flops=2 * B * n * hid * 32, reads=[qkv], writes=[ctx])
         self._raw(ops, lambda st: cabi.check(lib.ld_linattn_ctxfold(ctx.data_ptr(), nchunks, wout.data_ptr(), wfold.data_ptr(),
                                                                     B, c, heads, 32, 0, dt, st), "linattn_ctxfold"),
-                  "linattn_ctxfold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32)
+                  "linattn_ctxfold", nbytes=B * c * hid * es, flops=2 * B * c * hid * 32, reads=[ctx], writes=[wfold])
         q = self.src(qkv, hid, stride=3 * hid)
         return self.conv1(ops, [q], wfold, c, h, w, bias=f[p + ".to_out.0.bias"], epi=cabi.EPI_RMS_RES,
                           bstride=c * hid * self.esize, g2=self.P["g2"][p + ".to_out.1.g"], residual=x,
@@ -793,7 +855,7 @@ class _Plan:
         self.keep += [qkv, att]
         self._raw(ops, lambda st: cabi.check(lib.ld_attention(qkv.data_ptr(), att.data_ptr(), B, n, heads, 32, dt, st),
                                              "attention"),
-                  "attention", nbytes=4 * B * n * hid * self.esize, flops=4 * B * n * n * hid)
+                  "attention", nbytes=4 * B * n * hid * self.esize, flops=4 * B * n * n * hid, reads=[qkv], writes=[att])
         return self.conv1(ops, [self.src(att, hid)], self.P["w"][p + ".to_out.weight"], c, h, w,
                           bias=f[p + ".to_out.bias"], epi=cabi.EPI_RES, residual=x, what="full to_out " + p)
 
@@ -862,12 +924,12 @@ class _Plan:
             self._raw(ops, lambda st: cabi.check(lib.ld_conv_stem(
                 self.x_in.data_ptr(), wstem.data_ptr(), bi.data_ptr(), r.data_ptr(), B, cfg.channels, H, W, self.dt, st),
                 "init_conv"), "conv_image7x7",
-                nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W)
+                nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W, writes=[r])
         else:
             self._raw(ops, lambda st: cabi.check(lib.ld_conv_image(
                 self.x_in.data_ptr(), wi.data_ptr(), bi.data_ptr(), r.data_ptr(), None, 1, B, cfg.channels, H, W, 7,
                 self.dt, st), "init_conv"), "conv_image7x7",
-                nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W)
+                nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W, writes=[r])
         self.named["init_conv"] = r
         x, c, h, w = r, cfg.init_dim, H, W
         skips = []
@@ -918,7 +980,7 @@ class _Plan:
             self._raw(ops, lambda st, r2=r2: cabi.check(lib.ld_conv_stem(
                 self.x_in.data_ptr(), wstem2.data_ptr(), bi.data_ptr(), r2.data_ptr(), B, cfg.channels, H, W, self.dt, st),
                 "init_conv (again)"), "conv_image7x7",
-                nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W)
+                nbytes=B * H * W * (4 * cfg.channels + self.esize * cfg.init_dim), flops=2 * 49 * cfg.channels * cfg.init_dim * B * H * W, writes=[r2])
             r_cat = r2                                   # (``r`` itself stays bound: the first launch's closures write it)
         else:
             r_cat = r
@@ -928,10 +990,11 @@ class _Plan:
         bf = f["final_conv.bias"]
         self.keep += [wf, bf, x, r]
         self.final = (x, wf, bf)              # operands of the last op (diffusion.py fuses it with the sampler update)
+        self.live_out.append(x)               # ... which reads x AFTER the launch list: declared live to the end of the evaluation
         self._raw(ops, lambda st, x=x: cabi.check(lib.ld_final_conv(
             x.data_ptr(), wf.data_ptr(), bf.data_ptr(), self.model_out.data_ptr(), B, H, W, cfg.dim, cfg.out_dim,
             self.dt, st), "final_conv"), "final_conv",
-            nbytes=B * H * W * (self.esize * cfg.dim + 4 * cfg.out_dim), flops=2 * cfg.dim * cfg.out_dim * B * H * W)
+            nbytes=B * H * W * (self.esize * cfg.dim + 4 * cfg.out_dim), flops=2 * cfg.dim * cfg.out_dim * B * H * W, reads=[x])
 
     def __del__(self):
         try:

@@ -76,3 +76,18 @@ def test_inputs_and_outputs_of_one_launch_never_alias():
 def test_empty_and_single():
     assert place_intervals([], [], []) == ({}, 0) and peak_live([], [], []) == 0
     assert place_intervals([5], [2], [2]) == ({0: 0}, 5)
+
+
+def test_declarations_and_the_reflection_scan_must_agree():
+    """pool.check_declared: the builders' reads / writes and what the scan of the launch list finds are compared launch by
+    launch; either direction of disagreement names the launch and the buffer."""
+    import pytest
+    from localdiffusion_hallucination_amd.pool import check_declared, intervals_from_declared
+    ops, bufs = ["conv a", "gn_apply", "conv b"], ["#0", "#1", "#2"]
+    check_declared([{0}, {0, 1}, {1, 2}], [{0}, {0, 1}, {1, 2}], ops, bufs)
+    with pytest.raises(RuntimeError, match=r"launch 1 \(gn_apply\).*#2.*does not\s+declare"):
+        check_declared([{0}, {0, 1}, {1, 2}], [{0}, {0, 1, 2}], ops, bufs)          # an undeclared pointer into buffer 2
+    with pytest.raises(RuntimeError, match=r"launch 2 \(conv b\).*#1.*no patchable reference"):
+        check_declared([{0}, {0, 1}, {1, 2}], [{0}, {0, 1}, {2}], ops, bufs)          # declared, but held as something the scan cannot patch
+    first, last = intervals_from_declared([{0}, {0, 1}, {1, 2}], 4, live_out={2})
+    assert first == [0, 1, 2, -1] and last == [1, 2, 3, 3]                            # live_out -> n_ops; undeclared buffer 3 is kept apart
