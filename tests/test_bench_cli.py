@@ -109,4 +109,5 @@ def test_cfg5_one_image_on_two_ranks_spreads_its_branch_units_and_equals_the_one
     print(f"cfg5 fp32, one image: 2 ranks (branch units sharded) vs 1 rank: max-abs {float(d.max()):.3e} mean-abs {float(d.mean()):.3e}")
     # the unit runner and sample() step a branch with the same kernels on the same shapes; what differs is the order of a few
     # fp32 sums (tests/test_hip_dist.py pins the same equality at 1e-5 on small maps)
-    assert float(d.max()) < 5e-3 and float(d.mean()) < 5e-5, (float(d.max()), float(d.mean()))
+    # measured: 4.8e-5 / 1.4e-6
+    assert float(d.max()) < 1e-3 and float(d.mean()) < 2e-5, (float(d.max()), float(d.mean()))

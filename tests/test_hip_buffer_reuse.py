@@ -119,7 +119,7 @@ def test_pool_verify_cfg3_shape():
     pool is still the 100.7 MB peak live set of a 4-patch plan."""
     cond = torch.from_numpy(rng.uniform((8, 3, 256, 256), 35, 1, 0.0, 2.0))
     stats = _verify_pair(dict(channels=3, out_dim=3, mode="mvtec"), dict(data="mvtec"), 256, 6, "bf16", cond, None, 8)
-    four = [ps for ps in stats if ps["bytes_pool"] > 50e6]
+    four = [ps for ps in stats if 50e6 < ps["bytes_pool"] < 150e6]          # the two 4-patch sub-batch plans (the 8-patch parent plan: 201.3 MB)
     print(stats)
     assert four and all(abs(ps["bytes_pool"] - 100.7e6) < 0.6e6 and ps["bytes_pool"] == ps["bytes_peak_live"] for ps in four), stats
 
