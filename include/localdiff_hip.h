@@ -324,6 +324,10 @@ int ld_attention(const void* qkv, void* out, int B, int n, int heads, int dim_he
 int ld_time_mlp(const int32_t* times, int n, const float* freqs, int dim, const float* w1,
                 const float* b1, const float* w2, const float* b2, int time_dim, float* temb,
                 void* stream);
+/* The same with RandomOrLearnedSinusoidalPosEmb in front (ddpm.py:151-165; learned_sinusoidal_cond / random_fourier_features):
+ * emb = [t | sin(2 pi w_k t) | cos(2 pi w_k t)] with the module's `weights` [learned_dim / 2]; w1 is [time_dim, learned_dim + 1]. */
+int ld_time_mlp_fourier(const int32_t* times, int n, const float* weights, int learned_dim, const float* w1,
+                        const float* b1, const float* w2, const float* b2, int time_dim, float* temb, void* stream);
 /* film[i] = Linear(SiLU(temb[i]))  -> [n, 2*C] */
 int ld_film(const float* temb, int n, int time_dim, const float* w, const float* b, int two_c,
             float* film, void* stream);

@@ -99,6 +99,7 @@ _SIGS = {
     "ld_linattn_ctx_part_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ld_attention": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_time_mlp": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),
+    "ld_time_mlp_fourier": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]),
     "ld_film": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]),
     "ld_final_conv": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "ld_final_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, C.c_int, u64, i64, C.c_int, C.c_int, C.c_int,

@@ -296,6 +296,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 // the store has read them (cdna_hip_programming.md 5.7 item 1).  Other policy bits on the same store, in the sampler (three
 // alternating runs, sc1 = 1.244 ms): `sc0 sc1` 1.242 (the same), `sc1 nt` 1.298 (+4.4 %), `nt` alone 1.311 (+5.3 %: worse than
 // plain stores, although one kernel alone on the chip ran as fast with `nt` as with `sc1`).
+// PRECONDITION: the data and address registers must be VALU results, never raw MFMA accumulators.  hipcc's hazard
+// recogniser does not see inside the asm: the `s_nop 1` covers the overwrite of the data registers BEHIND the store, nothing covers
+// an MFMA write -> vector-memory read hazard (up to ~18 wait states) IN FRONT of it.  Every call site packs / converts / adds a bias
+// between the accumulator and the store, and the compiler-handled MFMA -> VALU wait protects that VALU instruction.  The shipped
+// machine code is checked for it: tools/scan_asm_store_sources.py (tests/test_codegen.py) finds the last writer of every sc1
+// store's registers in the library's code objects and fails if one is a matrix instruction.
 #ifndef LD_STORE_WT
 #define LD_STORE_WT 1
 #endif

@@ -6,6 +6,10 @@
 #include "common.hip.h"
 
 namespace {
+// FOURIER = false: SinusoidalPosEmb, emb = [sin(t f_k) | cos(t f_k)], `dim` wide (ddpm.py:136-149).
+// FOURIER = true: RandomOrLearnedSinusoidalPosEmb (ddpm.py:151-165), emb = [t | sin(2 pi w_k t) | cos(2 pi w_k t)], `dim` =
+// learned_sinusoidal_dim + 1 wide, `freqs` = the module's `weights`; the angle is ((t * w) * 2) * pi in fp32, the reference's order.
+template <bool FOURIER>
 __global__ void time_mlp_kernel(const int* __restrict__ times, const float* __restrict__ freqs, int dim,
                                 const float* __restrict__ w1, const float* __restrict__ b1,
                                 const float* __restrict__ w2, const float* __restrict__ b2, int td,
@@ -13,12 +17,19 @@ __global__ void time_mlp_kernel(const int* __restrict__ times, const float* __re
   extern __shared__ float sm[];            // emb[dim] | h[td]
   float* emb = sm;
   float* hbuf = sm + dim;
-  const int i = blockIdx.x, tid = threadIdx.x, half = dim / 2;
+  const int i = blockIdx.x, tid = threadIdx.x, half = dim / 2;      // (FOURIER: dim is odd, half = learned_sinusoidal_dim / 2)
   const float t = (float)times[i];
   if (tid < half) {
-    const float ang = t * freqs[tid];
-    emb[tid] = sinf(ang);
-    emb[half + tid] = cosf(ang);
+    if (FOURIER) {
+      const float ang = ((t * freqs[tid]) * 2.0f) * 3.14159265358979323846f;
+      emb[1 + tid] = sinf(ang);
+      emb[1 + half + tid] = cosf(ang);
+      if (tid == 0) emb[0] = t;
+    } else {
+      const float ang = t * freqs[tid];
+      emb[tid] = sinf(ang);
+      emb[half + tid] = cosf(ang);
+    }
   }
   __syncthreads();
   for (int o = tid; o < td; o += blockDim.x) {
@@ -56,9 +67,21 @@ extern "C" int ld_time_mlp(const int32_t* times, int n, const float* freqs, int 
                            void* stream) {
   LD_REQUIRE(times && freqs && w1 && b1 && w2 && b2 && temb && n > 0, "ld_time_mlp: bad args");
   LD_REQUIRE(dim % 2 == 0 && dim / 2 <= 128, "ld_time_mlp: dim %d", dim);
-  LD_LAUNCH(time_mlp_kernel, dim3(n), dim3(128), (dim + time_dim) * sizeof(float),
+  LD_LAUNCH(time_mlp_kernel<false>, dim3(n), dim3(128), (dim + time_dim) * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), times, freqs, dim, w1, b1, w2, b2, time_dim, temb);
   LD_LAUNCH_CHECK("time_mlp");
+  return LD_OK;
+}
+
+extern "C" int ld_time_mlp_fourier(const int32_t* times, int n, const float* weights, int learned_dim, const float* w1,
+                                   const float* b1, const float* w2, const float* b2, int time_dim, float* temb,
+                                   void* stream) {
+  LD_REQUIRE(times && weights && w1 && b1 && w2 && b2 && temb && n > 0, "ld_time_mlp_fourier: bad args");
+  LD_REQUIRE(learned_dim % 2 == 0 && learned_dim >= 2 && learned_dim / 2 <= 128, "ld_time_mlp_fourier: learned_sinusoidal_dim %d", learned_dim);
+  const int dim = learned_dim + 1;
+  LD_LAUNCH(time_mlp_kernel<true>, dim3(n), dim3(128), (dim + time_dim) * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), times, weights, dim, w1, b1, w2, b2, time_dim, temb);
+  LD_LAUNCH_CHECK("time_mlp_fourier");
   return LD_OK;
 }
 

@@ -50,9 +50,14 @@ class Unet(nn.Module):
                  attn_heads=4, full_attn=(False, False, False, True), flash_attn=False, mode="mri",
                  compute_dtype="fp32", tuning=None):
         super().__init__()
-        if self_condition or learned_variance or learned_sinusoidal_cond or random_fourier_features:
-            raise NotImplementedError("self_condition / learned_variance / learned sinusoidal embeddings "
-                                      "are never enabled by the reference's callers (test.py:117-129)")
+        # The reference's remaining constructor options (ddpm.py:294-300; no shipped caller sets them, test.py:117-129):
+        #   learned_variance      -> only the default out_dim doubles (:394); Unet.forward is unchanged;
+        #   learned_sinusoidal_cond / random_fourier_features -> time_mlp.0 is RandomOrLearnedSinusoidalPosEmb (:151-165, a
+        #       `weights` parameter of learned_sinusoidal_dim / 2 frequencies) and time_mlp.1 takes dim + 1 features;
+        #   self_condition        -> accepted like the reference accepts it; its forward then concatenates x_self_cond into an
+        #       init_conv that was built for `channels` inputs (:315-319, :406-408) and fails there -- mirrored in forward().
+        if (learned_sinusoidal_cond or random_fourier_features) and (learned_sinusoidal_dim % 2 or not 2 <= learned_sinusoidal_dim <= 256):
+            raise ValueError("learned_sinusoidal_dim must be even (ddpm.py:156) and at most 256")
         if dim != 32:
             raise ValueError("dim must be 32: the conditioning encoder hard-codes its widths "
                              "(unet_model.py:100) and is concatenated with the 8*dim bottleneck")
@@ -63,16 +68,19 @@ class Unet(nn.Module):
         full_attn = tuple(full_attn) if isinstance(full_attn, (tuple, list)) else (full_attn,) * len(dim_mults)
         assert len(full_attn) == len(dim_mults)
         init_dim = dim if init_dim is None else init_dim
-        self.cfg = UnetConfig(dim=dim, init_dim=init_dim, out_dim=channels if out_dim is None else out_dim,
+        learned = bool(learned_sinusoidal_cond or random_fourier_features)
+        default_out = channels * (2 if learned_variance else 1)                    # ddpm.py:394
+        self.cfg = UnetConfig(dim=dim, init_dim=init_dim, out_dim=default_out if out_dim is None else out_dim,
                               dim_mults=tuple(dim_mults), channels=channels,
                               resnet_block_groups=resnet_block_groups, attn_dim_head=attn_dim_head,
-                              attn_heads=attn_heads, full_attn=full_attn, mode=mode)
+                              attn_heads=attn_heads, full_attn=full_attn, mode=mode,
+                              learned_sinusoidal_dim=int(learned_sinusoidal_dim) if learned else 0)
         self.mode = mode
         self.channels = channels
         self.out_dim = self.cfg.out_dim
-        self.self_condition = False
+        self.self_condition = bool(self_condition)
         self.cond_img = cond_img
-        self.random_or_learned_sinusoidal_cond = False
+        self.random_or_learned_sinusoidal_cond = learned
         self.theta = sinusoidal_pos_emb_theta
         self.compute_dtype = compute_dtype
         g = torch.Generator().manual_seed(0)
@@ -80,6 +88,8 @@ class Unet(nn.Module):
         for name, shape in shapes.items():
             if name.endswith(".g"):
                 t = torch.ones(shape)
+            elif name.endswith(".weights"):
+                t = torch.randn(shape, generator=g)                                # ddpm.py:158
             elif len(shape) == 1 and (".norm." in name or "convblock.1" in name or "convblock.4" in name
                                       or "identity.1" in name):
                 t = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
@@ -288,6 +298,12 @@ class Unet(nn.Module):
     def forward(self, x, cond_img, time, x_self_cond=None):
         """ddpm.py:404-451.  x [B,C,H,W], cond_img [B,Cc,H,W], time int64 [B] -> [B,out_dim,H,W]."""
         B, _, H, W = x.shape
+        if self.self_condition:
+            # ddpm.py:406-408 concatenates x_self_cond (zeros by default) in front of x, and :413 feeds the 2 * channels result to an
+            # init_conv built for `channels` inputs (:315-319): the reference raises there, whatever the inputs.  Same here.
+            c = self.cfg.channels
+            raise RuntimeError(f"Given groups=1, weight of size [{self.cfg.init_dim}, {c}, 7, 7], expected input[{B}, {2 * c}, {H}, {W}] to have "
+                               f"{c} channels, but got {2 * c} channels instead (self_condition=True: ddpm.py:406-413)")
         p = self.plan(B, H, W)
         st = torch.cuda.current_stream().cuda_stream
         p.x_in.copy_(x.to(torch.float32))
@@ -701,10 +717,17 @@ class _Plan:
         self.keep.append(times)
         freqs = self.P["freqs"]
         n, td = self.rows, cfg.time_dim
-        self.ops_time.append(lambda st: cabi.check(lib.ld_time_mlp(
-            times.data_ptr(), n, freqs.data_ptr(), cfg.dim, f["time_mlp.1.weight"].data_ptr(),
-            f["time_mlp.1.bias"].data_ptr(), f["time_mlp.3.weight"].data_ptr(), f["time_mlp.3.bias"].data_ptr(),
-            td, self.temb.data_ptr(), st), "time_mlp"))
+        if cfg.learned_sinusoidal_dim:            # RandomOrLearnedSinusoidalPosEmb (ddpm.py:151-165): [t, sin(2 pi w t), cos(2 pi w t)]
+            wts = f["time_mlp.0.weights"]
+            self.ops_time.append(lambda st: cabi.check(lib.ld_time_mlp_fourier(
+                times.data_ptr(), n, wts.data_ptr(), cfg.learned_sinusoidal_dim, f["time_mlp.1.weight"].data_ptr(),
+                f["time_mlp.1.bias"].data_ptr(), f["time_mlp.3.weight"].data_ptr(), f["time_mlp.3.bias"].data_ptr(),
+                td, self.temb.data_ptr(), st), "time_mlp (learned Fourier features)"))
+        else:
+            self.ops_time.append(lambda st: cabi.check(lib.ld_time_mlp(
+                times.data_ptr(), n, freqs.data_ptr(), cfg.dim, f["time_mlp.1.weight"].data_ptr(),
+                f["time_mlp.1.bias"].data_ptr(), f["time_mlp.3.weight"].data_ptr(), f["time_mlp.3.bias"].data_ptr(),
+                td, self.temb.data_ptr(), st), "time_mlp"))
         for name in f:
             if name.endswith(".mlp.1.weight") and not name.startswith("conv_fusion"):
                 p = name[:-len(".mlp.1.weight")]

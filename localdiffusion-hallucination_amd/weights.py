@@ -31,6 +31,7 @@ class UnetConfig:
     attn_heads: int = 4
     full_attn: Tuple[bool, ...] = (False, False, False, True)
     mode: str = "mri"
+    learned_sinusoidal_dim: int = 0       # > 0: RandomOrLearnedSinusoidalPosEmb of that dim instead of SinusoidalPosEmb (ddpm.py:330-337)
 
     @property
     def dims(self):
@@ -44,6 +45,11 @@ class UnetConfig:
     @property
     def time_dim(self):
         return self.dim * 4
+
+    @property
+    def fourier_dim(self):
+        # ddpm.py:332-337: learned / random Fourier features are [t, sin, cos] (dim + 1), the sinusoidal embedding is `dim` wide
+        return self.learned_sinusoidal_dim + 1 if self.learned_sinusoidal_dim else self.dim
 
     @property
     def hidden(self):
@@ -126,7 +132,9 @@ def unet_param_shapes(cfg: UnetConfig) -> "OrderedDict[str, tuple]":
         _basic_block(sh, "cond_model.mid_conv.0", f[3], f[3], f[4])
     _conv(sh, "init_conv", cfg.init_dim, cfg.channels, 7)
     td = cfg.time_dim
-    sh["time_mlp.1.weight"] = (td, cfg.dim)
+    if cfg.learned_sinusoidal_dim:
+        sh["time_mlp.0.weights"] = (cfg.learned_sinusoidal_dim // 2,)            # ddpm.py:158 (requires_grad only differs)
+    sh["time_mlp.1.weight"] = (td, cfg.fourier_dim)
     sh["time_mlp.1.bias"] = (td,)
     sh["time_mlp.3.weight"] = (td, td)
     sh["time_mlp.3.bias"] = (td,)
@@ -192,7 +200,7 @@ def procedural_state_dict(cfg: UnetConfig, seed=0, final_gain=3.0):
         u = procedural_tensor(name, shape, seed)
         is_norm = (".norm." in name and not name.endswith(".g")) or \
                   ("convblock.1." in name) or ("convblock.4." in name) or ("identity.1." in name)
-        if name.endswith(".g"):
+        if name.endswith(".g") or name.endswith(".weights"):      # (.weights: the Fourier frequencies, any O(1) values)
             t = u
         elif is_norm:
             t = (1.0 + 0.1 * u) if name.endswith(".weight") else (0.1 * u)

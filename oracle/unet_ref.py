@@ -28,12 +28,19 @@ def rms_norm(x, g):
 
 
 def time_embedding(sd, time, dim, theta=10000.0):
-    """ddpm.py:136-149 (sinusoidal, half=dim/2 frequencies) + :339-344 (Linear-GELU-Linear)."""
-    half = dim // 2
-    step = math.log(theta) / (half - 1)
-    freq = torch.exp(torch.arange(half) * -step)
-    ang = time[:, None] * freq[None, :]
-    emb = torch.cat([ang.sin(), ang.cos()], dim=-1)
+    """ddpm.py:136-149 (sinusoidal, half=dim/2 frequencies) + :339-344 (Linear-GELU-Linear).  With a ``time_mlp.0.weights``
+    entry the first module is RandomOrLearnedSinusoidalPosEmb (ddpm.py:151-165; learned_sinusoidal_cond /
+    random_fourier_features): [t, sin(2 pi w t), cos(2 pi w t)]."""
+    if "time_mlp.0.weights" in sd:
+        x = time[:, None]                                                  # :161 rearrange 'b -> b 1'
+        freqs = x * sd["time_mlp.0.weights"][None, :] * 2 * math.pi        # :162
+        emb = torch.cat((x, torch.cat((freqs.sin(), freqs.cos()), dim=-1)), dim=-1)   # :163-164
+    else:
+        half = dim // 2
+        step = math.log(theta) / (half - 1)
+        freq = torch.exp(torch.arange(half) * -step)
+        ang = time[:, None] * freq[None, :]
+        emb = torch.cat([ang.sin(), ang.cos()], dim=-1)
     h = F.linear(emb, sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
     h = F.gelu(h)
     return F.linear(h, sd["time_mlp.3.weight"], sd["time_mlp.3.bias"])

@@ -170,3 +170,36 @@ def test_large_k_projections_fall_back_to_the_exact_softmax_shift(dtype, limit):
     rel = float((y - y_ref).abs().max()) / float(y_ref.abs().max())
     print(f"k rows x6, {dtype}: bounds {sorted(round(b, 1) for b in bounds.values())}, out rel err {rel:.3e}")
     assert torch.isfinite(y).all() and rel < (8e-3 if dtype == "fp16" else 5e-2)
+
+
+def test_remaining_constructor_options_match_the_reference(golden):
+    """The reference's Unet options no shipped caller sets (ddpm.py:294-300; golden G17 from the real reference):
+    learned_variance doubles the default out_dim (:394), learned_sinusoidal_cond / random_fourier_features put
+    RandomOrLearnedSinusoidalPosEmb in front of the time MLP (:151-165), self_condition is accepted by the constructor and fails
+    in the forward's init_conv exactly as the reference's does (:406-413).  GaussianDiffusion refuses the first two, as the
+    reference's asserts do (:515-516)."""
+    g = golden("g17_unet_options")
+    kw = dict(dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist", learned_variance=True, learned_sinusoidal_dim=16)
+    B, _, H, _ = [int(v) for v in g["shape"]]
+    x = torch.from_numpy(rng.randn((B, 1, H, H), 17, 100))
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 17, 101, 0.0, 2.0))
+    for opt in (dict(learned_sinusoidal_cond=True), dict(random_fourier_features=True)):
+        net, sd = build(dict(kw, **opt), "fp32")
+        assert net.out_dim == 2 and net.random_or_learned_sinusoidal_cond and "time_mlp.0.weights" in sd
+        assert list(net.state_dict().keys()) == list(sd.keys()) and tuple(sd["time_mlp.1.weight"].shape) == (128, 17)
+        for t in (0, 7, 99):
+            tv = torch.full((B,), t, dtype=torch.long)
+            y = net(x.cuda(), cond.cuda(), tv.cuda()).cpu()
+            with torch.no_grad():
+                y_orc = unet_ref.unet_forward(sd, net.cfg, x, cond, tv)
+            e_orc, e_gold = float((y - y_orc).abs().max()), float((y - torch.from_numpy(g[f"t{t}_out"])).abs().max())
+            print(f"learned Fourier features {opt} t={t}: vs oracle {e_orc:.2e}, vs reference golden {e_gold:.2e}")
+            assert tuple(y.shape) == (B, 2, H, H) and e_orc < 2e-4 and e_gold < 2e-4
+        with pytest.raises(AssertionError):
+            ldh.GaussianDiffusion(dict(branch_out=False, start_intermediate=False, start_timestep=2, data="mnist", mask_x=False, ood_AD=False,
+                                       ood_confidence=False, classifier=False, use_gt=False), net, image_size=H, timesteps=10, objective="pred_x0")
+    assert int(g["selfcond_forward_raises"][0]) == 1
+    sc = ldh.Unet(dim=32, init_dim=32, self_condition=True, dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist").to("cuda")
+    assert sc.self_condition
+    with pytest.raises(RuntimeError, match="to have 1 channels, but got 2 channels"):
+        sc(x.cuda(), cond.cuda(), torch.zeros(B, dtype=torch.long).cuda())

@@ -336,3 +336,26 @@ def test_training_forward_losses(golden, tag, cfg, H, B):
     # the timesteps of forward(train=False): torch's generator seeded with 42 (ddpm.py:1210-1211), drawn on the host
     torch.random.manual_seed(42)
     assert torch.randint(0, 100, (B,)).tolist() == g[f"{tag}_pred_x0_t_fwd"].tolist()
+
+
+def test_unet_constructor_options_fixture(golden):
+    """Golden G17 (the real reference with learned_variance + learned Fourier time features, tools/make_goldens.py g17): the
+    oracle reproduces it, the parameter inventory carries ``time_mlp.0.weights`` and a 17-wide first Linear, and the product's
+    constructor accepts every option of the reference's (ddpm.py:294-300) -- self_condition too, whose failure is the
+    forward's (tests/test_hip_unet.py)."""
+    import localdiffusion_hallucination_amd as ldh
+    g = golden("g17_unet_options")
+    cfg = weights.UnetConfig(dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist", out_dim=2, learned_sinusoidal_dim=16)
+    sd = {k: torch.from_numpy(v) for k, v in weights.procedural_state_dict(cfg, 0).items()}
+    B, _, H, _ = [int(v) for v in g["shape"]]
+    x = torch.from_numpy(rng.randn((B, 1, H, H), 17, 100))
+    cond = torch.from_numpy(rng.uniform((B, 1, H, H), 17, 101, 0.0, 2.0))
+    for t in (0, 7, 99):
+        with torch.no_grad():
+            y = unet_ref.unet_forward(sd, cfg, x, cond, torch.full((B,), t, dtype=torch.long))
+        assert float((y - torch.from_numpy(g[f"t{t}_out"])).abs().max()) <= 1e-5
+    net = ldh.Unet(dim=32, init_dim=32, dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist", learned_variance=True,
+                   random_fourier_features=True, self_condition=True)
+    assert net.cfg == cfg and net.out_dim == 2 and net.self_condition and net.random_or_learned_sinusoidal_cond
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    assert ldh.Unet(dim=32, learned_variance=True, out_dim=5).out_dim == 5          # an explicit out_dim wins (ddpm.py:395)

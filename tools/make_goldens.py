@@ -885,6 +885,57 @@ def g0_inventory(ddpm):
         f.write("\n".join(lines) + "\n")
 
 
+def g17(ddpm):
+    """The reference's remaining Unet constructor options (ddpm.py:294-300), which no shipped caller sets: learned_variance
+    (out_dim doubles, :394), learned_sinusoidal_cond / random_fourier_features (RandomOrLearnedSinusoidalPosEmb, :151-165) and
+    self_condition (accepted by the constructor; the forward then fails in init_conv, :406-413).  Forward outputs of the real
+    reference with the first two on, on the MNIST-shaped net; the oracle must reproduce them."""
+    print("G17 Unet constructor options: learned_variance + learned Fourier time features; self_condition")
+    cfg = weights.UnetConfig(dim_mults=(1, 2, 4), full_attn=(False, False, True), mode="mnist", out_dim=2, learned_sinusoidal_dim=16)
+    sd = sd_torch(cfg)
+    out = {}
+    for tag, kw in (("learned", dict(learned_sinusoidal_cond=True)), ("random", dict(random_fourier_features=True))):
+        ref = ddpm.Unet(dim=cfg.dim, init_dim=cfg.init_dim, dim_mults=cfg.dim_mults, channels=cfg.channels, full_attn=cfg.full_attn,
+                        mode=cfg.mode, learned_variance=True, learned_sinusoidal_dim=16, **kw)
+        assert ref.out_dim == 2 and ref.random_or_learned_sinusoidal_cond
+        ref_sd = ref.state_dict()
+        assert list(ref_sd.keys()) == list(sd.keys()), set(ref_sd) ^ set(sd)
+        for k in ref_sd:
+            assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+        ref.load_state_dict(sd)
+        ref.eval()
+        B, H = 2, 28
+        x = torch.from_numpy(rng.randn((B, 1, H, H), 17, 100))
+        cond = torch.from_numpy(rng.uniform((B, 1, H, H), 17, 101, 0.0, 2.0))
+        for t in (0, 7, 99):
+            tv = torch.full((B,), t, dtype=torch.long)
+            with torch.no_grad():
+                y_ref = ref(x, cond, tv)
+                y_orc = unet_ref.unet_forward(sd, cfg, x, cond, tv)
+            d = maxdiff(y_ref, y_orc)
+            print(f"  {tag} t={t}: out {tuple(y_ref.shape)}, oracle-vs-reference {d:.2e}")
+            assert tuple(y_ref.shape) == (B, 2, H, H) and d <= 1e-5, (tag, t, d)
+            if tag == "learned":
+                out[f"t{t}_out"] = y_ref.numpy()
+        try:                          # the reference's own GaussianDiffusion refuses both (ddpm.py:515-516)
+            _ref_diffusion(ddpm, base_config(data="mnist"), ref, H, 10, "sigmoid", "pred_x0", None)
+            raise SystemExit("GaussianDiffusion accepted a learned-variance / learned-sinusoidal Unet")
+        except AssertionError:
+            pass
+    sc = ddpm.Unet(dim=32, init_dim=32, dim_mults=cfg.dim_mults, channels=1, full_attn=cfg.full_attn, mode="mnist", self_condition=True)
+    try:
+        with torch.no_grad():
+            sc(x, cond, torch.zeros(B, dtype=torch.long))
+        raised = ""
+    except RuntimeError as e:
+        raised = str(e)
+    print("  self_condition=True forward:", raised[:120] or "no error")
+    assert "channels" in raised
+    out["selfcond_forward_raises"] = np.array([1])
+    out["shape"] = np.array([B, 1, H, 1])
+    save("g17_unet_options", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -894,7 +945,7 @@ def main():
     ddpm = import_reference()
     os.makedirs(GOLD, exist_ok=True)
     todo = [("G0", g0_inventory), ("G1", g1), ("G2", g2), ("G3", g3), ("G4", g4), ("G6", g6),
-            ("G7", g7), ("G8", g8), ("G9", g9), ("G10", g10), ("G12", g12), ("G14", g14), ("G15", g15), ("G5", g5), ("G11", g11), ("G13", g13), ("G16", g16)]
+            ("G7", g7), ("G8", g8), ("G9", g9), ("G10", g10), ("G12", g12), ("G14", g14), ("G15", g15), ("G17", g17), ("G5", g5), ("G11", g11), ("G13", g13), ("G16", g16)]
     only = set(filter(None, a.only.split(",")))
     for name, fn in todo:
         if only and name not in only:
