@@ -38,6 +38,14 @@ tail -1 $OUT/${TAG}_cfg5_bench.log > $OUT/${TAG}_cfg5_bench.json
 rm -rf /tmp/prof_k5
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k5 -o r -- python3 $R/bench.py --workload cfg5 --steps 100 --no-cpu-baseline --no-roofline > $OUT/${TAG}_cfg5_ks.log 2>&1 < /dev/null
 cp $(find /tmp/prof_k5 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_cfg5_kernel_stats.csv
+# 7. the conv path's chip-level leg as its own program: un-profiled wall figure, then the union of the same launches' execution
+#    intervals from a kernel trace (the two must agree)      -> <tag>_conv_path_chip.txt
+rm -rf /tmp/prof_cp
+(echo "# un-profiled: python3 tools/conv_path_chip_trace.py --reps 200"; python3 $R/tools/conv_path_chip_trace.py --reps 200 2> /dev/null | tail -1
+ echo "# rocprofv3 --kernel-trace -- python3 tools/conv_path_chip_trace.py --reps 200: the program's own wall figure under the profiler"
+ rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_cp -o r -- python3 $R/tools/conv_path_chip_trace.py --reps 200 2> /dev/null | tail -1
+ echo "# ... and the union of the conv-path dispatches' execution intervals in that trace (tools/conv_path_union.py)"
+ python3 $R/tools/conv_path_union.py $(find /tmp/prof_cp -name '*kernel_trace.csv' | head -1)) > $OUT/${TAG}_conv_path_chip.txt 2>&1 < /dev/null
 cut -c1-200 $OUT/${TAG}_bench.json
 head -14 $OUT/${TAG}_s1_kernel_stats.csv | cut -c1-150
 tail -15 $OUT/${TAG}_s1_pmc_summary.txt
