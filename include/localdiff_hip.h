@@ -98,10 +98,7 @@ int ld_stream_wait_event(void* stream, void* ev);
  * conv1x1 launches that qualify use the kernels with preloaded leading arguments), conv_s32 (3: bit mask of the launches the lean
  * Cout = 32 kernel of conv3x3_s32.hip takes -- 1 single-chunk without prologue, 2 with the GroupNorm prologue, 4 two-chunk),
  * conv_s32_min_tiles (1024: 16 x 16 tiles per launch from which it is used), attn_xcd_map (1: ld_attention's XCD-aware workgroup
- * order), conv_big4_min (256: workgroups of the 64-channel x 16-row tile from which ld_conv3x3 uses it instead of 64 x 8 rows),
- * gn_reg_coef (bit mask -- 1: ld_gn_apply's streaming launches whose channel fragments lie inside one group, 4: those whose fragments
- * span two groups (C = 32), 2: ld_conv1x1's GroupNorm-tail launches -- build their GroupNorm coefficients in registers instead of
- * through LDS; same values bit for bit).
+ * order), conv_big4_min (256: workgroups of the 64-channel x 16-row tile from which ld_conv3x3 uses it instead of 64 x 8 rows).
  * Values change routing, never
  * results beyond the summation order of a tile variant.  Unknown name: LD_EINVAL.  Not thread-safe against concurrent
  * launches (set it before launching).  The reference has no counterpart (its tuning is cuDNN's). */

@@ -67,7 +67,7 @@ struct LdTuning {
   long long conv_c32, conv_c32_min_tiles;
   long long conv_s32, conv_s32_min_tiles;
   long long conv_big4_min;
-  long long gn_frags_per_block, fold_split_min, attn_split_max_wgs, attn_split_min_n, lead_args, attn_xcd_map, gn_reg_coef;
+  long long gn_frags_per_block, fold_split_min, attn_split_max_wgs, attn_split_min_n, lead_args, attn_xcd_map;
 };
 const LdTuning& ld_tuning();
 
@@ -551,69 +551,6 @@ __device__ __forceinline__ void build_gn_coef(const SrcDev& S, int b, int trow, 
     coef[C + c] = s;
   }
   __syncthreads();
-}
-
-// The same coefficients in REGISTERS, for a thread that owns E consecutive channels c0 .. c0 + E - 1 for its whole launch (gn_apply's
-// streaming loop; round 6, VERDICT r5 item 2 -- the lean 3x3 kernel's prologue, finding 89, brought to the launches whose head is
-// still the LDS chain above: statistics -> DPP -> LDS -> barrier -> per-channel coefficients -> LDS -> barrier -> LDS reads).  Every
-// thread requests the 16 stripes of ITS group(s) itself -- a wave's lanes read the same 128-byte line per request (one stripe holds all
-// groups of an image), so the 16 requests of a wave are 16 line reads -- and gamma / beta / FiLM of its channels as 16-byte loads;
-// no LDS, no barrier, nothing that waits for another wave.  NG = groups the E channels span: 1 (E | channels per group) or 2
-// (channels per group = E / 2: C = 32 with 8 groups in 16-bit storage).  The stripes are added in row_group_sum_d's order -- a balanced
-// tree over stripes 0 .. 15 -- and the arithmetic behind them is build_gn_coef's, operation for operation: the coefficients are
-// bit-identical to the LDS path's.
-template <bool PRECISE, int E, int NG>
-__device__ __forceinline__ void gn_coef_regs(const SrcDev& S, int b, long npix, int c0, float* ca, float* cs) {
-  static_assert(LD_STAT_STRIPES == 16, "the stripe tree below is written for 16 stripes");
-  static_assert(E % 4 == 0 && (NG == 1 || NG == 2), "gn_coef_regs");
-  typedef __attribute__((ext_vector_type(2))) double f64x2;
-  const int C = S.C, G = S.groups, gs = C / G, g0 = c0 / gs;
-  const float* fp = S.film ? S.film + (long)b * S.film_bstride : S.gamma;      // (a null FiLM reads gamma's address and is discarded)
-  f32x4 gam[E / 4], bet[E / 4], fsc[E / 4], fsh[E / 4];
-#pragma unroll
-  for (int q = 0; q < E / 4; ++q) {
-    gam[q] = *reinterpret_cast<const f32x4*>(S.gamma + c0 + 4 * q);
-    bet[q] = *reinterpret_cast<const f32x4*>(S.beta + c0 + 4 * q);
-    fsc[q] = *reinterpret_cast<const f32x4*>(fp + c0 + 4 * q);
-    fsh[q] = *reinterpret_cast<const f32x4*>(fp + (S.film ? C : 0) + c0 + 4 * q);
-  }
-  f64x2 st[NG][16];
-  const double* sp = S.stats + ((size_t)b * LD_STAT_STRIPES * G + g0) * 2;
-#pragma unroll
-  for (int s = 0; s < 16; ++s)
-#pragma unroll
-    for (int j = 0; j < NG; ++j) st[j][s] = *reinterpret_cast<const f64x2*>(sp + ((size_t)s * G + j) * 2);
-  __builtin_amdgcn_sched_barrier(0);                     // every request of the head has left before anything waits
-  float mean[NG], rstd[NG];
-  const double inv_n = PRECISE ? 1.0 / ((double)npix * gs) : (double)__builtin_amdgcn_rcpf((float)npix * (float)gs);
-#pragma unroll
-  for (int j = 0; j < NG; ++j) {
-    f64x2 t[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) t[s] = st[j][s];
-#pragma unroll
-    for (int w = 1; w < 16; w *= 2)                      // (0+1), (2+3), ... then quads, halves, the row: row_group_sum_d's tree
-#pragma unroll
-      for (int s = 0; s < 16; s += 2 * w) t[s] = t[s] + t[s + w];
-    const double m = t[0][0] * inv_n;
-    double var = t[0][1] * inv_n - m * m;
-    var = var > 0.0 ? var : 0.0;
-    mean[j] = (float)m;
-    rstd[j] = PRECISE ? (float)(1.0 / sqrt(var + 1e-5)) : __builtin_amdgcn_rsqf((float)(var + 1e-5));
-  }
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int j = NG == 1 ? 0 : e / (E / 2);
-    float a = rstd[j] * gam[e >> 2][e & 3];
-    float s_ = bet[e >> 2][e & 3] - mean[j] * a;
-    if (S.film) {
-      const float sc = fsc[e >> 2][e & 3] + 1.0f;
-      a *= sc;
-      s_ = s_ * sc + fsh[e >> 2][e & 3];
-    }
-    ca[e] = a;
-    cs[e] = s_;
-  }
 }
 
 // RMSNorm's 1 / max(||x||, 1e-12) from the sum of squares (ddpm.py:131, F.normalize): exact IEEE sqrt + divide for fp32

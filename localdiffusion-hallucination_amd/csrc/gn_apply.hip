@@ -29,15 +29,10 @@ int run(const GnDev& g, hipStream_t st) {
                     (long)g.H * g.W < (1L << 31) && 256 % (g.a.C / E) == 0;
   if (lead) {
     const int cg = g.a.C | (g.a.groups << 10) | ((int)blocks << 16), hw = g.H * g.W;     // blocks <= 2048
-    // coefficients in registers (gn_coef_regs) where a thread's channel fragment lies inside one group, or spans exactly two
-    const int gs = g.a.C / g.a.groups;
-    const long long rm = ld_tuning().gn_reg_coef;            // bit 1: fragments inside one group, bit 4: fragments spanning two (C = 32)
-    const int reg = ((rm & 1) && gs % E == 0) ? 1 : (((rm & 4) && 2 * gs == E) ? 2 : 0);
-#define LD_GN_LEAD(HB, REG) LD_LAUNCH((gn_apply_lead_kernel<T, HB, REG>), grid, dim3(256), (REG) ? 0 : lds, st, g.a.data, g.b.data, g.a.stats, \
-                                      g.a.gamma, g.a.beta, g.a.film, cg, hw, g)
-    if (g.has_b) { if (reg == 1) LD_GN_LEAD(true, 1); else if (reg == 2) LD_GN_LEAD(true, 2); else LD_GN_LEAD(true, 0); }
-    else { if (reg == 1) LD_GN_LEAD(false, 1); else if (reg == 2) LD_GN_LEAD(false, 2); else LD_GN_LEAD(false, 0); }
-#undef LD_GN_LEAD
+    if (g.has_b) LD_LAUNCH((gn_apply_lead_kernel<T, true>), grid, dim3(256), lds, st, g.a.data, g.b.data, g.a.stats, g.a.gamma, g.a.beta,
+                           g.a.film, cg, hw, g);
+    else LD_LAUNCH((gn_apply_lead_kernel<T, false>), grid, dim3(256), lds, st, g.a.data, g.b.data, g.a.stats, g.a.gamma, g.a.beta,
+                   g.a.film, cg, hw, g);
   } else if (g.has_b) {
     if (g.pool) LD_LAUNCH((gn_apply_kernel<T, true, true>), grid, dim3(256), lds, st, g);
     else LD_LAUNCH((gn_apply_kernel<T, true, false>), grid, dim3(256), lds, st, g);

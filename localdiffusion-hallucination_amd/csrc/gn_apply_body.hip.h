@@ -50,9 +50,7 @@ __device__ __forceinline__ void eval_pixel(const GnDev& g, const float* ca, cons
 typedef const GnDev __attribute__((address_space(4)))* GnKernargPtr;   // the block in kernel-argument (constant) memory
 // `rest` (gn_apply_lead_kernel): `head` holds only what the head's requests need (preloaded kernel arguments); the
 // activation kinds and the output pointer are read from the block BEHIND those requests (finding 83).
-// REG = 1 / 2 (gn_apply_lead_kernel with 256 % fragments-per-pixel == 0, one normalised operand): the thread builds the
-// coefficients of its own channel fragment in registers (gn_coef_regs: 1 or 2 groups per fragment) -- no LDS, no barrier.
-template <typename T, bool HAS_B, bool POOL, int REG = 0>
+template <typename T, bool HAS_B, bool POOL>
 __device__ __forceinline__ void gn_apply_tile(const GnDev& head, const int bx, const int gdx, const int b, float* s_coef,
                                               GnKernargPtr rest = nullptr) {
   constexpr int E = DT<T>::E;
@@ -82,13 +80,8 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& head, const int bx, c
       pb1 = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(g.b.data) + e1);
     }
   }
-  float rca[E], rsa[E];
-  if constexpr (REG != 0) {
-    gn_coef_regs<DT<T>::precise, E, REG>(g.a, b, npix_in, (tid % fpp) * E, rca, rsa);
-  } else {
-    build_gn_coef<DT<T>::precise>(g.a, b, trow, npix_in, s_coef, red, tid, 256);
-    if (HAS_B && g.b.stats) build_gn_coef<DT<T>::precise>(g.b, b, trow, npix_in, s_coef + 2 * C, red, tid, 256);
-  }
+  build_gn_coef<DT<T>::precise>(g.a, b, trow, npix_in, s_coef, red, tid, 256);
+  if (HAS_B && g.b.stats) build_gn_coef<DT<T>::precise>(g.b, b, trow, npix_in, s_coef + 2 * C, red, tid, 256);
   if (rest) {
     GnKernargPtr pr = rest;
     asm volatile("" : "+s"(pr));
@@ -112,17 +105,13 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& head, const int bx, c
     }
     store16_out(out + (size_t)opix * C + c, pack16<T>(v));
   };
-  if (REG != 0 || 256 % fpp == 0) {
+  if (256 % fpp == 0) {
     const int c = (tid % fpp) * E, ppb = 256 / fpp;    // pixels per block-iteration
     float ca[E], sa[E], cb[E], sb[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      if constexpr (REG != 0) {
-        ca[e] = rca[e]; sa[e] = rsa[e]; cb[e] = 0.f; sb[e] = 0.f;
-      } else {
-        ca[e] = s_coef[c + e]; sa[e] = s_coef[C + c + e];
-        cb[e] = HAS_B ? s_coef[2 * C + c + e] : 0.f; sb[e] = HAS_B ? s_coef[3 * C + c + e] : 0.f;
-      }
+      ca[e] = s_coef[c + e]; sa[e] = s_coef[C + c + e];
+      cb[e] = HAS_B ? s_coef[2 * C + c + e] : 0.f; sb[e] = HAS_B ? s_coef[3 * C + c + e] : 0.f;
     }
     const int step = gdx * ppb;
     int opix = bx * ppb + tid / fpp;
@@ -161,7 +150,7 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& head, const int bx, c
         one(opix, c, ca, sa, cb, sb);
       }
     }
-  } else if constexpr (REG == 0) {
+  } else {
     const int nfrag = npix_out * fpp;
     for (int f = bx * 256 + tid; f < nfrag; f += gdx * 256) {
       const int opix = f / fpp, c = (f - opix * fpp) * E;
@@ -174,7 +163,7 @@ __device__ __forceinline__ void gn_apply_tile(const GnDev& head, const int bx, c
 // 14 leading scalar dwords -- both operands, the GroupNorm tables, C | groups << 10 | gridDim.x << 16 (the grid size is a
 // HIDDEN kernel argument: read through gridDim it is a scalar load in front of everything), pixels per image -- are
 // preloaded into SGPRs with the wave, so the pixel requests and the coefficient requests leave without a scalar round trip.
-template <typename T, bool HAS_B, int REG>
+template <typename T, bool HAS_B>
 __global__ __launch_bounds__(256) void gn_apply_lead_kernel(const void* a_data, const void* b_data, const double* a_stats, const float* a_gamma,
                                                             const float* a_beta, const float* a_film, int c_groups, int hw, GnDev rest) {
   extern __shared__ __attribute__((aligned(16))) float s_coef[];
@@ -186,8 +175,8 @@ __global__ __launch_bounds__(256) void gn_apply_lead_kernel(const void* a_data, 
   constexpr unsigned REST_OFF = ld_kernarg_offset<const void*, const void*, const double*, const float*, const float*, const float*, int, int>(alignof(GnDev));
   static_assert(REST_OFF == 56, "gn_apply_lead_kernel: leading arguments changed");
   typedef const char __attribute__((address_space(4)))* KChar;
-  gn_apply_tile<T, HAS_B, false, REG>(g, blockIdx.x, (int)((unsigned)c_groups >> 16), blockIdx.y, s_coef,
-                                      (GnKernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF));
+  gn_apply_tile<T, HAS_B, false>(g, blockIdx.x, (int)((unsigned)c_groups >> 16), blockIdx.y, s_coef,
+                                 (GnKernargPtr)((KChar)__builtin_amdgcn_kernarg_segment_ptr() + REST_OFF));
 }
 
 template <typename T, bool HAS_B, bool POOL>

@@ -196,7 +196,7 @@ LdTuning g_tuning = {/*c1_group*/ 1, /*c1_group_max_px*/ 32768, /*c1_group_min_c
                      /*conv_raw*/ 1, /*conv_mt4_min_wgs*/ 256, /*conv_big_min*/ 512, /*conv_sk*/ 0, /*conv_sk_max_wgs*/ 256,
                      /*conv_c32*/ 0, /*conv_c32_min_tiles*/ 2048, /*conv_s32*/ 3, /*conv_s32_min_tiles*/ 1024, /*conv_big4_min*/ 256,
                      /*gn_frags_per_block*/ 512, /*fold_split_min*/ 32,
-                     /*attn_split_max_wgs*/ 256, /*attn_split_min_n*/ 2048, /*lead_args*/ 1, /*attn_xcd_map*/ 1, /*gn_reg_coef*/ 3};
+                     /*attn_split_max_wgs*/ 256, /*attn_split_min_n*/ 2048, /*lead_args*/ 1, /*attn_xcd_map*/ 1};
 struct TuningEntry { const char* name; long long LdTuning::*field; };
 const TuningEntry g_tuning_entries[] = {
     {"c1_group", &LdTuning::c1_group}, {"c1_group_max_px", &LdTuning::c1_group_max_px}, {"c1_group_min_ch", &LdTuning::c1_group_min_ch},
@@ -205,8 +205,7 @@ const TuningEntry g_tuning_entries[] = {
     {"conv_sk_max_wgs", &LdTuning::conv_sk_max_wgs}, {"conv_c32", &LdTuning::conv_c32}, {"conv_c32_min_tiles", &LdTuning::conv_c32_min_tiles},
     {"conv_s32", &LdTuning::conv_s32}, {"conv_s32_min_tiles", &LdTuning::conv_s32_min_tiles}, {"conv_big4_min", &LdTuning::conv_big4_min},
     {"gn_frags_per_block", &LdTuning::gn_frags_per_block}, {"fold_split_min", &LdTuning::fold_split_min},
-    {"attn_split_max_wgs", &LdTuning::attn_split_max_wgs}, {"attn_split_min_n", &LdTuning::attn_split_min_n}, {"lead_args", &LdTuning::lead_args}, {"attn_xcd_map", &LdTuning::attn_xcd_map},
-    {"gn_reg_coef", &LdTuning::gn_reg_coef}};
+    {"attn_split_max_wgs", &LdTuning::attn_split_max_wgs}, {"attn_split_min_n", &LdTuning::attn_split_min_n}, {"lead_args", &LdTuning::lead_args}, {"attn_xcd_map", &LdTuning::attn_xcd_map}};
 constexpr int g_tuning_n = sizeof(g_tuning_entries) / sizeof(g_tuning_entries[0]);
 void tuning_env_once() {
   // the ONE place the library reads tuning from the environment: LD_<NAME IN CAPITALS>, once per process

@@ -54,7 +54,7 @@ def test_kernel_table_defaults_and_explicit_sets():
     assert lib.ld_tuning_name(lib.ld_tuning_count()) is None
     defaults = dict(c1_group=1, c1_group_max_px=32768, c1_group_min_ch=4, c1_pair_max_px=1 << 40, c1_small_min=256, conv_raw=1,
                     conv_mt4_min_wgs=256, conv_big_min=512, conv_sk=0, conv_sk_max_wgs=256, conv_c32=0, conv_c32_min_tiles=2048, conv_s32=3, conv_s32_min_tiles=1024, conv_big4_min=256,
-                    gn_frags_per_block=512, fold_split_min=32, attn_split_max_wgs=256, attn_split_min_n=2048, lead_args=1, attn_xcd_map=1, gn_reg_coef=3)
+                    gn_frags_per_block=512, fold_split_min=32, attn_split_max_wgs=256, attn_split_min_n=2048, lead_args=1, attn_xcd_map=1)
     assert sorted(names) == sorted(defaults)
     overridden = {n for n in names if os.environ.get("LD_" + n.upper()) is not None}
     table = kernel_table(lib)
