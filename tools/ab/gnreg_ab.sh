@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: same-box A/B of the register GroupNorm coefficients (library table entry gn_reg_coef, LD_GN_REG_COEF):
 #   0 = LDS chain everywhere, 1 = gn_apply (fragment inside one group), 5 = + gn_apply at C = 32, 3 / 7 = + conv1x1's GroupNorm tails.
-# usage: bash tools/ab/gnreg_ab.sh "0 1 5 7" [steps]
+# usage: bash tools/ab/gnreg_ab.sh "0 1 5 7" [steps]   (the kernels of this experiment: git show eea172d; measured slower, reverted -- docs/findings.md 111)
 cd $GRAFT_REPO_ROOT
 SET=${1:-"0 1 5"}
 STEPS=${2:-400}

@@ -4,7 +4,8 @@
 #   2. the same with LD_SUB_BATCHES=1 (one batch, one stream: the regime `roofline.frac` prices)  -> <tag>_s1_bench.json
 #   3. rocprofv3 --kernel-trace --stats of both commands (fewer steps)    -> <tag>_kernel_stats.csv, <tag>_s1_kernel_stats.csv
 #   4. separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of the solo regime -> <tag>_s1_pmc_traffic.json / _pmc_summary.txt
-#   5. the same passes in the default regime -> <tag>_pmc_traffic.json / _pmc_summary.txt;  6. cfg5 bench line + kernel trace
+#   5. the same passes in the default regime -> <tag>_pmc_traffic.json / _pmc_summary.txt;  6. cfg5 bench line + kernel trace + its own
+#   --pmc passes (<tag>_cfg5_pmc_traffic.json);  7. the conv path's chip-level leg alone, un-profiled and as a kernel trace
 # rocprofv3's interception slows the graph launches of the two-sub-batch regime (its kernels then overlap less than
 # un-profiled); the single-stream eager run is hardly perturbed, which is why the roofline numbers are tied to it.
 TAG=${1:-rXX}
@@ -38,6 +39,11 @@ tail -1 $OUT/${TAG}_cfg5_bench.log > $OUT/${TAG}_cfg5_bench.json
 rm -rf /tmp/prof_k5
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k5 -o r -- python3 $R/bench.py --workload cfg5 --steps 100 --no-cpu-baseline --no-roofline > $OUT/${TAG}_cfg5_ks.log 2>&1 < /dev/null
 cp $(find /tmp/prof_k5 -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_cfg5_kernel_stats.csv
+# 6b. cfg5's own --pmc passes (its dominant conv3x3<f16,2,2> had no traffic figure) -> <tag>_cfg5_pmc_traffic.json
+rm -rf /tmp/prof_f5 /tmp/prof_w5
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f5 -o r -- python3 $R/bench.py --workload cfg5 --steps 50 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pf5.log 2>&1 < /dev/null
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w5 -o r -- python3 $R/bench.py --workload cfg5 --steps 50 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pw5.log 2>&1 < /dev/null
+python3 $R/tools/pmc_summarize.py /tmp/prof_f5 /tmp/prof_w5 $OUT/${TAG}_cfg5_pmc_traffic.json $OUT/${TAG}_cfg5_bench.json > $OUT/${TAG}_cfg5_pmc_summary.txt 2>&1
 # 7. the conv path's chip-level leg as its own program: un-profiled wall figure, then the union of the same launches' execution
 #    intervals from a kernel trace (the two must agree)      -> <tag>_conv_path_chip.txt
 rm -rf /tmp/prof_cp
