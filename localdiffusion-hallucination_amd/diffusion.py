@@ -65,6 +65,9 @@ def _align_streams(streams):
                 gs.wait_event(ev)
 
 
+_SIDE_STREAMS = {}       # (device index, CU-mask kind) -> side streams shared by all samplers of the process (_sub_streams)
+
+
 def _masked_stream(i, kind):
     """A side stream restricted to a subset of the CUs (``GaussianDiffusion.sub_cu_mask``; DESIGN finding 40):
     ``lo`` (mask bits [128 i, 128 i + 128)), ``xcd`` (bits with (bit mod 8) div 4 == i: the KFD stripes mask bits over
@@ -740,13 +743,15 @@ class GaussianDiffusion(nn.Module):
         return b * H * W >= self.min_sub_batch * 256 * 256 or b >= 2 * self.min_sub_batch
 
     def _sub_streams(self, S):
-        """The S side streams of the sub-batch runners (shared by all of them: HIP maps streams onto a few
-        hardware queues per process, so more streams than needed only make two of them share a queue)."""
-        if not hasattr(self, "_side_streams"):
-            self._side_streams = []
-        while len(self._side_streams) < S:
-            self._side_streams.append(_masked_stream(len(self._side_streams), self.sub_cu_mask) or torch.cuda.Stream())
-        return self._side_streams[:S]
+        """The S side streams of the sub-batch runners, shared by every runner AND every sampler object of the process on this
+        device: HIP maps streams onto a few hardware queues per process (four by default), so a second ``GaussianDiffusion``
+        with side streams of its own finds two of them on ONE queue and its sub-batches serialise (round 6: a cfg5 sampler built
+        after a cfg3 sampler in the same process ran 9.6 images/s instead of 15.0).  The pool is keyed by (device, CU-mask kind)."""
+        key = (torch.cuda.current_device(), self.sub_cu_mask)
+        pool = _SIDE_STREAMS.setdefault(key, [])
+        while len(pool) < S:
+            pool.append(_masked_stream(len(pool), self.sub_cu_mask) or torch.cuda.Stream())
+        return pool[:S]
 
     def timed_plan(self, jp):
         """The plan whose launches ``run_joint_steps(..., timers=acc)`` times: sub-batch 0 when the joint steps

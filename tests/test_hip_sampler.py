@@ -765,3 +765,12 @@ def test_auto_normalize_maps_the_result_to_zero_one():
     auto2 = make(MNIST, dict(data="mnist"), H, T)
     l_plain = float(auto2.p_losses((x0 * 2 - 1).cuda(), cond.cuda(), t))
     assert l_auto == l_plain
+
+
+def test_sampler_objects_of_one_process_share_their_side_streams():
+    """HIP maps a process's streams onto four hardware queues: a second GaussianDiffusion that created side streams of its own
+    found two of them on ONE queue, and its two sub-batches ran one after the other (round 6: the cfg5 leg of bench.py's default
+    line read 9.6 images/s where `--workload cfg5` alone reads 15.0).  The pool of side streams is per (device, CU-mask kind)."""
+    a, b = make(dict(mode="mri"), dict(data="mri"), 32, 8), make(dict(mode="mri"), dict(data="mri"), 64, 8)
+    sa, sb = a._sub_streams(2), b._sub_streams(2)
+    assert len(sa) == 2 and all(x is y for x, y in zip(sa, sb))
