@@ -44,6 +44,13 @@ rm -rf /tmp/prof_f5 /tmp/prof_w5
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f5 -o r -- python3 $R/bench.py --workload cfg5 --steps 50 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pf5.log 2>&1 < /dev/null
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w5 -o r -- python3 $R/bench.py --workload cfg5 --steps 50 --no-cpu-baseline --no-roofline > $OUT/${TAG}_pw5.log 2>&1 < /dev/null
 python3 $R/tools/pmc_summarize.py /tmp/prof_f5 /tmp/prof_w5 $OUT/${TAG}_cfg5_pmc_traffic.json $OUT/${TAG}_cfg5_bench.json > $OUT/${TAG}_cfg5_pmc_summary.txt 2>&1
+# 6c. the same for cfg4's per-GPU share (64 patches per GPU) -> <tag>_p64_pmc_traffic.json (the default line's cfg4_share leg quotes it)
+rm -rf /tmp/prof_f6 /tmp/prof_w6
+python3 $R/bench.py --patches 64 --steps 20 --warmup 5 --no-cpu-baseline --no-other-dtype > $OUT/${TAG}_p64s_bench.log 2>&1 < /dev/null
+tail -1 $OUT/${TAG}_p64s_bench.log > $OUT/${TAG}_p64s_bench.json
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_f6 -o r -- python3 $R/bench.py --patches 64 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_pf6.log 2>&1 < /dev/null
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_w6 -o r -- python3 $R/bench.py --patches 64 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-other-dtype > $OUT/${TAG}_pw6.log 2>&1 < /dev/null
+python3 $R/tools/pmc_summarize.py /tmp/prof_f6 /tmp/prof_w6 $OUT/${TAG}_p64_pmc_traffic.json $OUT/${TAG}_p64s_bench.json > $OUT/${TAG}_p64_pmc_summary.txt 2>&1
 # 7. the conv path's chip-level leg as its own program: un-profiled wall figure, then the union of the same launches' execution
 #    intervals from a kernel trace (the two must agree)      -> <tag>_conv_path_chip.txt
 rm -rf /tmp/prof_cp
