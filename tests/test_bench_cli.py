@@ -111,3 +111,24 @@ def test_cfg5_one_image_on_two_ranks_spreads_its_branch_units_and_equals_the_one
     # fp32 sums (tests/test_hip_dist.py pins the same equality at 1e-5 on small maps)
     # measured: 4.8e-5 / 1.4e-6
     assert float(d.max()) < 1e-3 and float(d.mean()) < 2e-5, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.gpu
+def test_default_line_carries_every_baseline_config():
+    """The default bench line (what the driver runs, N = 1): the headline cfg3 measurement first, then the compact `cfg4_share`
+    (64 patches per GPU) and `cfg5` (512^2, fp16, DDIM 50, branch + fusion) legs with throughput, step time and their dominant
+    family's roofline fraction, the other storage dtype, the dtype's end-to-end distance -- ONE JSON line."""
+    import json
+    r = _run(["--steps", "6", "--warmup", "3", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["metric"].startswith("local patches/sec") and j["n_gpus"] == 1 and j["steps"] == 6 and j["dtype"] == "bf16"
+    assert j["roofline"]["bound"] in ("hbm", "mfma") and 0 < j["roofline"]["frac"] < 1 and "resblock_conv_path" in j["roofline"]
+    c4, c5 = j["cfg4_share"], j["cfg5"]
+    assert c4["patches_per_gpu"] == 64 and c4["unit"] == "patches/s" and c4["value"] > 0 and 0 < c4["dominant"]["frac"] < 1
+    assert c5["unit"] == "images/s" and c5["dtype"] == "fp16" and c5["value"] > 0 and c5["dominant"]["kernel"].startswith("conv3x3<f16")
+    # a second sampler object must not serialise its sub-batches behind the first one's streams (round 6): cfg5 alone reads ~15
+    assert c5["value"] > 11.0, c5
+    assert j["other_dtype"]["dtype"] == "fp16" and "dtype_end_to_end" in j
