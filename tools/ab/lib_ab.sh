@@ -8,7 +8,7 @@ K=${3:-600}
 for i in $(seq 1 $N); do
   for which in tree other; do
     if [ $which = other ]; then export LD_LIB_OVERRIDE=$OTHER; else unset LD_LIB_OVERRIDE; fi
-    python bench.py --no-cpu-baseline --no-other-dtype --no-roofline --steps $K 2>/dev/null | python -c "
+    python bench.py --no-cpu-baseline --no-other-dtype --no-roofline --no-legs --steps $K 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('$which (${1:-libplain.so})', round(d['ms_per_step'],4))"
   done
 done

@@ -6,7 +6,7 @@ N=$1; K=$2; shift 2
 for i in $(seq 1 $N); do
   for which in tree "$@"; do
     if [ $which = tree ]; then unset LD_LIB_OVERRIDE; else export LD_LIB_OVERRIDE=$GRAFT_REPO_ROOT/tools/ab/$which; fi
-    python bench.py --no-cpu-baseline --no-other-dtype --no-roofline --steps $K 2>/dev/null | python -c "
+    python bench.py --no-cpu-baseline --no-other-dtype --no-roofline --no-legs --steps $K 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('%-12s' % '$which', round(d['ms_per_step'],4))"
   done
 done
