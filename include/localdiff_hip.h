@@ -163,6 +163,10 @@ typedef struct ld_conv3x3_args {
                            /* second operand does not change between reverse steps (conv_fusion, ddpm.py:434-436) */
   int32_t weight_terms;    /* 0 / 1: `weight` from ld_pack_conv_weight; 2: two-term weights from                    */
                            /* ld_pack_conv_weight_terms(..., 2) (16-bit storage): x*hi + x*lo, weights exact to 2^-17 */
+  const void* side_weight; /* optional second output of the launch (16-bit storage, raw sources): a 1x1 convolution of the  */
+  const float* side_bias;  /* SAME concatenated input -- the ResnetBlock's res_conv (ddpm.py:198, 212) beside its block1     */
+  void* side_out;          /* convolution.  side_weight [Cout, Cin] packed by ld_pack_conv_weight(ksize 1), side_bias [Cout],  */
+                           /* side_out NHWC [B,H,W,Cout] = W_side x + side_bias (no statistics).  NULL = none.              */
 } ld_conv3x3_args;
 int ld_conv3x3(const ld_conv3x3_args* args, void* stream);
 

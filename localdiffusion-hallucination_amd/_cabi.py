@@ -33,7 +33,8 @@ class Src(C.Structure):
 class Conv3x3Args(C.Structure):
     _fields_ = [("src", Src * 2), ("nsrc", i32), ("weight", vp), ("bias", vp), ("out", vp),
                 ("out_stats", vp), ("out_groups", i32), ("B", i32), ("H", i32), ("W", i32),
-                ("Cout", i32), ("t_ptr", vp), ("dtype", i32), ("addend", vp), ("weight_terms", i32)]
+                ("Cout", i32), ("t_ptr", vp), ("dtype", i32), ("addend", vp), ("weight_terms", i32),
+                ("side_weight", vp), ("side_bias", vp), ("side_out", vp)]
 
 
 class Conv1x1Args(C.Structure):

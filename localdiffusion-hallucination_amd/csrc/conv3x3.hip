@@ -37,18 +37,18 @@ namespace {
 int g_span_shape[1024][5];
 #endif
 
-template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
+template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false, bool SIDE = false>
 int launch_dbg(const Conv3Dev& a, hipStream_t st) {
   constexpr int TR = 4 * NW, HR = TR + 2, HC = 18;
   constexpr int NPIXP = (HR * HC + 15) / 16 * 16;
   const int ctot = a.s[0].C + (a.nsrc > 1 ? a.s[1].C : 0);
-  const size_t lds = (SK ? 2 : 1) * (4 * NPIXP * 16 + 9 * MT * 1024) + 2 * ctot * sizeof(float) + 4 * 2 * 16 * MT * sizeof(double);
+  const size_t lds = (SK ? 2 : 1) * (4 * NPIXP * 16 + (9 + (SIDE ? 1 : 0)) * MT * 1024) + 2 * ctot * sizeof(float) + 4 * 2 * 16 * MT * sizeof(double);
   Conv3Dev d = a;
   d.tiles_x = (a.W + 15) / 16;
   const int tiles_y = (a.H + TR - 1) / TR;
   dim3 grid(d.tiles_x * tiles_y, a.Cout / (16 * MT), a.B);
-  if (lds > 65536) LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>, lds));   // cached per device
-  LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW>), grid, dim3(SK ? 512 : 256), lds, st, d.s[0].data, d.w, d.H, d.W, d.tiles_x,
+  if (lds > 65536) LD_HIP(ld_allow_lds(conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW, SIDE>, lds));   // cached per device
+  LD_LAUNCH((conv3x3_kernel<T, MT, NW, DEEP, DBG, SK, RAW, SIDE>), grid, dim3(SK ? 512 : 256), lds, st, d.s[0].data, d.w, d.H, d.W, d.tiles_x,
             d.s[0].C, d.s[0].ld, d.s[0].ups, d.nsrc, d.wsplit, d.Cout, d);
   LD_LAUNCH_CHECK("conv3x3");
   return LD_OK;
@@ -129,6 +129,14 @@ int dispatch(const Conv3Dev& a, hipStream_t st) {
   // 25.5 -> 22.5, 512->256 46.0 -> 37.6; four-chunk launches and grids beyond one workgroup per CU lose.  Over a
   // step: +0.6 % for one batch of 8 on one stream, -1 % with two concurrent sub-batches (the second stream already
   // fills the gaps this variant closes), hence off by default.
+  if constexpr (sizeof(T) == 2) {
+    // SIDE: the block's res_conv as a second output (ld_conv3x3_args.side_*): RAW launches on the register tiles below 16 fragments
+    // (<2,2>, <4,2>): a launch that would take a 16-row tile takes the 8-row tile of its channel width instead
+    if (a.w2) {       // (<2,4> with the side accumulators does not fit 168 registers: 156 bytes of scratch -- not instantiated)
+      if (mt4) return launch_dbg<T, 4, 2, false, 0, false, true, true>(a, st);
+      return launch_dbg<T, 2, 2, false, 0, false, true, true>(a, st);
+    }
+  }
   const int force_sk = (int)tn.conv_sk;
   const long sk_max_wgs = tn.conv_sk_max_wgs;
   bool sk = force_sk >= 1 && sizeof(T) == 2 && !big && !deep && ((nch >= 8 && wg <= sk_max_wgs) || force_sk == 2);
@@ -193,6 +201,14 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   a.ogroups = p->out_groups > 0 ? p->out_groups : 1;
   a.B = p->B; a.H = p->H; a.W = p->W; a.Cout = p->Cout; a.t_ptr = p->t_ptr; a.tiles_x = 0;
   a.addend = p->addend;
+  a.w2 = p->side_weight; a.bias2 = p->side_bias; a.out2 = p->side_out;
+  if (p->side_weight) {
+    LD_REQUIRE(ld_dtype_16(p->dtype), "ld_conv3x3: the side (res_conv) output needs 16-bit storage");
+    LD_REQUIRE(p->side_bias && p->side_out, "ld_conv3x3: side_weight without side_bias / side_out");
+    LD_REQUIRE(p->weight_terms != 2 && !p->addend, "ld_conv3x3: the side output does not combine with two-term weights or an addend");
+    for (int s = 0; s < p->nsrc; ++s)
+      LD_REQUIRE(!p->src[s].gn_stats && !p->src[s].upsample, "ld_conv3x3: the side output needs raw, un-resampled sources (a ResnetBlock's block1)");
+  }
   LD_REQUIRE(p->weight_terms >= 0 && p->weight_terms <= 2 && !(p->weight_terms == 2 && !ld_dtype_16(p->dtype)),
              "ld_conv3x3: weight_terms %d (2 needs 16-bit storage)", p->weight_terms);
   a.wsplit = p->weight_terms == 2 ? 1 : 0;
@@ -209,6 +225,10 @@ extern "C" int ld_conv3x3(const ld_conv3x3_args* p, void* stream) {
   }
 #endif
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (p->side_weight) {         // (only the generic kernel has the side output)
+    ld_count(LD_COUNTER_CONV3X3_GENERIC);
+    return LD_DISPATCH16(p->dtype, dispatch<T>(a, st));
+  }
   if (p->weight_terms != 2) {   // (the persistent kernel keeps ONE chunk of weights in registers)
     const int rc = ld_conv3x3_c32_try(p, st);        // persistent LDS-DMA kernel for the Cout=32 stages (>= 2,048 tiles)
     if (rc != 0) return rc < 0 ? rc : LD_OK;

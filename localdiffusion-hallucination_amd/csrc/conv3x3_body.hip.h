@@ -13,6 +13,9 @@ struct Conv3Dev {    // pointers together, scalars together: the argument block 
   double* ostats;
   const int* t_ptr;
   const void* addend;
+  const void* w2;      // SIDE: the ResnetBlock's res_conv (1x1 over the same concatenated input, ddpm.py:198) as a second output of this launch
+  const float* bias2;  //   packed like a 1x1 weight ([chunk][cout-tile][kq][row][e]: one fragment per m-tile and chunk), its bias,
+  void* out2;          //   and where res_conv(x) + bias2 goes (NHWC [B,H,W,Cout], no statistics)
   int nsrc;
   int ogroups;
   int B, H, W, Cout;
@@ -41,8 +44,14 @@ __device__ unsigned long long g_conv_span[1024][2];
 // those scalar tests, branches and register copies sit on the chunk loop's critical path (DESIGN finding 42).
 // The kernel body as a device function of the (virtual) workgroup index: conv3x3_kernel calls it with its own index,
 // the archived stage-program experiment (tools/experiments/stage_programs.hip) with the tiles it takes from its work counter.
+// SIDE (round 6; RAW launches of 16-bit storage, register tiles below 16 fragments): the block's res_conv -- a 1x1 convolution of the
+// SAME concatenated input (ddpm.py:198, 212) -- rides in this launch.  Its B operand is the centre tap's activation fragment, which
+// is in registers anyway; per chunk it costs one more weight fragment per m-tile (1 KB of the 18-36 KB a chunk stages) and MT * NW
+// of the chunk's 9 * MT * NW + MT * NW MFMAs.  The block's tail then needs no GEMM of its own: `out = res_conv(x) + SiLU(GN(h2))` was a
+// conv1x1 launch walking the block's 6-12 input chunks a second time (12-14 us at 32^2 where gn_apply takes 4.5), and x / skip die
+// after block1 instead of after the tail (the pool's peak live set: six 256^2 tensors -> five).
 typedef const Conv3Dev __attribute__((address_space(4)))* Conv3KernargPtr;   // the block in kernel-argument (constant) memory: scalar loads
-template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
+template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false, bool SIDE = false>
 __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargPtr rest, const int bx, const int by, const int bz,
                                              const int gdx, const int gdz, char* smem) {
   // `head`: the fields the first requests need (conv3x3_kernel's preloaded arguments; everything else unset).  `rest`:
@@ -56,10 +65,12 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
   constexpr int UNITS = 9 * MT * 64, WU = (UNITS + 255) / 256;
   constexpr bool P = DT<T>::precise;
 
-  constexpr int STAGE = 4 * PLANE + 9 * MT * 1024;         // one half's staging buffers
+  static_assert(!SIDE || (RAW && !SK && !DEEP && MT * NW < 16 && sizeof(T) == 2), "SIDE: RAW 16-bit launches of the small register tiles");
+  constexpr int STAGE = 4 * PLANE + (9 + (SIDE ? 1 : 0)) * MT * 1024;         // one half's staging buffers (+ the res_conv fragments)
   const int half = SK ? (int)(threadIdx.x >> 8) : 0;       // wave-uniform
   char* s_x = smem + half * STAGE;
   char* s_w = s_x + 4 * PLANE;
+  char* s_w2 = s_w + 9 * MT * 1024;                        // SIDE
   float* s_coef = reinterpret_cast<float*>(smem + (SK ? 2 : 1) * STAGE);
   // (everything in front of the first requests is computed from the PRELOADED arguments only -- conv3x3_kernel: scalar
   //  loads return out of order, so the first use of ANY field of the argument block waits for all of it; the fields of
@@ -92,6 +103,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
   // (halo fragments + weight fragments) are issued before the MFMAs of chunk k and written to LDS
   // after them, so a workgroup pays ONE exposed global round trip instead of one per chunk.
   uint4 hxA[ITER], wxA[WU], hxB[DEEP ? ITER : 1], wxB[DEEP ? WU : 1];   // B set: prefetch distance 2 (DEEP)
+  uint4 wx2 = make_uint4(0u, 0u, 0u, 0u);                               // SIDE: this thread's 16 bytes of the chunk's res_conv fragments (tid < 64 MT)
   // Loop-invariant addressing (with one wave per SIMD every VALU instruction in the chunk loop is on the
   // critical path, PMC: MFMA busy ~20 % of wave cycles): per-thread element offsets of the halo pixels for
   // both source geometries and of the weight units are computed once; a chunk only adds a scalar stride.
@@ -154,6 +166,9 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
       wx[k] = make_uint4(0u, 0u, 0u, 0u);
       if (woffb[k] != ~0u) wx[k] = *reinterpret_cast<const uint4*>(wc + woffb[k]);
     }
+    if constexpr (SIDE && !FIRST) {                       // (chunk 0's are requested behind the argument block: a.w2 is not a preloaded argument)
+      if (tid < MT * 64) wx2 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w2) + ((long)ch * mt_total + m0) * 1024 + tid * 16);
+    }
     if (!same_halo) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
@@ -184,6 +199,9 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
     for (int k = 0; k < WU; ++k) {
       const int u = k * 256 + tid;
       if (u < UNITS) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = wx[k];
+    }
+    if constexpr (SIDE) {
+      if (tid < MT * 64) *reinterpret_cast<uint4*>(s_w2 + tid * 16) = wx2;
     }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -219,6 +237,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
     a.s[0].film_bstride = pr->s[0].film_bstride;
     a.bias = pr->bias; a.out = pr->out; a.ostats = pr->ostats; a.t_ptr = pr->t_ptr; a.addend = pr->addend;
     a.ogroups = pr->ogroups; a.B = pr->B; a.dbg = pr->dbg;
+    if constexpr (SIDE) { a.w2 = pr->w2; a.bias2 = pr->bias2; a.out2 = pr->out2; }
   }
   if constexpr (!SK) second_source();
   {
@@ -232,6 +251,13 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
   float4 bias[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) bias[m] = *reinterpret_cast<const float4*>(a.bias + (m0 + m) * 16 + kq * 4);
+  float4 bias2[SIDE ? MT : 1];
+  if constexpr (SIDE) {
+    asm volatile("" ::"s"(a.w2), "s"(a.bias2), "s"(a.out2));
+    if (tid < MT * 64) wx2 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.w2) + (long)m0 * 1024 + tid * 16);   // chunk 0
+#pragma unroll
+    for (int m = 0; m < MT; ++m) bias2[m] = *reinterpret_cast<const float4*>(a.bias2 + (m0 + m) * 16 + kq * 4);
+  }
 
   // ---- prologue coefficients (overlaps the loads above)
   {
@@ -252,10 +278,14 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
 
   TR_STAMP(3);
   f32x4 acc[MT][NW];
+  f32x4 acc2[SIDE ? MT : 1][SIDE ? NW : 1];                // SIDE: res_conv's accumulators
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int j = 0; j < NW; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NW; ++j) {
+      acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (SIDE) acc2[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
   // LDS fragment reads are software-pipelined against the MFMAs: all fragments of tap column dx+1 (3*MT
   // weight + NW+2 activation fragments) are requested before the MFMAs of column dx issue, so the ~100-cycle
@@ -311,6 +341,11 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
         Bq[set][rr] = *reinterpret_cast<const uint4*>(s_x + kq * PLANE + (((wv * NW + rr) * HC + dx + px) * 16));
     };
     load_frags(0, 0);
+    uint4 A2[SIDE ? MT : 1];
+    if constexpr (SIDE) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) A2[m] = *reinterpret_cast<const uint4*>(s_w2 + m * 1024 + lane * 16);
+    }
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
       if (dx + 1 < 3) load_frags(dx + 1, (dx + 1) & 1);
@@ -322,6 +357,12 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
           if (j >= 0 && j < NW) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) mma16<T>(acc[m][j], A[dx & 1][dy][m], Bq[dx & 1][rr]);
+            if constexpr (SIDE) {                           // the centre tap's activation fragment IS the 1x1 convolution's operand
+              if (dx == 1 && dy == 1) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) mma16<T>(acc2[m][j], A2[m], Bq[dx & 1][rr]);
+              }
+            }
           }
         }
       }
@@ -486,6 +527,27 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
   };
   if (rows_in && !a.addend && half == 0) emit(std::true_type{});
   else emit(std::false_type{});
+  if constexpr (SIDE) {       // res_conv(x) + bias2 -> out2: the same fragment pairs, the same write-through stores, no statistics
+    char* out2b = reinterpret_cast<char*>(a.out2) + obase * (long)sizeof(T);
+#pragma unroll
+    for (int m = 0; m < MT; m += 2) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const int gy = ty0 + wv * NW + j;
+        const bool valid = rows_in || (gy < H && gx < W);
+        float v[2][4];
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          const float4 bv = bias2[m + mm];
+          v[mm][0] = acc2[m + mm][j][0] + bv.x; v[mm][1] = acc2[m + mm][j][1] + bv.y;
+          v[mm][2] = acc2[m + mm][j][2] + bv.z; v[mm][3] = acc2[m + mm][j][3] + bv.w;
+        }
+        const uint4 w16 = pair_frag16<T>(v[0], v[1]);
+        const unsigned off = lane_off - kq * 4 * (unsigned)sizeof(T) + j * row_off + m * 16 * (unsigned)sizeof(T) + pair_frag16_off(kq);
+        if (valid) store16_out(out2b + off, w16);
+      }
+    }
+  }
   TR_STAMP(9);
   if (a.ostats) {
     __syncthreads();                            // s_stat may still be read as build_gn_coef scratch
@@ -577,7 +639,7 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
 // (up to 14 dwords) into SGPRs before the wave starts and the halo / weight requests leave without a scalar round trip
 // in front of them (a by-value struct is never preloaded: finding 67).  The rest of the block (`rest`: second source,
 // GroupNorm operands, bias, outputs) is fetched in ONE batch that is pinned BEHIND those requests (conv3x3_tile).
-template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false>
+template <typename T, int MT, int NW, bool DEEP, int DBG, bool SK = false, bool RAW = false, bool SIDE = false>
 __global__ __launch_bounds__(SK ? 512 : 256) __attribute__((amdgpu_waves_per_eu(SK ? 2 : (MT == 2 ? 3 : 1), SK ? 2 : (MT == 2 ? 3 : 2))))
 void conv3x3_kernel(const void* data0, const void* w, int H, int W, int tiles_x, int C0, int ld0, int ups0, int nsrc, int wsplit, int Cout,
                     Conv3Dev rest) {
@@ -595,7 +657,7 @@ void conv3x3_kernel(const void* data0, const void* w, int H, int W, int tiles_x,
     a.tiles_x = tiles_x;
     conv3x3_tile<T, MT, NW, DEEP, DBG, SK, RAW>(a, nullptr, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z, smem);
   } else {
-    conv3x3_tile<T, MT, NW, DEEP, DBG, SK, RAW>(a, pr, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z, smem);
+    conv3x3_tile<T, MT, NW, DEEP, DBG, SK, RAW, SIDE>(a, pr, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.z, smem);
   }
 }
 

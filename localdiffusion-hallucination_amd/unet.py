@@ -289,7 +289,7 @@ class Unet(nn.Module):
         #  not silently keep plans built under the old one -- ADVICE r4)
         tn = self.tuning
         key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels,
-               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse, tn.recompute_stem, tn.pool_by_size, tn.pool_verify)
+               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.side_res_conv, tn.side_res_conv_max_px, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse, tn.recompute_stem, tn.pool_by_size, tn.pool_verify)
         if key not in self._plans:
             self._plans[key] = _Plan(self, B, H, W, table_T)
         return self._plans[key]
@@ -621,7 +621,9 @@ class _Plan:
             self.meta[len(ops) - 1] = dict(what=what, family=what, bytes=nbytes, flops=flops)
             self.decl[len(ops) - 1] = ([t for t in reads if t is not None], [t for t in writes if t is not None])
 
-    def conv3(self, ops, srcs, wname, cout, h, w, stats=None, groups=8, weight=None, bias=None, addend=None):
+    def conv3(self, ops, srcs, wname, cout, h, w, stats=None, groups=8, weight=None, bias=None, addend=None, side=None):
+        """``side`` = (packed 1x1 weight, bias): the ResnetBlock's res_conv over the same input as a second output of the launch
+        (ld_conv3x3_args.side_*); returns (out, side_out) then."""
         a = cabi.Conv3x3Args()
         for i, s in enumerate(srcs):
             a.src[i] = s
@@ -634,6 +636,11 @@ class _Plan:
         self.keep += [weight, bias, addend]
         out = self.buf(h, w, cout)
         a.out = out.data_ptr()
+        side_out = None
+        if side is not None:
+            side_out = self.buf(h, w, cout)
+            a.side_weight, a.side_bias, a.side_out = side[0].data_ptr(), side[1].data_ptr(), side_out.data_ptr()
+            self.keep += [side[0], side[1]]
         if stats is not None:
             a.out_stats, a.out_groups = stats.data_ptr(), groups
         a.B, a.H, a.W, a.Cout = self.B, h, w, cout
@@ -646,9 +653,13 @@ class _Plan:
         big = blocks16 >= 512 and h >= 16 and not mt4
         big = big or (mt4 and h >= 16 and blocks16 >= self._kt("conv_big4_min"))    # mirrors conv3x3.hip:dispatch
         dname = {cabi.LD_F32: "f32", cabi.LD_BF16: "bf16", cabi.LD_F16: "f16"}[self.dt]
+        if side is not None:
+            big = False                                # mirrors conv3x3.hip:dispatch (the side output rides on the 8-row tiles)
         fam = f"conv3x3<{dname},{4 if mt4 else 2},{4 if big else 2}>"
         ck = 16 if self.dt == cabi.LD_F32 else 32
-        if (cout == 32 and len(srcs) == 1 and cin == ck and addend is None and h >= 32 and w >= 32 and h % 16 == 0
+        if side is not None:
+            pass                                       # (only the generic kernel has the side output)
+        elif (cout == 32 and len(srcs) == 1 and cin == ck and addend is None and h >= 32 and w >= 32 and h % 16 == 0
                 and w % 16 == 0 and (w // 16) * (h // 16) * self.B >= self._kt("conv_c32_min_tiles")
                 and self._kt("conv_c32") and a.weight_terms != 2):
             fam = f"conv3x3_c32<{dname}>"              # the persistent LDS-DMA kernel takes it (conv3x3_c32.hip)
@@ -660,11 +671,14 @@ class _Plan:
             if (self._kt("conv_s32") & bit) and (not pro or (len(srcs) == 1 and srcs[0].C == 32 and srcs[0].gn_groups == 8)):
                 fam = f"conv3x3_s32<{dname}>"
         in_el = sum(s.C * (npx // 4 if s.upsample else npx) for s in srcs)
-        self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname,
-                   dict(family=fam, bytes=(in_el + npx * cout + 9 * cin * cout) * self.esize + 4 * cout,
-                        flops=2 * 9 * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"),
-                   reads=[s._tensor for s in srcs] + [addend], writes=[out])
-        return out
+        # (algorithmic bytes / flops, SURVEY 8d: with a side output the launch also carries res_conv's -- its input, read here once
+        #  for both, counted for both as the reference's two modules would)
+        side_b = (in_el + npx * cout + cin * cout) * self.esize + 4 * cout if side is not None else 0
+        self._call(ops, self.lib.ld_conv3x3, a, "conv3x3 " + wname + (" + res_conv" if side is not None else ""),
+                   dict(family=fam, bytes=(in_el + npx * cout + 9 * cin * cout) * self.esize + 4 * cout + side_b,
+                        flops=2 * (9 + (1 if side is not None else 0)) * cin * cout * npx, shape=f"{cin}->{cout}@{h}x{w}"),
+                   reads=[s._tensor for s in srcs] + [addend], writes=[out, side_out])
+        return out if side is None else (out, side_out)
 
     def conv1(self, ops, srcs, weight, cout, h, w, bias=None, epi=cabi.EPI_PLAIN, unshuffle=0, rms_in=0,
               bstride=0, g2=None, residual=None, what="conv1x1", out=None, kmax_out=None, gn_tail=None):
@@ -746,7 +760,18 @@ class _Plan:
         concatenated tensors); ``res_tensor`` is the single input tensor when cin == cout."""
         f, G = self.f32, self.cfg.resnet_block_groups
         s1, s2 = self.slot(), self.slot()
-        raw1 = self.conv3(ops, srcs_fn(), p + ".block1.proj", cout, h, w, stats=s1, groups=G)
+        # res_conv in block1's launch (round 6, 16-bit storage, one-term weights, maps up to side_res_conv_max_px): the tail below
+        # is then a gn_apply with res_conv(x) as its second operand instead of a conv1x1 that walks the block's input a second time
+        wres = self.P["w"].get(p + ".res_conv.weight")
+        side = None
+        if (wres is not None and self.tn.side_res_conv and self.dt != cabi.LD_F32 and h * w <= self.tn.side_res_conv_max_px
+                and wres.data_ptr() not in self.P["terms2"] and self.P["w"][p + ".block1.proj.weight"].data_ptr() not in self.P["terms2"]):
+            side = (wres, f[p + ".res_conv.bias"])
+        rc = None
+        if side is not None:
+            raw1, rc = self.conv3(ops, srcs_fn(), p + ".block1.proj", cout, h, w, stats=s1, groups=G, side=side)
+        else:
+            raw1 = self.conv3(ops, srcs_fn(), p + ".block1.proj", cout, h, w, stats=s1, groups=G)
         film = self.films.get(p)
         n1 = self.src(raw1, cout, gn=(s1, f[p + ".block1.norm.weight"], f[p + ".block1.norm.bias"], G),
                       act=cabi.ACT_SILU, film=film)
@@ -760,7 +785,9 @@ class _Plan:
         raw2 = self.conv3(ops, [n1], p + ".block2.proj", cout, h, w, stats=s2, groups=G)
         n2 = self.src(raw2, cout, gn=(s2, f[p + ".block2.norm.weight"], f[p + ".block2.norm.bias"], G),
                       act=cabi.ACT_SILU)
-        if (p + ".res_conv.weight") in f:
+        if rc is not None:
+            out = self.gn_apply(ops, n2, self.src(rc, cout), h, w, cout)          # out = SiLU(GN(raw2)) + res_conv(x)
+        elif (p + ".res_conv.weight") in f:
             # block tail fused into the res_conv epilogue: out = res_conv(x) + SiLU(GN(raw2))
             out = self.conv1(ops, srcs_fn(), self.P["w"][p + ".res_conv.weight"], cout, h, w,
                              bias=f[p + ".res_conv.bias"], epi=cabi.EPI_GN_TAIL, gn_tail=n2, what="res_conv+tail " + p)

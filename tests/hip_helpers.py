@@ -58,7 +58,8 @@ def make_src(t, c, stride=0, ups=0, gn=None, act=0, film=None, film_b=0, film_t=
     return s
 
 
-def conv3x3(srcs, wpacked, bias, B, H, W, cout, dtype, stats=None, groups=8, t_ptr=None):
+def conv3x3(srcs, wpacked, bias, B, H, W, cout, dtype, stats=None, groups=8, t_ptr=None, side=None):
+    """``side`` = (packed 1x1 weight, bias): returns (out, side_out)."""
     a = cabi.Conv3x3Args()
     for i, s in enumerate(srcs):
         a.src[i] = s
@@ -70,8 +71,12 @@ def conv3x3(srcs, wpacked, bias, B, H, W, cout, dtype, stats=None, groups=8, t_p
         a.out_stats, a.out_groups = stats.data_ptr(), groups
     a.B, a.H, a.W, a.Cout, a.dtype = B, H, W, cout, cabi.dtype_code(dtype)
     a.t_ptr = cabi.ptr(t_ptr)
+    side_out = None
+    if side is not None:
+        side_out = torch.empty(B, H, W, cout, dtype=TDT[dtype], device=DEV)
+        a.side_weight, a.side_bias, a.side_out = side[0].data_ptr(), side[1].data_ptr(), side_out.data_ptr()
     cabi.check(cabi.lib().ld_conv3x3(C.byref(a), st()), "conv3x3")
-    return out
+    return out if side is None else (out, side_out)
 
 
 def conv1x1(srcs, wpacked, B, H, W, cout, dtype, bias=None, epi=0, unshuffle=0, rms_in=0, bstride=0, g2=None,

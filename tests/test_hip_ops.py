@@ -40,6 +40,31 @@ def test_conv3x3_plain_and_stats(dtype, B, cin, cout, H, W):
     assert hh.rel_err(stats.sum(1).cpu(), sref) < (1e-5 if dtype == "fp32" else 1e-2)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,c1,c2,cout,H,W", [(2, 256, 128, 256, 16, 16), (1, 128, 64, 128, 24, 40), (2, 64, 32, 64, 17, 23), (3, 32, 32, 32, 32, 16)])
+def test_conv3x3_with_the_res_conv_as_a_side_output(dtype, B, c1, c2, cout, H, W):
+    """ld_conv3x3_args.side_*: a ResnetBlock's res_conv (a 1x1 convolution of the same concatenated input, ddpm.py:198, 212) as a
+    second output of its block1 convolution's launch.  Both outputs against fp32 F.conv2d; the 3x3 output and its statistics
+    bit-equal to the launch without the side output where the tile variant is the same; ragged tiles, 32- and 64-channel tiles."""
+    x1, x2 = _q(hh.rand((B, c1, H, W), 40), dtype), _q(hh.rand((B, c2, H, W), 41), dtype)
+    w, b = _q(hh.rand((cout, c1 + c2, 3, 3), 42, -0.1, 0.1), dtype), hh.rand((cout,), 43)
+    wr, br = _q(hh.rand((cout, c1 + c2, 1, 1), 44, -0.1, 0.1), dtype), hh.rand((cout,), 45)
+    xc = torch.cat([x1, x2], 1)
+    ref, ref_side = F.conv2d(xc, w, b, padding=1), F.conv2d(xc, wr, br)
+    srcs = lambda: [hh.make_src(hh.nhwc(x1, dtype), c1), hh.make_src(hh.nhwc(x2, dtype), c2)]
+    stats, stats0 = hh.stats_buffer(B, 8), hh.stats_buffer(B, 8)
+    out, side = hh.conv3x3(srcs(), hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype, stats=stats, groups=8,
+                           side=(hh.pack(wr, dtype, 1), br.to(hh.DEV)))
+    out0 = hh.conv3x3(srcs(), hh.pack(w, dtype, 3), b.to(hh.DEV), B, H, W, cout, dtype, stats=stats0, groups=8)
+    assert hh.rel_err(hh.nchw(out), ref) < hh.RTOL[dtype] and hh.rel_err(hh.nchw(side), ref_side) < hh.RTOL[dtype]
+    assert hh.rel_err(stats.sum(1).cpu(), hh.gn_stats_ref(ref, 8)) < 1e-2
+    # the taps arrive in the same order per accumulator whatever the tile: the 3x3 output does not change
+    assert torch.equal(out, out0)
+    # ... and the side output is the 1x1 kernel's result for the same operands (same chunk order, same MFMA)
+    side1 = hh.conv1x1(srcs(), hh.pack(wr, dtype, 1), B, H, W, cout, dtype, bias=br.to(hh.DEV))
+    assert torch.equal(side, side1)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_concat_upsample(dtype):
     B, c1, c2, cout, H, W = 2, 64, 32, 32, 12, 12
