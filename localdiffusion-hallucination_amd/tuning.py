@@ -33,7 +33,8 @@ class Tuning:
     sep_act_min_c: int = 128             # ... with at least this many channels
     fusion_fold: bool = True             # conv_fusion's conditioning halves evaluated once per sample (16-bit storage)
     side_res_conv: bool = True           # a ResnetBlock's res_conv rides in its block1 convolution's launch (16-bit storage); the tail is a gn_apply
-    side_res_conv_max_px: int = 128 * 128   # ... on maps of at most this many pixels (at 256^2 the 16-row tile has no room for the side accumulators)
+    side_res_conv_max_px: int = 64 * 64  # ... on maps of at most this many pixels (measured: 32^2 and 64^2 win; at 128^2 the launch leaves the 64 x 16-row tile and loses, at 256^2 the 16-row tile has no registers for the side accumulators)
+    side_res_conv_px: Optional[Tuple[int, ...]] = None   # experiments: exactly these map sizes (pixels) instead of the max_px rule
     linattn_chunk_px: Optional[Tuple[int, int, int]] = None   # kvctx chunk pixels for n >= 65536 / n >= 16384 / smaller (None: by batch)
     graph_prewarm: bool = True           # a captured graph is launched once where it is captured (the first launch completes its set-up)
     pool_by_size: bool = True            # pool placement: largest buffers first (False: by first use; 9 % more pool at the bench shape)
@@ -53,6 +54,7 @@ class Tuning:
         "LD_NO_SEPARATE_ACT": ("separate_act", lambda v: False),
         "LD_NO_FUSION_FOLD": ("fusion_fold", lambda v: False),
         "LD_NO_SIDE_RES_CONV": ("side_res_conv", lambda v: False), "LD_SIDE_RES_CONV_MAX_PX": ("side_res_conv_max_px", int),
+        "LD_SIDE_RES_CONV_PX": ("side_res_conv_px", lambda v: tuple(int(x) for x in v.split(","))),
         "LD_NO_GRAPH_PREWARM": ("graph_prewarm", lambda v: False),
         "LD_POOL_BY_START": ("pool_by_size", lambda v: False),
         "LD_RECOMPUTE_STEM": ("recompute_stem", lambda v: v not in ("0", "")),

@@ -289,7 +289,7 @@ class Unet(nn.Module):
         #  not silently keep plans built under the old one -- ADVICE r4)
         tn = self.tuning
         key = (B, H, W, table_T, self.compute_dtype, instance, self.weight_split_levels,
-               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.side_res_conv, tn.side_res_conv_max_px, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse, tn.recompute_stem, tn.pool_by_size, tn.pool_verify)
+               tn.separate_act, tn.sep_act_max_px, tn.sep_act_min_c, tn.fusion_fold, tn.side_res_conv, tn.side_res_conv_max_px, tn.side_res_conv_px, tn.fused_step_begin, tn.linattn_chunk_px, tn.buffer_reuse, tn.recompute_stem, tn.pool_by_size, tn.pool_verify)
         if key not in self._plans:
             self._plans[key] = _Plan(self, B, H, W, table_T)
         return self._plans[key]
@@ -764,7 +764,8 @@ class _Plan:
         # is then a gn_apply with res_conv(x) as its second operand instead of a conv1x1 that walks the block's input a second time
         wres = self.P["w"].get(p + ".res_conv.weight")
         side = None
-        if (wres is not None and self.tn.side_res_conv and self.dt != cabi.LD_F32 and h * w <= self.tn.side_res_conv_max_px
+        px_ok = (h * w in self.tn.side_res_conv_px) if self.tn.side_res_conv_px is not None else h * w <= self.tn.side_res_conv_max_px
+        if (wres is not None and self.tn.side_res_conv and self.dt != cabi.LD_F32 and px_ok
                 and wres.data_ptr() not in self.P["terms2"] and self.P["w"][p + ".block1.proj.weight"].data_ptr() not in self.P["terms2"]):
             side = (wres, f[p + ".res_conv.bias"])
         rc = None

@@ -19,7 +19,7 @@ def test_host_defaults_are_the_measured_ones():
     t = Tuning.from_env(env={})
     assert t.describe() == dict(sub_batches=2, min_sub_batch=2, sub_resync=32, sub_resync_early=1, sub_ahead=2, sub_joint_graph=False,
                                 fused_final_step=True, fused_step_begin=True, weight_split_levels=0, separate_act=True, sep_act_max_px=1024,
-                                sep_act_min_c=128, fusion_fold=True, side_res_conv=True, side_res_conv_max_px=16384, linattn_chunk_px=None, graph_prewarm=True, pool_by_size=True, recompute_stem=False, buffer_reuse=True, pool_verify=False, kernel={})
+                                sep_act_min_c=128, fusion_fold=True, side_res_conv=True, side_res_conv_max_px=4096, side_res_conv_px=None, linattn_chunk_px=None, graph_prewarm=True, pool_by_size=True, recompute_stem=False, buffer_reuse=True, pool_verify=False, kernel={})
     assert t.chunk_rule(4) == (512, 256, 128) and t.chunk_rule(8) == (512, 256, 128) and t.chunk_rule(32) == (1024, 256, 128)
 
 
