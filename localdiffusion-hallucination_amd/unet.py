@@ -765,7 +765,9 @@ class _Plan:
         wres = self.P["w"].get(p + ".res_conv.weight")
         side = None
         px_ok = (h * w in self.tn.side_res_conv_px) if self.tn.side_res_conv_px is not None else h * w <= self.tn.side_res_conv_max_px
-        if (wres is not None and self.tn.side_res_conv and self.dt != cabi.LD_F32 and px_ok
+        # (not in the accuracy mode: res_conv's output is rounded to the storage type on its way to the tail, one rounding the fused
+        #  tail does not have -- with two-term weights that rounding shows in the chain's max-abs distance, golden G16)
+        if (wres is not None and self.tn.side_res_conv and self.dt != cabi.LD_F32 and px_ok and self.net.weight_split_levels == 0
                 and wres.data_ptr() not in self.P["terms2"] and self.P["w"][p + ".block1.proj.weight"].data_ptr() not in self.P["terms2"]):
             side = (wres, f[p + ".res_conv.bias"])
         rc = None

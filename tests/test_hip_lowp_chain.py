@@ -104,8 +104,8 @@ def test_cfg2_chain_with_two_term_weights(golden, dtype):
 # is a few ulps of the image (quantised in steps of 1.2e-7).  Measured (printed by the test):
 #             through t = 100          final image (t = 0)
 #   fp32      1.2e-6 / 8.6e-8          2.2e-6 / 2.0e-7     (the reference against itself, 1 thread vs 8: 1.4e-6 / 1.9e-7)
-#   bf16      2.3e-3 / 3.7e-4          1.1e-2 / 7.4e-4
-#   fp16      3.8e-4 / 5.6e-5          2.1e-3 / 1.1e-4
+#   bf16      2.1e-3 / 3.8e-4          1.17e-2 / 7.5e-4    (before the side res_conv, finding 117: 2.3e-3 / 3.7e-4 and 1.125e-2 / 7.4e-4)
+#   fp16      3.9e-4 / 5.6e-5          2.0e-3 / 1.1e-4
 #   bf16x2    4.6e-4 / 5.1e-5          9.8e-3 / 6.9e-4     (two-term weights on two levels)
 #   fp16x2    5.2e-5 / 6.6e-6          1.4e-3 / 8.7e-5
 # What the last ten steps add in every 16-bit mode is the rounding of ONE evaluation's activations: the posterior weight of
