@@ -459,6 +459,10 @@ __device__ __forceinline__ void conv3x3_tile(const Conv3Dev& head, Conv3KernargP
   // (tools/scan_store_waits.py on the hipcc -S output).
 #pragma unroll
   for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(bias[m].x), "v"(bias[m].y), "v"(bias[m].z), "v"(bias[m].w));
+  if constexpr (SIDE) {                                     // ... the side output's bias too: its first use is behind the main output's stores
+#pragma unroll
+    for (int m = 0; m < MT; ++m) asm volatile("" ::"v"(bias2[m].x), "v"(bias2[m].y), "v"(bias2[m].z), "v"(bias2[m].w));
+  }
   const bool rows_in = ty0 + TR <= H && tx0 + TC <= W;      // workgroup-uniform: no ragged row / column in this tile
   // FULL: every pixel of the tile is inside the image and there is no addend (all but one launch of a cfg3 step): the
   // stores and the statistics run without per-fragment execution masks and selects.
